@@ -1,0 +1,126 @@
+/*
+ * include/pdmssd_hip.h — C ABI of libpdmssd_hip.so (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for PDM-SSD's point-cloud hot path.  Each entry point replaces one
+ * function of the reference's native extension `pointnet2_batch_cuda`
+ * (/root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-24); the
+ * reference-side line each one replaces is cited on the declaration.  Integer/float arguments keep
+ * the reference's names, order and meaning; tensors arrive as raw device pointers.
+ *
+ * Contract (differs from the reference only where the reference is unsafe):
+ *   - `stream` is a hipStream_t (NULL = the null stream).  The reference launches on the legacy
+ *     default stream with no device guard; here the caller picks the stream and the device is the
+ *     one current on the calling thread.  All calls are asynchronous, re-entrant and stateless.
+ *   - Ownership: the CALLER allocates and pre-initialises every output / scratch buffer exactly as
+ *     the reference's Python does (idx zero-filled for ball_query, temp filled with 1e10 for FPS,
+ *     grad buffers zero-filled); the callee only writes through the pointers it is given and
+ *     retains nothing.
+ *   - Errors: return 0 on success; a positive value is a hipError_t from the launch, a negative
+ *     value an argument error (PDM_E_*).  Nothing here ever calls exit() (the reference does:
+ *     ball_query_gpu.cu:68-72).  pdm_last_error() returns a thread-local message.
+ *   - All tensors are contiguous; data is fp32, indices are int32; 64-bit offsets internally.
+ *   - No host synchronisation, allocation or memcpy inside any call: every entry point is
+ *     hipGraph-capturable.
+ */
+#ifndef PDMSSD_HIP_H
+#define PDMSSD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDM_ABI_VERSION 1
+
+#define PDM_E_BADARG (-1)   /* negative size, null pointer, unsupported parameter */
+#define PDM_E_TOOLARGE (-2) /* size exceeds what the kernel's grid/indexing supports */
+
+int pdm_abi_version(void);
+const char *pdm_last_error(void);
+
+/* ---- pointnet2_batch operators ------------------------------------------------------------ */
+
+/* replaces ball_query_wrapper_fast            ball_query.cpp:29-39 -> ball_query_gpu.cu:15-73
+ * new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample), caller-zeroed. */
+int pdm_ball_query(void *stream, int b, int n, int m, float radius, int nsample,
+                   const float *new_xyz, const float *xyz, int *idx);
+
+/* replaces group_points_wrapper_fast          group_points.cpp:27-36 -> group_points_gpu.cu:53-92
+ * points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample). */
+int pdm_group_points(void *stream, int b, int c, int n, int npoints, int nsample,
+                     const float *points, const int *idx, float *out);
+
+/* replaces group_points_grad_wrapper_fast     group_points.cpp:15-24 -> group_points_gpu.cu:14-50
+ * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N), caller-zeroed, accumulated. */
+int pdm_group_points_grad(void *stream, int b, int c, int n, int npoints, int nsample,
+                          const float *grad_out, const int *idx, float *grad_points);
+
+/* replaces gather_points_wrapper_fast         sampling.cpp:14-22 -> sampling_gpu.cu:15-51
+ * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
+int pdm_gather_points(void *stream, int b, int c, int n, int npoints, const float *points,
+                      const int *idx, float *out);
+
+/* replaces gather_points_grad_wrapper_fast    sampling.cpp:25-34 -> sampling_gpu.cu:53-90 */
+int pdm_gather_points_grad(void *stream, int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points);
+
+/* replaces farthest_point_sampling_wrapper    sampling.cpp:37-46 -> sampling_gpu.cu:100-260
+ * points (B,N,3), temp (B,N) caller-filled with 1e10 (read as the initial min-distances and left
+ * holding the final ones) -> idx (B,m).  Tie order identical to the reference's block reduction
+ * for block_size = min(2^floor(log2 n), 1024). */
+int pdm_furthest_point_sampling(void *stream, int b, int n, int m, const float *points,
+                                float *temp, int *idx);
+
+/* replaces three_nn_wrapper_fast              interpolate.cpp:18-26 -> interpolate_gpu.cu:16-81
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) squared distances, idx (B,n,3). */
+int pdm_three_nn(void *stream, int b, int n, int m, const float *unknown, const float *known,
+                 float *dist2, int *idx);
+
+/* replaces three_interpolate_wrapper_fast     interpolate.cpp:29-41 -> interpolate_gpu.cu:84-124
+ * points (B,C,M), idx/weight (B,N,3) -> out (B,C,N). */
+int pdm_three_interpolate(void *stream, int b, int c, int m, int n, const float *points,
+                          const int *idx, const float *weight, float *out);
+
+/* replaces three_interpolate_grad_wrapper_fast interpolate.cpp:44-56 -> interpolate_gpu.cu:127-168
+ * grad_out (B,C,N) -> grad_points (B,C,M), caller-zeroed, accumulated. */
+int pdm_three_interpolate_grad(void *stream, int b, int c, int n, int m, const float *grad_out,
+                               const int *idx, const float *weight, float *grad_points);
+
+/* ---- fused forms of the same path (additions; same arithmetic, fewer passes over HBM) ------ */
+
+/* QueryAndGroup.forward as one call (pointnet2_utils.py:241-264, use_xyz=True):
+ * idx = ball_query (written, caller need not zero it), out[:,0:3] = xyz[idx] - new_xyz,
+ * out[:,3:3+C] = features[:, idx].  features (B,C,N) may be NULL when c == 0.
+ * out is (B, 3+C, M, nsample). */
+int pdm_query_and_group(void *stream, int b, int n, int m, int c, float radius, int nsample,
+                        const float *xyz, const float *new_xyz, const float *features, int *idx,
+                        float *out);
+
+/* ---- PDM neck (build-defined spec, DESIGN.md "PDM spec"; no reference source exists) ------- */
+
+/* Multi-centre scatter-add of dilated, SH x Gaussian weighted point features into a BEV grid.
+ * xyz (B,P,3), feat (B,P,C), sh (B,P,(degree+1)^2), inv2s2 (B,P); origin/cell/inv_cell are
+ * 3 floats each passed by value; grid dims W (x), H (y), D (z); dilation kx,ky,kz odd.
+ * layout 1: grid is (B,H,W,C*D) (channels-last storage of the logical (B,C*D,H,W) tensor,
+ * inner index c*D+z); layout 0: (B,C*D,H,W) contiguous.  wsum (B,H,W,D).  Both caller-zeroed. */
+int pdm_scatter_bev(void *stream, int B, int P, int C, int degree, const float *xyz,
+                    const float *feat, const float *sh, const float *inv2s2, float ox, float oy,
+                    float oz, float cx, float cy, float cz, float icx, float icy, float icz, int W,
+                    int H, int D, int kx, int ky, int kz, int layout, float *grid, float *wsum);
+
+/* grid[cell] /= wsum[cell] where |wsum| > eps */
+int pdm_bev_normalize(void *stream, int B, int C, int W, int H, int D, int layout, float eps,
+                      float *grid, const float *wsum);
+
+/* backward of pdm_scatter_bev w.r.t. feat, sh, inv2s2 (outputs fully written, no zero-fill needed);
+ * dwsum may be NULL. */
+int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const float *xyz,
+                         const float *feat, const float *sh, const float *inv2s2, float ox,
+                         float oy, float oz, float cx, float cy, float cz, float icx, float icy,
+                         float icz, int W, int H, int D, int kx, int ky, int kz, int layout,
+                         const float *dgrid, const float *dwsum, float *dfeat, float *dsh,
+                         float *dinv2s2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDMSSD_HIP_H */

@@ -1,0 +1,268 @@
+"""numpy/ctypes front end of the CPU oracle (oracle/pointnet2_oracle.c, oracle/pdm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under pdm_ssd_amd/ may import this module.
+
+Function names and argument order follow the reference's Python operator API
+(/root/reference/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py) so the parity tests read
+like calls into the reference.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpdmssd_oracle.so")
+_lib = None
+
+DIST_PINNED, DIST_NONE, DIST_HIPCC_DEFAULT = 0, 1, 2
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pdm_oracle.c", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "libpdmssd_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+def set_dist_mode(mode):
+    lib().oracle_set_dist_mode(int(mode))
+
+
+def set_threads(t):
+    lib().oracle_set_threads(int(t))
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def opt_n_threads(n):
+    return int(lib().oracle_opt_n_threads(int(n)))
+
+
+def furthest_point_sample(xyz, npoint, block_size=0, return_temp=False):
+    """xyz (B,N,3) -> idx (B,npoint) int32.  pointnet2_utils.py:12-29."""
+    xyz, px = _f(xyz)
+    B, N, _ = xyz.shape
+    temp = np.full((B, N), 1e10, dtype=np.float32)
+    idx = np.zeros((B, npoint), dtype=np.int32)
+    rc = lib().oracle_furthest_point_sampling(B, N, npoint, px, temp.ctypes.data_as(_f32p),
+                                              idx.ctypes.data_as(_i32p), int(block_size))
+    assert rc == 0
+    return (idx, temp) if return_temp else idx
+
+
+def gather_operation(features, idx):
+    """features (B,C,N), idx (B,M) -> (B,C,M).  pointnet2_utils.py:42-60."""
+    features, pf = _f(features)
+    idx, pi = _i(idx)
+    B, C, N = features.shape
+    M = idx.shape[1]
+    out = np.empty((B, C, M), dtype=np.float32)
+    lib().oracle_gather_points(B, C, N, M, pf, pi, out.ctypes.data_as(_f32p))
+    return out
+
+
+def gather_operation_grad(grad_out, idx, N):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    B, C, M = grad_out.shape
+    g = np.zeros((B, C, N), dtype=np.float32)
+    lib().oracle_gather_points_grad(B, C, N, M, pg, pi, g.ctypes.data_as(_f32p))
+    return g
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """-> idx (B,M,nsample) int32, zero rows for empty balls.  pointnet2_utils.py:203-221."""
+    xyz, px = _f(xyz)
+    new_xyz, pn = _f(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.zeros((B, M, nsample), dtype=np.int32)
+    lib().oracle_ball_query(B, N, M, ctypes.c_float(radius), int(nsample), pn, px,
+                            idx.ctypes.data_as(_i32p))
+    return idx
+
+
+def grouping_operation(features, idx):
+    """features (B,C,N), idx (B,M,ns) -> (B,C,M,ns).  pointnet2_utils.py:159-177."""
+    features, pf = _f(features)
+    idx, pi = _i(idx)
+    B, C, N = features.shape
+    _, M, ns = idx.shape
+    out = np.empty((B, C, M, ns), dtype=np.float32)
+    lib().oracle_group_points(B, C, N, M, ns, pf, pi, out.ctypes.data_as(_f32p))
+    return out
+
+
+def grouping_operation_grad(grad_out, idx, N):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    B, C, M, ns = grad_out.shape
+    g = np.zeros((B, C, N), dtype=np.float32)
+    lib().oracle_group_points_grad(B, C, N, M, ns, pg, pi, g.ctypes.data_as(_f32p))
+    return g
+
+
+def three_nn(unknown, known):
+    """-> (dist (B,n,3) = sqrt(dist2), idx (B,n,3)).  pointnet2_utils.py:79-98."""
+    unknown, pu = _f(unknown)
+    known, pk = _f(known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = np.empty((B, n, 3), dtype=np.float32)
+    idx = np.empty((B, n, 3), dtype=np.int32)
+    lib().oracle_three_nn(B, n, m, pu, pk, dist2.ctypes.data_as(_f32p), idx.ctypes.data_as(_i32p))
+    return np.sqrt(dist2), idx
+
+
+def three_nn_dist2(unknown, known):
+    unknown, pu = _f(unknown)
+    known, pk = _f(known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist2 = np.empty((B, n, 3), dtype=np.float32)
+    idx = np.empty((B, n, 3), dtype=np.int32)
+    lib().oracle_three_nn(B, n, m, pu, pk, dist2.ctypes.data_as(_f32p), idx.ctypes.data_as(_i32p))
+    return dist2, idx
+
+
+def three_interpolate(features, idx, weight):
+    """features (B,C,m), idx/weight (B,n,3) -> (B,C,n).  pointnet2_utils.py:111-131."""
+    features, pf = _f(features)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    B, C, m = features.shape
+    n = idx.shape[1]
+    out = np.empty((B, C, n), dtype=np.float32)
+    lib().oracle_three_interpolate(B, C, m, n, pf, pi, pw, out.ctypes.data_as(_f32p))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    B, C, n = grad_out.shape
+    g = np.zeros((B, C, m), dtype=np.float32)
+    lib().oracle_three_interpolate_grad(B, C, n, m, pg, pi, pw, g.ctypes.data_as(_f32p))
+    return g
+
+
+def query_and_group(radius, nsample, xyz, new_xyz, features=None):
+    """QueryAndGroup.forward with use_xyz=True (pointnet2_utils.py:241-264) -> (out (B,3+C,M,ns), idx)."""
+    xyz, px = _f(xyz)
+    new_xyz, pn = _f(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    if features is not None:
+        features, pf = _f(features)
+        C = features.shape[1]
+    else:
+        pf, C = None, 0
+    idx = np.zeros((B, M, nsample), dtype=np.int32)
+    out = np.empty((B, 3 + C, M, nsample), dtype=np.float32)
+    lib().oracle_query_and_group(B, N, M, C, ctypes.c_float(radius), int(nsample), px, pn, pf,
+                                 idx.ctypes.data_as(_i32p), out.ctypes.data_as(_f32p))
+    return out, idx
+
+
+# ----------------------------------------------------------------------------- PDM (build-defined spec)
+
+def pdm_grid_params(point_cloud_range, cell_size):
+    """fp32 origin / cell / inv_cell triple and integer dims (W,H,D) shared by oracle and product."""
+    r = np.asarray(point_cloud_range, dtype=np.float64)
+    cs = np.asarray(cell_size, dtype=np.float64)
+    dims = np.round((r[3:6] - r[0:3]) / cs).astype(np.int64)
+    origin = r[0:3].astype(np.float32)
+    cell = cs.astype(np.float32)
+    inv_cell = (np.float32(1.0) / cell).astype(np.float32)
+    return origin, cell, inv_cell, (int(dims[0]), int(dims[1]), int(dims[2]))
+
+
+def pdm_scatter(xyz, feat, sh, inv2s2, origin, cell, inv_cell, dims, kernel, degree, layout=1):
+    """-> (grid, wsum).  grid is (B,H,W,C*D) for layout 1 or (B,C*D,H,W) for layout 0; wsum (B,H,W,D)."""
+    xyz, px = _f(xyz)
+    feat, pf = _f(feat)
+    sh, ps = _f(sh)
+    inv2s2, pv = _f(inv2s2)
+    origin, po = _f(origin)
+    cell, pc = _f(cell)
+    inv_cell, pic = _f(inv_cell)
+    B, P, _ = xyz.shape
+    C = feat.shape[2]
+    W, H, D = dims
+    shape = (B, H, W, C * D) if layout == 1 else (B, C * D, H, W)
+    grid = np.zeros(shape, dtype=np.float32)
+    wsum = np.zeros((B, H, W, D), dtype=np.float32)
+    rc = lib().oracle_pdm_scatter(B, P, C, int(degree), px, pf, ps, pv, po, pc, pic, W, H, D,
+                                  int(kernel[0]), int(kernel[1]), int(kernel[2]), int(layout),
+                                  grid.ctypes.data_as(_f32p), wsum.ctypes.data_as(_f32p))
+    assert rc == 0, rc
+    return grid, wsum
+
+
+def pdm_normalize(grid, wsum, C, dims, layout=1, eps=1e-6):
+    W, H, D = dims
+    B = grid.shape[0]
+    grid = np.ascontiguousarray(grid, dtype=np.float32).copy()
+    wsum, pw = _f(wsum)
+    lib().oracle_pdm_normalize(B, C, W, H, D, int(layout), ctypes.c_float(eps),
+                               grid.ctypes.data_as(_f32p), pw)
+    return grid
+
+
+def pdm_scatter_grad(xyz, feat, sh, inv2s2, origin, cell, inv_cell, dims, kernel, degree, dgrid,
+                     dwsum=None, layout=1):
+    xyz, px = _f(xyz)
+    feat, pf = _f(feat)
+    sh, ps = _f(sh)
+    inv2s2, pv = _f(inv2s2)
+    origin, po = _f(origin)
+    cell, pc = _f(cell)
+    inv_cell, pic = _f(inv_cell)
+    dgrid, pg = _f(dgrid)
+    if dwsum is not None:
+        dwsum, pw = _f(dwsum)
+    else:
+        pw = None
+    B, P, _ = xyz.shape
+    C = feat.shape[2]
+    W, H, D = dims
+    dfeat = np.zeros_like(feat)
+    dsh = np.zeros_like(sh)
+    dinv = np.zeros((B, P), dtype=np.float32)
+    rc = lib().oracle_pdm_scatter_grad(B, P, C, int(degree), px, pf, ps, pv, po, pc, pic, W, H, D,
+                                       int(kernel[0]), int(kernel[1]), int(kernel[2]), int(layout),
+                                       pg, pw, dfeat.ctypes.data_as(_f32p),
+                                       dsh.ctypes.data_as(_f32p), dinv.ctypes.data_as(_f32p))
+    assert rc == 0, rc
+    return dfeat, dsh, dinv

@@ -1,0 +1,69 @@
+"""ctypes binding of libpdmssd_hip.so (the C ABI declared in include/pdmssd_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  Nothing here imports the CPU oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdmssd_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (after the leading `void *stream`); mirrors include/pdmssd_hip.h
+_SIGNATURES = {
+    "pdm_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp],
+    "pdm_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "pdm_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "pdm_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp],
+    "pdm_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp],
+    "pdm_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp],
+    "pdm_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdm_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdm_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdm_query_and_group": [_i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
+    "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
+    "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,
+}
+EXPORTS = ["pdm_abi_version", "pdm_last_error"] + list(_SIGNATURES)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libpdmssd_hip.so once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C pdm_ssd_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "pdm_ssd_amd has no CPU or PyTorch fallback for its operators.")
+        l = ctypes.CDLL(LIB_PATH)
+        l.pdm_abi_version.restype = _i
+        l.pdm_last_error.restype = ctypes.c_char_p
+        if l.pdm_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(
+                f"libpdmssd_hip.so ABI {l.pdm_abi_version()} != expected {ABI_VERSION}; rebuild it")
+        for name, args in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = _i
+            fn.argtypes = [_vp] + args
+        _lib = l
+    return _lib
+
+
+def call(name, stream, *args):
+    """Invoke an entry point on `stream` (an int hipStream_t); raise on a non-zero return."""
+    l = lib()
+    rc = getattr(l, name)(stream, *args)
+    if rc != 0:
+        msg = l.pdm_last_error().decode("utf-8", "replace")
+        raise NativeLibraryError(f"{name} failed with code {rc}: {msg}")

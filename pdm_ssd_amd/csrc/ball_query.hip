@@ -1,0 +1,108 @@
+// Ball query for gfx950.
+//
+// Semantics: /root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/ball_query_gpu.cu:15-51 —
+// per centre, the first `nsample` point indices in ASCENDING index order with d2 < radius^2
+// (strict), remaining slots padded with the first hit, rows of empty balls left as the caller's
+// zeros.  The design is different: the reference gives every centre one thread that walks all N
+// points with scalar uncoalesced loads.
+//
+// Exhaustive kernel (any N): a wave64 owns BQ_CPW centres.  The waves of a workgroup share
+// LDS-staged point tiles (coalesced HBM reads; SoA in LDS so lane l reads point base+l without
+// bank conflicts); each step a lane holds ONE point and tests it against the wave's centres
+// (centre coordinates are wave-uniform), `ballot` gives the hit mask per centre, the running count
+// is wave-uniform, hits are written in index order via the mask's prefix popcount, and a centre
+// stops consuming points once it has nsample hits.
+#include "common.h"
+
+namespace pdm {
+
+constexpr int BQ_WAVES = 4;
+constexpr int BQ_CPW = 4;      // centres per wave
+constexpr int BQ_TILE = 2048;  // points per LDS tile (24 KB)
+
+__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
+    int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx) {
+    __shared__ float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW;  // first centre of this wave
+    const float *__restrict__ pts = xyz + (size_t)b * n * 3;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    float cx[BQ_CPW], cy[BQ_CPW], cz[BQ_CPW];
+    int cnt[BQ_CPW], first[BQ_CPW];
+#pragma unroll
+    for (int c = 0; c < BQ_CPW; ++c) {
+        const bool have = j0 + c < m;
+        const float *ctr = new_xyz + ((size_t)b * m + (have ? j0 + c : 0)) * 3;
+        cx[c] = ctr[0]; cy[c] = ctr[1]; cz[c] = ctr[2];
+        cnt[c] = have ? 0 : nsample;
+        first[c] = -1;
+    }
+    int *__restrict__ out = idx + ((size_t)b * m + j0) * nsample;
+
+    for (int base = 0; base < n; base += BQ_TILE) {
+        const int tile = min(BQ_TILE, n - base);
+        __syncthreads();  // previous tile fully consumed
+        for (int i = threadIdx.x; i < tile * 3; i += BQ_WAVES * 64) {
+            const float v = pts[(size_t)base * 3 + i];
+            const int pnt = i / 3, comp = i - pnt * 3;
+            (comp == 0 ? sx : comp == 1 ? sy : sz)[pnt] = v;
+        }
+        __syncthreads();
+        bool wave_done = true;
+#pragma unroll
+        for (int c = 0; c < BQ_CPW; ++c) wave_done = wave_done && cnt[c] >= nsample;
+        if (!wave_done) {
+            for (int s = 0; s < tile; s += 64) {
+                const int k = s + lane;
+                const bool in = k < tile;
+                const float x = in ? sx[k] : 0.f, y = in ? sy[k] : 0.f, z = in ? sz[k] : 0.f;
+                bool all_done = true;
+#pragma unroll
+                for (int c = 0; c < BQ_CPW; ++c) {
+                    if (cnt[c] >= nsample) continue;  // wave-uniform
+                    const float d2 = sqdist(cx[c] - x, cy[c] - y, cz[c] - z);
+                    const bool hit = in && d2 < radius2;
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask != 0ull) {
+                        if (first[c] < 0) first[c] = base + s + (__ffsll((long long)mask) - 1);
+                        const int pos = cnt[c] + __popcll(mask & below);
+                        if (hit && pos < nsample) out[(size_t)c * nsample + pos] = base + k;
+                        cnt[c] += __popcll(mask);
+                    }
+                    all_done = all_done && cnt[c] >= nsample;
+                }
+                if (all_done) { wave_done = true; break; }
+            }
+        }
+        // every wave of the block done -> stop staging tiles
+        if (__syncthreads_and(wave_done)) break;
+    }
+    // ball_query_gpu.cu:41-45 — slots beyond the hit count hold the first hit
+#pragma unroll
+    for (int c = 0; c < BQ_CPW; ++c) {
+        if (j0 + c < m && first[c] >= 0 && cnt[c] < nsample)
+            for (int l = cnt[c] + lane; l < nsample; l += 64) out[(size_t)c * nsample + l] = first[c];
+    }
+}
+
+}  // namespace pdm
+
+using namespace pdm;
+
+extern "C" int pdm_ball_query(void *stream, int b, int n, int m, float radius, int nsample,
+                              const float *new_xyz, const float *xyz, int *idx) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, PDM_E_BADARG,
+                "ball_query: negative size b=%d n=%d m=%d nsample=%d", b, n, m, nsample);
+    if (b == 0 || m == 0 || nsample == 0 || n == 0) return 0;
+    PDM_REQUIRE(new_xyz && xyz && idx, PDM_E_BADARG, "ball_query: null pointer");
+    PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "ball_query: b=%d exceeds grid", b);
+    const float radius2 = radius * radius;  // ball_query_gpu.cu:29 (fp32 product)
+    dim3 grid(divup(m, BQ_WAVES * BQ_CPW), b);
+    hipLaunchKernelGGL(ball_query_wave_kernel, grid, dim3(BQ_WAVES * 64), 0, as_stream(stream), n,
+                       m, radius2, nsample, new_xyz, xyz, idx);
+    return check_launch("ball_query");
+}

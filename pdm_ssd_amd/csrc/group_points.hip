@@ -1,0 +1,190 @@
+// group_points (forward / backward) and the fused QueryAndGroup gather for gfx950.
+//
+// Semantics: /root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/group_points_gpu.cu
+// (forward :53-72, backward :14-31) and pointnet2_utils.py:241-264 for the fused form.
+//
+// The op is a pure HBM-write stream: out (B,C,M*ns) is written once, the source rows (N floats
+// per (b,c)) are small enough to stay in L2.  Design: a thread owns FOUR consecutive outputs of
+// the flattened (M*ns) axis — one 16-byte index load, then for each channel of its channel group
+// four L2-resident gathers and one 16-byte coalesced store.  The reference issues one 4-byte
+// store per thread and re-reads the index for every channel.
+#include "common.h"
+
+namespace pdm {
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_CG = 8;  // channels per workgroup (index registers reused across them)
+
+// vectorised: L % 4 == 0, idx/out 16-byte aligned
+__global__ __launch_bounds__(GP_THREADS) void group_points_v4_kernel(
+    int c, int n, long long L, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long long q = (long long)blockIdx.x * GP_THREADS + threadIdx.x;  // quad index
+    if (q * 4 >= L) return;
+    const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)b * L + q * 4);
+    const int c0 = blockIdx.y * GP_CG;
+    const int c1 = min(c0 + GP_CG, c);
+    for (int ci = c0; ci < c1; ++ci) {
+        const float *__restrict__ row = points + ((size_t)b * c + ci) * n;
+        float4 v;
+        v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
+        *reinterpret_cast<float4 *>(out + ((size_t)b * c + ci) * L + q * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(GP_THREADS) void group_points_scalar_kernel(
+    int c, int n, long long L, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long long l = (long long)blockIdx.x * GP_THREADS + threadIdx.x;
+    if (l >= L) return;
+    const int id = idx[(size_t)b * L + l];
+    const int c0 = blockIdx.y * GP_CG;
+    const int c1 = min(c0 + GP_CG, c);
+    for (int ci = c0; ci < c1; ++ci)
+        out[((size_t)b * c + ci) * L + l] = points[((size_t)b * c + ci) * n + id];
+}
+
+__global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
+    int c, int n, long long L, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const long long l = (long long)blockIdx.x * GP_THREADS + threadIdx.x;
+    if (l >= L) return;
+    const int id = idx[(size_t)b * L + l];
+    const int c0 = blockIdx.y * GP_CG;
+    const int c1 = min(c0 + GP_CG, c);
+    for (int ci = c0; ci < c1; ++ci)
+        atomicAdd(grad_points + ((size_t)b * c + ci) * n + id, grad_out[((size_t)b * c + ci) * L + l]);
+}
+
+// Fused QueryAndGroup gather: out (B, 3+C, M, ns); blockIdx.y == 0 writes the three centred xyz
+// channels, blockIdx.y >= 1 a group of feature channels.  Requires ns % 4 == 0 (a quad never
+// straddles two centres) and 16-byte aligned idx/out.
+__global__ __launch_bounds__(GP_THREADS) void query_group_v4_kernel(
+    int c, int n, int m, int ns, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long long L = (long long)m * ns;
+    const long long q = (long long)blockIdx.x * GP_THREADS + threadIdx.x;
+    if (q * 4 >= L) return;
+    const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)b * L + q * 4);
+    float *__restrict__ ob = out + (size_t)b * (3 + c) * L + q * 4;
+    if (blockIdx.y == 0) {
+        const int j = (int)((q * 4) / ns);
+        const float *__restrict__ p = xyz + (size_t)b * n * 3;
+        const float *__restrict__ ctr = new_xyz + ((size_t)b * m + j) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float ca = ctr[a];
+            float4 v;
+            v.x = p[(size_t)id.x * 3 + a] - ca;
+            v.y = p[(size_t)id.y * 3 + a] - ca;
+            v.z = p[(size_t)id.z * 3 + a] - ca;
+            v.w = p[(size_t)id.w * 3 + a] - ca;
+            *reinterpret_cast<float4 *>(ob + (size_t)a * L) = v;
+        }
+    } else {
+        const int c0 = (blockIdx.y - 1) * GP_CG;
+        const int c1 = min(c0 + GP_CG, c);
+        for (int ci = c0; ci < c1; ++ci) {
+            const float *__restrict__ row = features + ((size_t)b * c + ci) * n;
+            float4 v;
+            v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
+            *reinterpret_cast<float4 *>(ob + (size_t)(3 + ci) * L) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(GP_THREADS) void query_group_scalar_kernel(
+    int c, int n, int m, int ns, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long long L = (long long)m * ns;
+    const long long l = (long long)blockIdx.x * GP_THREADS + threadIdx.x;
+    if (l >= L) return;
+    const int id = idx[(size_t)b * L + l];
+    float *__restrict__ ob = out + (size_t)b * (3 + c) * L + l;
+    if (blockIdx.y == 0) {
+        const int j = (int)(l / ns);
+        for (int a = 0; a < 3; ++a)
+            ob[(size_t)a * L] = xyz[((size_t)b * n + id) * 3 + a] - new_xyz[((size_t)b * m + j) * 3 + a];
+    } else {
+        const int c0 = (blockIdx.y - 1) * GP_CG;
+        const int c1 = min(c0 + GP_CG, c);
+        for (int ci = c0; ci < c1; ++ci)
+            ob[(size_t)(3 + ci) * L] = features[((size_t)b * c + ci) * n + id];
+    }
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace pdm
+
+using namespace pdm;
+
+extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, int nsample,
+                                const float *points, const int *idx, float *out) {
+    PDM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, PDM_E_BADARG,
+                "group_points: negative size");
+    const long long L = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || L == 0) return 0;
+    PDM_REQUIRE(points && idx && out, PDM_E_BADARG, "group_points: null pointer");
+    PDM_REQUIRE(b <= 65535 && divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_points: b=%d c=%d exceed grid", b, c);
+    if (L % 4 == 0 && aligned16(idx) && aligned16(out)) {
+        dim3 grid(divup(L / 4, GP_THREADS), divup(c, GP_CG), b);
+        hipLaunchKernelGGL(group_points_v4_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n,
+                           L, points, idx, out);
+    } else {
+        dim3 grid(divup(L, GP_THREADS), divup(c, GP_CG), b);
+        hipLaunchKernelGGL(group_points_scalar_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream),
+                           c, n, L, points, idx, out);
+    }
+    return check_launch("group_points");
+}
+
+extern "C" int pdm_group_points_grad(void *stream, int b, int c, int n, int npoints, int nsample,
+                                     const float *grad_out, const int *idx, float *grad_points) {
+    PDM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, PDM_E_BADARG,
+                "group_points_grad: negative size");
+    const long long L = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || L == 0) return 0;
+    PDM_REQUIRE(grad_out && idx && grad_points, PDM_E_BADARG, "group_points_grad: null pointer");
+    PDM_REQUIRE(b <= 65535 && divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_points_grad: exceeds grid");
+    dim3 grid(divup(L, GP_THREADS), divup(c, GP_CG), b);
+    hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n, L,
+                       grad_out, idx, grad_points);
+    return check_launch("group_points_grad");
+}
+
+extern "C" int pdm_query_and_group(void *stream, int b, int n, int m, int c, float radius,
+                                   int nsample, const float *xyz, const float *new_xyz,
+                                   const float *features, int *idx, float *out) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0, PDM_E_BADARG,
+                "query_and_group: negative size");
+    const long long L = (long long)m * nsample;
+    if (b == 0 || L == 0) return 0;
+    PDM_REQUIRE(xyz && new_xyz && idx && out && (c == 0 || features), PDM_E_BADARG,
+                "query_and_group: null pointer");
+    PDM_REQUIRE(n >= 1, PDM_E_BADARG, "query_and_group: n=%d", n);
+    PDM_REQUIRE(b <= 65535 && 1 + divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "query_and_group: exceeds grid");
+    // pointnet2_utils.py:218 — rows of empty balls are zeros
+    hipError_t e = hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * L, as_stream(stream));
+    if (e != hipSuccess) {
+        set_error("query_and_group: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    int rc = pdm_ball_query(stream, b, n, m, radius, nsample, new_xyz, xyz, idx);
+    if (rc != 0) return rc;
+    if (nsample % 4 == 0 && aligned16(idx) && aligned16(out)) {
+        dim3 grid(divup(L / 4, GP_THREADS), 1 + divup(c, GP_CG), b);
+        hipLaunchKernelGGL(query_group_v4_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n,
+                           m, nsample, xyz, new_xyz, features, idx, out);
+    } else {
+        dim3 grid(divup(L, GP_THREADS), 1 + divup(c, GP_CG), b);
+        hipLaunchKernelGGL(query_group_scalar_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c,
+                           n, m, nsample, xyz, new_xyz, features, idx, out);
+    }
+    return check_launch("query_and_group");
+}

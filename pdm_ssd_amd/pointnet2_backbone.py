@@ -1,0 +1,107 @@
+"""PointNet2MSG backbone on the HIP operators.
+
+Host-side restatement of /root/reference/pcdet/models/backbones_3d/pointnet2_backbone.py:9-94: same
+constructor (model_cfg, input_channels, **kwargs), same `.num_point_features`, same batch_dict keys in
+and out, same state_dict keys (SA_modules.{i}.mlps..., FP_modules.{i}.mlp...).  model_cfg may be an
+EasyDict (as in OpenPCDet) or a plain nested dict with the same key names.
+
+Differences: the per-sample point count check (:72-76) is one bincount instead of B host syncs, and
+the intermediate sets are additionally published as batch_dict['sa_xyz'] / ['sa_features'] for the
+PDM neck (extra keys; nothing upstream reads them).
+"""
+import torch
+import torch.nn as nn
+
+from .pointnet2_batch import pointnet2_modules
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class PointNet2MSG(nn.Module):
+    def __init__(self, model_cfg, input_channels, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        sa_cfg = _get(model_cfg, 'SA_CONFIG')
+        npoints, radius, nsample = _get(sa_cfg, 'NPOINTS'), _get(sa_cfg, 'RADIUS'), _get(sa_cfg, 'NSAMPLE')
+        mlps_cfg = _get(sa_cfg, 'MLPS')
+        use_xyz = _get(sa_cfg, 'USE_XYZ', True)
+        fp_mlps = _get(model_cfg, 'FP_MLPS')
+
+        self.SA_modules = nn.ModuleList()
+        channel_in = input_channels - 3
+        self.num_points_each_layer = []
+        skip_channel_list = [input_channels - 3]
+        channel_out = channel_in
+        for k in range(len(npoints)):
+            # fresh lists per layer: the SA constructor mutates mlps[i][0] (ref pointnet2_modules.py:86-88)
+            mlps = [[channel_in] + list(spec) for spec in mlps_cfg[k]]
+            channel_out = sum(spec[-1] for spec in mlps)
+            self.SA_modules.append(pointnet2_modules.PointnetSAModuleMSG(
+                npoint=npoints[k], radii=list(radius[k]), nsamples=list(nsample[k]), mlps=mlps,
+                use_xyz=use_xyz))
+            skip_channel_list.append(channel_out)
+            channel_in = channel_out
+
+        self.FP_modules = nn.ModuleList()
+        for k in range(len(fp_mlps)):
+            pre_channel = fp_mlps[k + 1][-1] if k + 1 < len(fp_mlps) else channel_out
+            self.FP_modules.append(pointnet2_modules.PointnetFPModule(
+                mlp=[pre_channel + skip_channel_list[k]] + list(fp_mlps[k])))
+        self.num_point_features = fp_mlps[0][-1]
+
+    @staticmethod
+    def break_up_pc(pc):
+        batch_idx = pc[:, 0]
+        xyz = pc[:, 1:4].contiguous()
+        features = pc[:, 4:].contiguous() if pc.size(-1) > 4 else None
+        return batch_idx, xyz, features
+
+    def forward(self, batch_dict):
+        """batch_dict['points'] (sum N, 1+3+C) with column 0 = sample index -> adds
+        'point_features' (B*N, C_out) and 'point_coords' (B*N, 4)."""
+        batch_size = batch_dict['batch_size']
+        points = batch_dict['points']
+        batch_idx, xyz, features = self.break_up_pc(points)
+        if not batch_dict.get('points_per_sample_checked', False):
+            counts = torch.bincount(batch_idx.long(), minlength=batch_size)
+            assert counts.min() == counts.max(), 'PointNet2MSG needs the same point count in every sample'
+        xyz = xyz.view(batch_size, -1, 3)
+        if features is not None:
+            features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
+
+        l_xyz, l_features = [xyz], [features]
+        for sa in self.SA_modules:
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+            l_xyz.append(li_xyz)
+            l_features.append(li_features)
+        batch_dict['sa_xyz'] = list(l_xyz)
+        batch_dict['sa_features'] = list(l_features)
+
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+
+        point_features = l_features[0].permute(0, 2, 1).contiguous()  # (B, N, C)
+        batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
+        batch_dict['point_coords'] = torch.cat((batch_idx[:, None].float(), l_xyz[0].view(-1, 3)), dim=1)
+        return batch_dict
+
+
+POINTRCNN_MSG_CFG = {
+    # upstream OpenPCDet tools/cfgs/kitti_models/pointrcnn.yaml BACKBONE_3D (yaml absent from the snapshot,
+    # SURVEY.md section 8); shapes BASELINE.json's 16384-point configs are quoted on.
+    'NAME': 'PointNet2MSG',
+    'SA_CONFIG': {
+        'NPOINTS': [4096, 1024, 256, 64],
+        'RADIUS': [[0.1, 0.5], [0.5, 1.0], [1.0, 2.0], [2.0, 4.0]],
+        'NSAMPLE': [[16, 32], [16, 32], [16, 32], [16, 32]],
+        'MLPS': [[[16, 16, 32], [32, 32, 64]],
+                 [[64, 64, 128], [64, 96, 128]],
+                 [[128, 196, 256], [128, 196, 256]],
+                 [[256, 256, 512], [256, 384, 512]]],
+    },
+    'FP_MLPS': [[128, 128], [256, 256], [512, 512], [512, 512]],
+}

@@ -1,0 +1,135 @@
+"""Drop-in for the reference's native extension module `pointnet2_batch_cuda`.
+
+Same nine function names, argument order and meaning as the pybind table at
+/root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-24, so the reference's
+pointnet2_utils.py works unchanged with
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as pointnet2
+Tensors are handed to libpdmssd_hip.so as raw device pointers on the CURRENT torch stream.
+Differences from the reference wrappers (all stricter): every tensor is checked for device, dtype
+and contiguity and a Python exception is raised (the reference checks only ball_query and calls
+exit(-1): ball_query.cpp:14-26); a failed launch raises instead of exiting.
+"""
+import torch
+
+from .. import _native
+
+
+def _check(name, t, dtype):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA/HIP tensor (got {t.device})")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def _numel_at_least(name, t, n):
+    if t.numel() < n:
+        raise ValueError(f"{name} has {t.numel()} elements, the call needs {n}")
+
+
+def _run(fn, ref, *args):
+    dev = ref.device
+    if torch.cuda.current_device() != dev.index:
+        with torch.cuda.device(dev):
+            _native.call(fn, torch.cuda.current_stream(dev).cuda_stream, *args)
+    else:
+        _native.call(fn, torch.cuda.current_stream(dev).cuda_stream, *args)
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    _check("new_xyz", new_xyz, torch.float32); _check("xyz", xyz, torch.float32); _check("idx", idx, torch.int32)
+    _numel_at_least("new_xyz", new_xyz, b * m * 3); _numel_at_least("xyz", xyz, b * n * 3)
+    _numel_at_least("idx", idx, b * m * nsample)
+    _run("pdm_ball_query", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    _check("points", points, torch.float32); _check("idx", idx, torch.int32); _check("out", out, torch.float32)
+    _numel_at_least("points", points, b * c * n); _numel_at_least("idx", idx, b * npoints * nsample)
+    _numel_at_least("out", out, b * c * npoints * nsample)
+    _run("pdm_group_points", points, b, c, n, npoints, nsample, points.data_ptr(), idx.data_ptr(), out.data_ptr())
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    _check("grad_out", grad_out, torch.float32); _check("idx", idx, torch.int32)
+    _check("grad_points", grad_points, torch.float32)
+    _numel_at_least("grad_out", grad_out, b * c * npoints * nsample)
+    _numel_at_least("idx", idx, b * npoints * nsample); _numel_at_least("grad_points", grad_points, b * c * n)
+    _run("pdm_group_points_grad", grad_out, b, c, n, npoints, nsample, grad_out.data_ptr(), idx.data_ptr(),
+         grad_points.data_ptr())
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    _check("points", points, torch.float32); _check("idx", idx, torch.int32); _check("out", out, torch.float32)
+    _numel_at_least("points", points, b * c * n); _numel_at_least("idx", idx, b * npoints)
+    _numel_at_least("out", out, b * c * npoints)
+    _run("pdm_gather_points", points, b, c, n, npoints, points.data_ptr(), idx.data_ptr(), out.data_ptr())
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    _check("grad_out", grad_out, torch.float32); _check("idx", idx, torch.int32)
+    _check("grad_points", grad_points, torch.float32)
+    _numel_at_least("grad_out", grad_out, b * c * npoints); _numel_at_least("idx", idx, b * npoints)
+    _numel_at_least("grad_points", grad_points, b * c * n)
+    _run("pdm_gather_points_grad", grad_out, b, c, n, npoints, grad_out.data_ptr(), idx.data_ptr(),
+         grad_points.data_ptr())
+    return 1
+
+
+def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    _check("points", points, torch.float32); _check("temp", temp, torch.float32); _check("idx", idx, torch.int32)
+    _numel_at_least("points", points, b * n * 3); _numel_at_least("temp", temp, b * n)
+    _numel_at_least("idx", idx, b * m)
+    _run("pdm_furthest_point_sampling", points, b, n, m, points.data_ptr(), temp.data_ptr(), idx.data_ptr())
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    _check("unknown", unknown, torch.float32); _check("known", known, torch.float32)
+    _check("dist2", dist2, torch.float32); _check("idx", idx, torch.int32)
+    _numel_at_least("unknown", unknown, b * n * 3); _numel_at_least("known", known, b * m * 3)
+    _numel_at_least("dist2", dist2, b * n * 3); _numel_at_least("idx", idx, b * n * 3)
+    _run("pdm_three_nn", unknown, b, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(), idx.data_ptr())
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    _check("points", points, torch.float32); _check("idx", idx, torch.int32)
+    _check("weight", weight, torch.float32); _check("out", out, torch.float32)
+    _numel_at_least("points", points, b * c * m); _numel_at_least("idx", idx, b * n * 3)
+    _numel_at_least("weight", weight, b * n * 3); _numel_at_least("out", out, b * c * n)
+    _run("pdm_three_interpolate", points, b, c, m, n, points.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+         out.data_ptr())
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    _check("grad_out", grad_out, torch.float32); _check("idx", idx, torch.int32)
+    _check("weight", weight, torch.float32); _check("grad_points", grad_points, torch.float32)
+    _numel_at_least("grad_out", grad_out, b * c * n); _numel_at_least("idx", idx, b * n * 3)
+    _numel_at_least("weight", weight, b * n * 3); _numel_at_least("grad_points", grad_points, b * c * m)
+    _run("pdm_three_interpolate_grad", grad_out, b, c, n, m, grad_out.data_ptr(), idx.data_ptr(),
+         weight.data_ptr(), grad_points.data_ptr())
+
+
+# ---- fused addition (not in the reference's table) -------------------------------------------
+
+def query_and_group_wrapper(b, n, m, c, radius, nsample, xyz, new_xyz, features, idx, out):
+    """QueryAndGroup.forward (pointnet2_utils.py:241-264, use_xyz=True) in one native call."""
+    _check("xyz", xyz, torch.float32); _check("new_xyz", new_xyz, torch.float32)
+    _check("idx", idx, torch.int32); _check("out", out, torch.float32)
+    _numel_at_least("xyz", xyz, b * n * 3); _numel_at_least("new_xyz", new_xyz, b * m * 3)
+    _numel_at_least("idx", idx, b * m * nsample); _numel_at_least("out", out, b * (3 + c) * m * nsample)
+    fptr = 0
+    if c > 0:
+        _check("features", features, torch.float32)
+        _numel_at_least("features", features, b * c * n)
+        fptr = features.data_ptr()
+    _run("pdm_query_and_group", xyz, b, n, m, c, float(radius), nsample, xyz.data_ptr(), new_xyz.data_ptr(),
+         fptr, idx.data_ptr(), out.data_ptr())
+    return 1

@@ -1,0 +1,111 @@
+"""Set-abstraction / feature-propagation modules over the HIP operators.
+
+Constructor signatures, attribute names and state_dict keys (`mlps.{s}.{0,3,6}.weight`, BatchNorm at
+`{1,4,7}`; `mlp.{0,3}.weight`) match
+/root/reference/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py so upstream checkpoints
+load; forward semantics follow the cited lines.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+
+
+def _shared_mlp(spec: List[int]) -> nn.Sequential:
+    """Conv2d(1x1, no bias) -> BatchNorm2d -> ReLU per stage (ref :91-97, :132-139)."""
+    layers = []
+    for cin, cout in zip(spec[:-1], spec[1:]):
+        layers += [nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+class _PointnetSAModuleBase(nn.Module):
+    """ref :9-55."""
+
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+        self.pool_method = 'max_pool'
+
+    def sample(self, xyz: torch.Tensor) -> Optional[torch.Tensor]:
+        """FPS + gather of the sampled coordinates (ref :30-35) -> (B, npoint, 3)."""
+        if self.npoint is None:
+            return None
+        idx = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        return pointnet2_utils.gather_operation(xyz_flipped, idx).transpose(1, 2).contiguous()
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B, sum_k mlps[k][-1], npoint)."""
+        if new_xyz is None:
+            new_xyz = self.sample(xyz)
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            x = mlp(grouper(xyz, new_xyz, features))  # (B, mlp[-1], npoint, nsample)
+            if self.pool_method == 'max_pool':
+                x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
+            elif self.pool_method == 'avg_pool':
+                x = F.avg_pool2d(x, kernel_size=[1, x.size(3)])
+            else:
+                raise NotImplementedError
+            pooled.append(x.squeeze(-1))
+        return new_xyz, torch.cat(pooled, dim=1)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Multi-scale grouping SA layer (ref :58-99).
+
+    Like the reference (:86-88) the constructor adds 3 to `mlps[i][0]` IN PLACE when use_xyz — callers
+    that reuse a spec list rely on that side effect.  `bn` is accepted and ignored, as upstream.
+    """
+
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]],
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, mlp_spec in zip(radii, nsamples, mlps):
+            self.groupers.append(
+                pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                mlp_spec[0] += 3
+            self.mlps.append(_shared_mlp(mlp_spec))
+        self.pool_method = pool_method
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale SA layer (ref :102-119)."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn,
+                         use_xyz=use_xyz, pool_method=pool_method)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation (ref :122-170)."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = _shared_mlp(mlp)
+
+    def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
+                known_feats: torch.Tensor) -> torch.Tensor:
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B, mlp[-1], n)."""
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)  # ref :154
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        x = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
+        return self.mlp(x.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,264 @@
+"""Operator API of the PointNet++ batch ops on MI355X.
+
+Mirrors the public names, argument order, shapes, dtypes and zero-fill behaviour of
+/root/reference/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py (cited per class), so the
+OpenPCDet module stack can import this file in its place.  Every operator dispatches to a
+hand-written HIP kernel in libpdmssd_hip.so; there is no PyTorch or CPU fallback.
+
+Additions over the reference: `QueryAndGroup(fused=True)` (default) runs ball query, both gathers,
+the centre subtraction and the concat as one native call writing (B, 3+C, M, ns) once; the
+autograd result is identical.  Floating inputs under autocast are computed in fp32 (coordinates
+and distances never leave fp32, so indices do not depend on the training dtype).
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import pointnet2_batch_hip as pointnet2
+
+_FP32_FWD = dict(device_type="cuda", cast_inputs=torch.float32)
+
+
+def _new(ref: torch.Tensor, shape, dtype, fill=None) -> torch.Tensor:
+    t = torch.empty(shape, dtype=dtype, device=ref.device)
+    if fill is not None:
+        t.fill_(fill)
+    return t
+
+
+class FarthestPointSampling(Function):
+    """ref pointnet2_utils.py:10-33 — xyz (B,N,3) -> int32 (B,npoint); no gradient."""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        xyz = xyz.float()
+        idx = _new(xyz, (B, npoint), torch.int32)
+        temp = _new(xyz, (B, N), torch.float32, fill=1e10)  # ref :26
+        pointnet2.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    """ref pointnet2_utils.py:39-70 — features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(**_FP32_FWD)
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        out = _new(features, (B, C, npoint), torch.float32)
+        pointnet2.gather_points_wrapper(B, C, N, npoint, features, idx, out)
+        ctx.for_backwards = (idx, C, N)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad_features = _new(grad_out, (B, C, N), torch.float32, fill=0)  # ref :67
+        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.float().contiguous(), idx,
+                                             grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    """ref pointnet2_utils.py:76-102 — three nearest known points of every unknown point.
+
+    Returns (dist (B,n,3) = sqrt of the squared distances, idx (B,n,3) int32); no gradient.
+    """
+
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert unknown.is_contiguous()
+        assert known.is_contiguous()
+        unknown, known = unknown.float(), known.float()
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = _new(unknown, (B, N, 3), torch.float32)
+        idx = _new(unknown, (B, N, 3), torch.int32)
+        pointnet2.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
+        dist = torch.sqrt(dist2)  # ref :98
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """ref pointnet2_utils.py:108-150 — features (B,C,M), idx/weight (B,n,3) -> (B,C,n)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(**_FP32_FWD)
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        assert weight.is_contiguous()
+        B, c, m = features.size()
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        out = _new(features, (B, c, n), torch.float32)
+        pointnet2.three_interpolate_wrapper(B, c, m, n, features, idx, weight, out)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = _new(grad_out, (B, c, m), torch.float32, fill=0)  # ref :146
+        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.float().contiguous(), idx, weight,
+                                                 grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    """ref pointnet2_utils.py:156-194 — features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(**_FP32_FWD)
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, nfeatures, nsample = idx.size()
+        _, C, N = features.size()
+        out = _new(features, (B, C, nfeatures, nsample), torch.float32)
+        pointnet2.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, out)
+        ctx.for_backwards = (idx, N)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.size()
+        grad_features = _new(grad_out, (B, C, N), torch.float32, fill=0)  # ref :190
+        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.float().contiguous(), idx,
+                                            grad_features)
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    """ref pointnet2_utils.py:200-225 — (radius, nsample, xyz (B,N,3), new_xyz (B,M,3)) -> int32 (B,M,nsample).
+
+    Rows of empty balls are all zero (the caller-side zero fill of ref :218); no gradient.
+    """
+
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        assert new_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        xyz, new_xyz = xyz.float(), new_xyz.float()
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = _new(xyz, (B, npoint, nsample), torch.int32, fill=0)
+        pointnet2.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class _FusedQueryAndGroup(Function):
+    """One native call for ball query + grouped xyz (centred) + grouped features + concat.
+
+    Forward value == cat([grouping(xyz^T, idx) - new_xyz^T[..., None], grouping(features, idx)], 1)
+    (ref :249-257).  Gradient flows to `features` only, exactly as in the unfused graph where xyz
+    reaches the output through non-differentiated leaf coordinates.
+    """
+
+    @staticmethod
+    @torch.amp.custom_fwd(**_FP32_FWD)
+    def forward(ctx, radius, nsample, xyz, new_xyz, features):
+        B, N, _ = xyz.size()
+        M = new_xyz.size(1)
+        C = 0 if features is None else features.size(1)
+        idx = _new(xyz, (B, M, nsample), torch.int32)
+        out = _new(xyz, (B, 3 + C, M, nsample), torch.float32)
+        pointnet2.query_and_group_wrapper(B, N, M, C, radius, nsample, xyz, new_xyz, features, idx, out)
+        ctx.for_backwards = (idx, N, C)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        idx, N, C = ctx.for_backwards
+        if C == 0 or not ctx.needs_input_grad[4]:
+            return None, None, None, None, None
+        B, _, M, ns = grad_out.size()
+        g = grad_out[:, 3:].float().contiguous()
+        grad_features = _new(grad_out, (B, C, N), torch.float32, fill=0)
+        pointnet2.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
+        return None, None, None, None, grad_features
+
+
+class QueryAndGroup(nn.Module):
+    """ref pointnet2_utils.py:231-264."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True, fused: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.fused = fused
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) -> (B, 3+C, npoint, nsample)."""
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        if self.fused and self.use_xyz and xyz.is_contiguous() and new_xyz.is_contiguous() and (
+                features is None or features.is_contiguous()):
+            return _FusedQueryAndGroup.apply(self.radius, self.nsample, xyz, new_xyz, features)
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+
+
+class GroupAll(nn.Module):
+    """ref pointnet2_utils.py:267-290 — (B, 3+C, 1, N), no centring."""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped_features = features.unsqueeze(2)
+        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features

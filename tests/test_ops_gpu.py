@@ -1,0 +1,242 @@
+"""Parity of the HIP operators (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact for indices (FPS, ball_query, three_nn) and for pure copies (gather, group_points);
+<= 1e-4 for fp32 features whose summation order is free (atomic backward passes); three_interpolate
+is pinned to the oracle's rounding sequence and compared bit-exactly too.
+"""
+import numpy as np
+import pytest
+import torch
+
+from pdm_ssd_amd import synthetic
+from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+
+pytestmark = pytest.mark.gpu
+
+SA_SCALES = [(0.1, 16), (0.5, 32), (1.0, 32), (2.0, 16), (4.0, 32)]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def clouds(kind, B, N, seed=1234):
+    f = synthetic.uniform_clouds if kind == "uniform" else synthetic.lidar_like_clouds
+    return f(B, N, seed)[:, :, :3].copy()
+
+
+# ------------------------------------------------------------------ FPS
+
+@pytest.mark.parametrize("kind", ["uniform", "lidar"])
+@pytest.mark.parametrize("N,m", [(1024, 256), (4096, 1024), (256, 64), (1000, 100), (3000, 64), (64, 64), (37, 9), (1, 1)])
+def test_fps_index_exact(oracle, dev, kind, N, m):
+    xyz = clouds(kind, 2, N, seed=7)
+    ref, ref_temp = oracle.furthest_point_sample(xyz, m, return_temp=True)
+    got = pu.furthest_point_sample(T(xyz, dev), m)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (2, m)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_fps_16384_full_size(oracle, dev):
+    xyz = clouds("lidar", 2, 16384, seed=11)
+    ref = oracle.furthest_point_sample(xyz, 4096)
+    got = pu.furthest_point_sample(T(xyz, dev), 4096)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_fps_ties_duplicated_points(oracle, dev):
+    """Padded clouds repeat points (data_processor.py:206-210): equal maxima are decided by the
+    reference's tree order, not by the smallest index."""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-20, 20, (2, 1024, 3)).astype(np.float32)
+    xyz = np.concatenate([base, base[:, ::-1]], axis=1)  # every point twice, N = 2048
+    ref = oracle.furthest_point_sample(xyz, 512)
+    got = pu.furthest_point_sample(T(xyz, dev), 512)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    # lattice: many exactly equal distances
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij"), -1).reshape(1, -1, 3)
+    g = g.astype(np.float32)
+    ref = oracle.furthest_point_sample(g, 300)
+    got = pu.furthest_point_sample(T(g, dev), 300)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_fps_streaming_variant_large_n(oracle, dev):
+    xyz = clouds("uniform", 1, 20000, seed=5)
+    ref = oracle.furthest_point_sample(xyz, 128)
+    got = pu.furthest_point_sample(T(xyz, dev), 128)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_fps_temp_holds_final_min_distances(oracle, dev):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    xyz = clouds("uniform", 2, 2048, seed=9)
+    ref, ref_temp = oracle.furthest_point_sample(xyz, 64, return_temp=True)
+    x = T(xyz, dev)
+    temp = torch.full((2, 2048), 1e10, device=dev)
+    idx = torch.empty((2, 64), dtype=torch.int32, device=dev)
+    ext.farthest_point_sampling_wrapper(2, 2048, 64, x, temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+
+
+# ------------------------------------------------------------------ ball query
+
+@pytest.mark.parametrize("kind", ["uniform", "lidar"])
+@pytest.mark.parametrize("N,M", [(4096, 1024), (1024, 256), (1000, 77), (256, 64)])
+@pytest.mark.parametrize("radius,ns", SA_SCALES)
+def test_ball_query_index_exact(oracle, dev, kind, N, M, radius, ns):
+    xyz = clouds(kind, 2, N, seed=21)
+    fidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.take_along_axis(xyz, fidx[:, :, None].astype(np.int64), 1)
+    ref = oracle.ball_query(radius, ns, xyz, new_xyz)
+    got = pu.ball_query(radius, ns, T(xyz, dev), T(new_xyz, dev))
+    assert got.dtype == torch.int32
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_ball_query_empty_balls_stay_zero(oracle, dev):
+    xyz = clouds("uniform", 2, 512, seed=1)
+    new_xyz = xyz[:, :32].copy()
+    new_xyz[:, ::2] += 1000.0  # far away: no neighbour
+    ref = oracle.ball_query(0.5, 8, xyz, new_xyz)
+    got = pu.ball_query(0.5, 8, T(xyz, dev), T(new_xyz, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert (got[:, ::2] == 0).all()
+
+
+def test_ball_query_odd_nsample_and_16384(oracle, dev):
+    xyz = clouds("lidar", 1, 16384, seed=2)
+    fidx = oracle.furthest_point_sample(xyz, 512)
+    new_xyz = np.take_along_axis(xyz, fidx[:, :, None].astype(np.int64), 1)
+    for radius, ns in [(0.5, 32), (0.3, 7), (2.0, 100)]:
+        ref = oracle.ball_query(radius, ns, xyz, new_xyz)
+        got = pu.ball_query(radius, ns, T(xyz, dev), T(new_xyz, dev))
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ gather / group
+
+def test_gather_and_grad(oracle, dev):
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((3, 5, 700)).astype(np.float32)
+    idx = rng.integers(0, 700, (3, 123)).astype(np.int32)
+    f = T(feat, dev).requires_grad_(True)
+    out = pu.gather_operation(f, T(idx, dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.gather_operation(feat, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(T(go, dev))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.gather_operation_grad(go, idx, 700), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,N,M,ns", [(1, 1024, 256, 16), (96, 4096, 256, 32), (7, 300, 33, 5), (3, 128, 16, 4), (17, 64, 1, 1)])
+def test_group_points_and_grad(oracle, dev, C, N, M, ns):
+    rng = np.random.default_rng(C * 1000 + ns)
+    feat = rng.standard_normal((2, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (2, M, ns)).astype(np.int32)
+    f = T(feat, dev).requires_grad_(True)
+    out = pu.grouping_operation(f, T(idx, dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.grouping_operation(feat, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(T(go, dev))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.grouping_operation_grad(go, idx, N), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("C", [0, 1, 29])
+@pytest.mark.parametrize("ns", [16, 6])
+def test_query_and_group_fused_matches_unfused_and_oracle(oracle, dev, C, ns):
+    xyz = clouds("lidar", 2, 2048, seed=4)
+    fidx = oracle.furthest_point_sample(xyz, 200)
+    new_xyz = np.take_along_axis(xyz, fidx[:, :, None].astype(np.int64), 1)
+    rng = np.random.default_rng(8)
+    feat = rng.standard_normal((2, C, 2048)).astype(np.float32) if C else None
+    ref, ref_idx = oracle.query_and_group(1.0, ns, xyz, new_xyz, feat)
+    x, nx = T(xyz, dev), T(new_xyz, dev)
+    f = T(feat, dev).requires_grad_(True) if C else None
+    fused = pu.QueryAndGroup(1.0, ns, use_xyz=True, fused=True)(x, nx, f)
+    np.testing.assert_array_equal(fused.detach().cpu().numpy(), ref)
+    f2 = T(feat, dev).requires_grad_(True) if C else None
+    unfused = pu.QueryAndGroup(1.0, ns, use_xyz=True, fused=False)(x, nx, f2)
+    np.testing.assert_array_equal(unfused.detach().cpu().numpy(), ref)
+    if C:
+        go = T(rng.standard_normal(ref.shape).astype(np.float32), dev)
+        fused.backward(go)
+        unfused.backward(go)
+        np.testing.assert_allclose(f.grad.cpu().numpy(), f2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(f.grad.cpu().numpy(),
+                                   oracle.grouping_operation_grad(go[:, 3:].cpu().numpy(), ref_idx, 2048),
+                                   rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ three_nn / interpolate
+
+@pytest.mark.parametrize("kind", ["uniform", "lidar"])
+@pytest.mark.parametrize("n,m", [(4096, 1024), (1024, 256), (333, 50), (64, 3), (16, 2)])
+def test_three_nn_index_exact(oracle, dev, kind, n, m):
+    unknown = clouds(kind, 2, n, seed=31)
+    known = clouds(kind, 2, m, seed=32) if m < 3 or n == 333 else unknown[:, :m].copy()
+    ref_d, ref_i = oracle.three_nn(unknown, known)
+    d, i = pu.three_nn(T(unknown, dev), T(known, dev))
+    np.testing.assert_array_equal(i.cpu().numpy(), ref_i)
+    np.testing.assert_array_equal(d.cpu().numpy(), ref_d)  # sqrt of identical fp32 squared distances
+
+
+def test_three_nn_exact_ties_prefer_lower_index(oracle, dev):
+    known = np.zeros((1, 8, 3), dtype=np.float32)
+    known[0, :, 0] = [1, -1, 1, -1, 2, 2, -2, 3]  # distances from origin: 1,1,1,1,4,4,4,9
+    unknown = np.zeros((1, 4, 3), dtype=np.float32)
+    ref_d, ref_i = oracle.three_nn(unknown, known)
+    np.testing.assert_array_equal(ref_i[0, 0], [0, 1, 2])
+    d, i = pu.three_nn(T(unknown, dev), T(known, dev))
+    np.testing.assert_array_equal(i.cpu().numpy(), ref_i)
+
+
+@pytest.mark.parametrize("C,m,n", [(1024, 64, 256), (256, 1024, 4096), (5, 33, 77)])
+def test_three_interpolate_and_grad(oracle, dev, C, m, n):
+    rng = np.random.default_rng(C)
+    feat = rng.standard_normal((2, C, m)).astype(np.float32)
+    idx = rng.integers(0, m, (2, n, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (2, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    f = T(feat, dev).requires_grad_(True)
+    out = pu.three_interpolate(f, T(idx, dev), T(w, dev))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.three_interpolate(feat, idx, w))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(T(go, dev))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad(go, idx, w, m), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ boundary behaviour
+
+def test_wrapper_rejects_bad_tensors(dev):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    xyz = torch.zeros((1, 8, 3), device=dev)
+    idx = torch.zeros((1, 2, 4), dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError):
+        ext.ball_query_wrapper(1, 8, 2, 1.0, 4, xyz[:, :2].cpu(), xyz, idx)  # not on the GPU
+    with pytest.raises(ValueError):
+        ext.ball_query_wrapper(1, 8, 2, 1.0, 4, xyz.transpose(1, 2)[:, :2], xyz, idx)  # not contiguous
+    with pytest.raises(TypeError):
+        ext.ball_query_wrapper(1, 8, 2, 1.0, 4, xyz[:, :2].contiguous(), xyz, idx.long())
+    with pytest.raises(ValueError):
+        ext.ball_query_wrapper(1, 8, 3, 1.0, 4, xyz[:, :2].contiguous(), xyz, idx)  # idx too small for m=3
+
+
+def test_native_argument_errors_raise(dev):
+    from pdm_ssd_amd import _native
+    with pytest.raises(_native.NativeLibraryError):
+        _native.call("pdm_ball_query", 0, -1, 8, 2, 1.0, 4, 0, 0, 0)
+    with pytest.raises(_native.NativeLibraryError):
+        _native.call("pdm_ball_query", 0, 1, 8, 2, 1.0, 4, 0, 0, 0)  # null pointers
+
+
+def test_ops_run_on_non_default_stream(oracle, dev):
+    xyz = clouds("uniform", 2, 1024, seed=77)
+    ref = oracle.furthest_point_sample(xyz, 128)
+    s = torch.cuda.Stream()
+    x = T(xyz, dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        got = pu.furthest_point_sample(x, 128)
+    s.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
