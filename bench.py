@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of PDM-SSD's point-cloud hot path on MI355X.
+
+One "step" = one forward pass of the hot path over one batch of synthetic KITTI-range clouds that are
+already resident in HBM: PointNet2MSG backbone (4 SA-MSG + 4 FP layers: FPS, ball query, grouping,
+shared MLPs, three-NN interpolation) followed by the PDM neck (dilation, SH x Gaussian filling,
+scatter-add to the BEV grid, normalise, height compression).  fp32, inference (BN in eval mode), the
+configuration BASELINE.json's metric is quoted on: bs = 32 clouds of 16384 points per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU = pure data parallel over whole clouds (weak scaling, 32 clouds per rank, no data-path
+collective; only the timing barriers).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from pdm_ssd_amd import _native, synthetic
+from pdm_ssd_amd.pdm_neck import PDMNeck
+from pdm_ssd_amd.pointnet2_backbone import POINTRCNN_MSG_CFG, PointNet2MSG
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VOXEL = [0.05, 0.05, 0.1]
+NECK_CFG = {'SOURCE_LAYER': 2, 'FEATURE_DIM': 128, 'DILATION': [7, 7, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 8,
+            'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 256, 'NORMALIZE': True}
+
+
+def build_models(device, seed=0):
+    torch.manual_seed(seed)
+    backbone = PointNet2MSG(POINTRCNN_MSG_CFG, input_channels=4)
+    neck = PDMNeck(NECK_CFG, grid_size=[1408, 1600, 40], voxel_size=VOXEL,
+                   point_cloud_range=list(synthetic.KITTI_RANGE))
+    with torch.no_grad():  # non-degenerate SH / scale head so the neck's arithmetic is fully exercised
+        neck.coef.weight.normal_(0.0, 0.02)
+    return backbone.to(device).eval(), neck.to(device).eval()
+
+
+def make_batch(B, N, kind, seed0, device):
+    gen = synthetic.uniform_clouds if kind == "uniform" else synthetic.lidar_like_clouds
+    clouds = gen(B, N, seed0)
+    pts = torch.from_numpy(synthetic.to_batch_points(clouds)).to(device)
+    return clouds, pts
+
+
+# ----------------------------------------------------------------------------- per-op accounting
+
+def algorithmic_bytes(name, a):
+    """SURVEY.md section 8 D4 formulas; `a` = the integer/float arguments of the C-ABI call."""
+    if name == "pdm_ball_query":
+        b, n, m, _r, ns = a[:5]
+        return b * (12 * n + 12 * m + 4 * m * ns)
+    if name == "pdm_group_concat":
+        b, n, m, c, ns = a[:5]
+        # idx + source once (xyz and C feature rows) + centres + the (3+C) output channels
+        return b * (4 * m * ns + 12 * n + 4 * c * n + 12 * m + 4 * (3 + c) * m * ns)
+    if name == "pdm_group_points":
+        b, c, n, m, ns = a[:5]
+        return b * (4 * m * ns + 4 * c * n + 4 * c * m * ns)
+    if name == "pdm_gather_points":
+        b, c, n, m = a[:4]
+        return b * (4 * m + 4 * c * n + 4 * c * m)
+    if name == "pdm_furthest_point_sampling":
+        b, n, m = a[:3]
+        return b * (12 * n + 4 * m)
+    if name == "pdm_three_nn":
+        b, n, m = a[:3]
+        return b * (12 * n + 12 * m + 24 * n)
+    if name == "pdm_three_interpolate":
+        b, c, m, n = a[:4]
+        return b * (24 * n + 4 * c * m + 4 * c * n)
+    if name == "pdm_scatter_bev":
+        B, P, C, deg = a[:4]
+        W, H, D = a[17:20]
+        return B * (12 * P + 4 * C * P + 4 * (deg + 1) ** 2 * P + 4 * P) + 4 * B * C * D * H * W
+    if name == "pdm_bev_normalize":
+        B, C, W, H, D = a[:5]
+        return B * H * W * D * (8 * C + 4)
+    return 0
+
+
+class OpTimer:
+    """Brackets every C-ABI call with HIP events on the stream the kernel is launched on."""
+
+    def __init__(self):
+        self.records = []
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = _native.call
+
+        def timed(name, stream, *args):
+            s = torch.cuda.current_stream()
+            assert s.cuda_stream == stream or stream == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            self._orig(name, stream, *args)
+            e1.record(s)
+            ints = [x for x in args if isinstance(x, (int, float))]
+            self.records.append((name, ints, e0, e1))
+
+        _native.call = timed
+        return self
+
+    def __exit__(self, *exc):
+        _native.call = self._orig
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, ints, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = agg.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+            d["calls"] += 1
+            d["ms"] += ms
+            d["bytes"] += algorithmic_bytes(name, ints)
+        out = []
+        for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            ms_step = d["ms"] / steps
+            out.append({"op": name, "calls_per_step": d["calls"] // steps, "ms_per_step": round(ms_step, 4),
+                        "alg_MB_per_step": round(d["bytes"] / steps / 1e6, 3),
+                        "GBps": round(d["bytes"] / steps / 1e9 / (ms_step / 1e3), 1) if ms_step > 0 else None})
+        return out
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+
+def cpu_baseline(backbone, neck, N, kind, frames=2):
+    """Times the CPU statement of the same step (oracle operators + torch-CPU MLPs) on `frames` clouds."""
+    import copy
+
+    from oracle import cpu_backbone, cpu_oracle
+    cpu_oracle.build()
+    bb = copy.deepcopy(backbone).cpu().eval()
+    nk = copy.deepcopy(neck).cpu().eval()
+    gen = synthetic.uniform_clouds if kind == "uniform" else synthetic.lidar_like_clouds
+    clouds = gen(frames, N, 4321)
+    threads = cpu_oracle.max_threads()
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    out = cpu_backbone.backbone_forward(bb, clouds)
+    cpu_backbone.neck_forward(nk, out['sa_xyz'], out['sa_features'])
+    dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} clouds x {N} pts, same step (oracle C operators with OpenMP + torch-CPU MLPs), "
+                      f"{dt:.1f} s wall; the reference itself has no CPU path for these operators"}
+
+
+# ----------------------------------------------------------------------------- main
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _native.lib()  # fail loudly now if the HIP library is missing
+
+    B, N = args.batch, args.points
+    backbone, neck = build_models(device)
+    _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
+
+    def step():
+        bd = {'batch_size': B, 'points': points, 'points_per_sample_checked': True}
+        bd = backbone(bd)
+        bd = neck(bd)
+        return bd['spatial_features'], bd['point_features']
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    mode = "eager"
+    with torch.no_grad():
+        # per-sample point-count check of the backbone (host sync) done once, outside the timed region
+        counts = torch.bincount(points[:, 0].long(), minlength=B)
+        assert int(counts.min()) == int(counts.max()) == N
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        run = step
+        graph = None
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step()
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = step()
+                run = graph.replay
+                mode = "hipGraph"
+                run()
+                torch.cuda.synchronize()
+            except Exception as e:  # capture unsupported -> measure eager, say so
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                graph, run, mode = None, step, "eager"
+                torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # per-kernel pass (eager, instrumented with HIP events on the launch stream); rank 0 only
+        ops = []
+        if rank == 0:
+            psteps = max(3, min(args.steps, 10))
+            with OpTimer() as timer:
+                for _ in range(psteps):
+                    step()
+                ops = timer.summary(psteps)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = world * B * args.steps / elapsed
+
+    # roofline of the dominant HBM-bound kernel of the path (BASELINE.json: ball_query+group_points vs HBM)
+    hbm_ops = [o for o in ops if o["op"] in ("pdm_group_concat", "pdm_group_points", "pdm_three_interpolate",
+                                              "pdm_scatter_bev", "pdm_bev_normalize")]
+    dom = max(hbm_ops, key=lambda o: o["ms_per_step"]) if hbm_ops else None
+    roofline = None
+    if dom:
+        per_launch_bytes = dom["alg_MB_per_step"] * 1e6 / dom["calls_per_step"]
+        per_launch_s = dom["ms_per_step"] / 1e3 / dom["calls_per_step"]
+        ach = per_launch_bytes / per_launch_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom["op"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": dom["calls_per_step"],
+                    "avg_launch_us": round(per_launch_s * 1e6, 2),
+                    "alg_bytes_per_launch": int(per_launch_bytes)}
+    bq = [o for o in ops if o["op"] in ("pdm_ball_query", "pdm_group_concat", "pdm_group_points")]
+    bq_ms = sum(o["ms_per_step"] for o in bq)
+    bq_mb = sum(o["alg_MB_per_step"] for o in bq)
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(backbone, neck, N, args.clouds, frames=args.cpu_frames)
+
+    line = {
+        "metric": "frames/sec (16384-pt clouds, bs=32)", "value": round(frames_per_s, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[2]: PointNet2MSG backbone + PDM neck forward, bs={B}/GPU x {N} pts, "
+                               f"{args.clouds} KITTI-range clouds, fp32 inference, inputs resident in HBM",
+                   "launch": mode, "parallelism": f"dp{world}"},
+        "roofline": roofline,
+        "ball_query_plus_group": {"ms_per_step": round(bq_ms, 4), "alg_MB_per_step": round(bq_mb, 2),
+                                  "GBps": round(bq_mb / 1e3 / (bq_ms / 1e3), 1) if bq_ms > 0 else None,
+                                  "frac_of_hbm_peak": round(bq_mb / 1e3 / (bq_ms / 1e3) / HBM_PEAK_GBS, 4) if bq_ms > 0 else None},
+        "ops": ops,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

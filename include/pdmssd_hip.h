@@ -95,6 +95,12 @@ int pdm_query_and_group(void *stream, int b, int n, int m, int c, float radius, 
                         const float *xyz, const float *new_xyz, const float *features, int *idx,
                         float *out);
 
+/* The gather half of the above for a given idx (B,M,nsample): grouped xyz minus centre, grouped
+ * features, concatenated on the channel axis -> out (B, 3+C, M, nsample)
+ * (pointnet2_utils.py:250-257: two grouping_operation calls, the in-place subtract and torch.cat). */
+int pdm_group_concat(void *stream, int b, int n, int m, int c, int nsample, const float *xyz,
+                     const float *new_xyz, const float *features, const int *idx, float *out);
+
 /* ---- PDM neck (build-defined spec, DESIGN.md "PDM spec"; no reference source exists) ------- */
 
 /* Multi-centre scatter-add of dilated, SH x Gaussian weighted point features into a BEV grid.

@@ -6,6 +6,10 @@ raised.  Nothing here imports the CPU oracle.
 import ctypes
 import os
 
+# torch first: its wheel bundles the HIP runtime (libamdhip64.so.7) this library must share with it —
+# streams and device pointers handed across the C ABI are only meaningful inside ONE runtime instance.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpdmssd_hip.so")
 ABI_VERSION = 1
@@ -26,6 +30,7 @@ _SIGNATURES = {
     "pdm_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_query_and_group": [_i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_group_concat": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,

@@ -158,6 +158,28 @@ extern "C" int pdm_group_points_grad(void *stream, int b, int c, int n, int npoi
     return check_launch("group_points_grad");
 }
 
+extern "C" int pdm_group_concat(void *stream, int b, int n, int m, int c, int nsample,
+                                const float *xyz, const float *new_xyz, const float *features,
+                                const int *idx, float *out) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0, PDM_E_BADARG,
+                "group_concat: negative size");
+    const long long L = (long long)m * nsample;
+    if (b == 0 || L == 0) return 0;
+    PDM_REQUIRE(xyz && new_xyz && idx && out && (c == 0 || features), PDM_E_BADARG,
+                "group_concat: null pointer");
+    PDM_REQUIRE(b <= 65535 && 1 + divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_concat: exceeds grid");
+    if (nsample % 4 == 0 && aligned16(idx) && aligned16(out)) {
+        dim3 grid(divup(L / 4, GP_THREADS), 1 + divup(c, GP_CG), b);
+        hipLaunchKernelGGL(query_group_v4_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n,
+                           m, nsample, xyz, new_xyz, features, idx, out);
+    } else {
+        dim3 grid(divup(L, GP_THREADS), 1 + divup(c, GP_CG), b);
+        hipLaunchKernelGGL(query_group_scalar_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c,
+                           n, m, nsample, xyz, new_xyz, features, idx, out);
+    }
+    return check_launch("group_concat");
+}
+
 extern "C" int pdm_query_and_group(void *stream, int b, int n, int m, int c, float radius,
                                    int nsample, const float *xyz, const float *new_xyz,
                                    const float *features, int *idx, float *out) {
@@ -168,7 +190,6 @@ extern "C" int pdm_query_and_group(void *stream, int b, int n, int m, int c, flo
     PDM_REQUIRE(xyz && new_xyz && idx && out && (c == 0 || features), PDM_E_BADARG,
                 "query_and_group: null pointer");
     PDM_REQUIRE(n >= 1, PDM_E_BADARG, "query_and_group: n=%d", n);
-    PDM_REQUIRE(b <= 65535 && 1 + divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "query_and_group: exceeds grid");
     // pointnet2_utils.py:218 — rows of empty balls are zeros
     hipError_t e = hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * L, as_stream(stream));
     if (e != hipSuccess) {
@@ -177,14 +198,5 @@ extern "C" int pdm_query_and_group(void *stream, int b, int n, int m, int c, flo
     }
     int rc = pdm_ball_query(stream, b, n, m, radius, nsample, new_xyz, xyz, idx);
     if (rc != 0) return rc;
-    if (nsample % 4 == 0 && aligned16(idx) && aligned16(out)) {
-        dim3 grid(divup(L / 4, GP_THREADS), 1 + divup(c, GP_CG), b);
-        hipLaunchKernelGGL(query_group_v4_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n,
-                           m, nsample, xyz, new_xyz, features, idx, out);
-    } else {
-        dim3 grid(divup(L, GP_THREADS), 1 + divup(c, GP_CG), b);
-        hipLaunchKernelGGL(query_group_scalar_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c,
-                           n, m, nsample, xyz, new_xyz, features, idx, out);
-    }
-    return check_launch("query_and_group");
+    return pdm_group_concat(stream, b, n, m, c, nsample, xyz, new_xyz, features, idx, out);
 }

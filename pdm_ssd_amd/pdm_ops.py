@@ -1,0 +1,101 @@
+"""Operator layer of the PDM neck: autograd wrapper over pdm_scatter_bev / pdm_scatter_bev_grad.
+
+No reference counterpart exists; the arithmetic is the written spec in DESIGN.md
+("PDM spec") whose normative CPU statement is oracle/pdm_oracle.c.
+"""
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _native
+
+
+class BevGrid:
+    """fp32 grid parameters shared bit-for-bit by host, kernels and oracle."""
+
+    def __init__(self, point_cloud_range: Sequence[float], cell_size: Sequence[float]):
+        r = np.asarray(point_cloud_range, dtype=np.float64)
+        cs = np.asarray(cell_size, dtype=np.float64)
+        dims = np.round((r[3:6] - r[0:3]) / cs).astype(np.int64)
+        self.origin = r[0:3].astype(np.float32)
+        self.cell = cs.astype(np.float32)
+        self.inv_cell = (np.float32(1.0) / self.cell).astype(np.float32)
+        self.W, self.H, self.D = int(dims[0]), int(dims[1]), int(dims[2])
+
+    def floats(self):
+        return [float(v) for v in (*self.origin, *self.cell, *self.inv_cell)]
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(name, t, shape=None):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous fp32 GPU tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+
+
+class PDMScatter(Function):
+    """(xyz (B,P,3), feat (B,P,C), sh (B,P,(L+1)^2), inv2s2 (B,P)) -> (grid, wsum).
+
+    layout 1: grid (B,H,W,C*D) — channels-last storage; `.permute(0,3,1,2)` is the (B,C*D,H,W) BEV map.
+    layout 0: grid (B,C*D,H,W) contiguous.  wsum (B,H,W,D).  Gradients: feat, sh, inv2s2.
+    """
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, xyz, feat, sh, inv2s2, grid_spec: BevGrid, kernel: Tuple[int, int, int], degree: int,
+                layout: int = 1):
+        B, P, _ = xyz.shape
+        C = feat.shape[2]
+        nsh = (degree + 1) ** 2
+        _chk("xyz", xyz, (B, P, 3)); _chk("feat", feat, (B, P, C)); _chk("sh", sh, (B, P, nsh))
+        _chk("inv2s2", inv2s2, (B, P))
+        g = grid_spec
+        shape = (B, g.H, g.W, C * g.D) if layout == 1 else (B, C * g.D, g.H, g.W)
+        grid = torch.zeros(shape, dtype=torch.float32, device=xyz.device)
+        wsum = torch.zeros((B, g.H, g.W, g.D), dtype=torch.float32, device=xyz.device)
+        _native.call("pdm_scatter_bev", _stream(xyz), B, P, C, degree, xyz.data_ptr(), feat.data_ptr(),
+                     sh.data_ptr(), inv2s2.data_ptr(), *g.floats(), g.W, g.H, g.D, *kernel, layout,
+                     grid.data_ptr(), wsum.data_ptr())
+        ctx.save_for_backward(xyz, feat, sh, inv2s2)
+        ctx.spec = (g, tuple(kernel), degree, layout)
+        return grid, wsum
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dgrid, dwsum):
+        xyz, feat, sh, inv2s2 = ctx.saved_tensors
+        g, kernel, degree, layout = ctx.spec
+        B, P, _ = xyz.shape
+        C = feat.shape[2]
+        dgrid = dgrid.float().contiguous()
+        dwsum_ptr = 0
+        if dwsum is not None:
+            dwsum = dwsum.float().contiguous()
+            dwsum_ptr = dwsum.data_ptr()
+        dfeat = torch.empty_like(feat)
+        dsh = torch.empty_like(sh)
+        dinv = torch.empty_like(inv2s2)
+        _native.call("pdm_scatter_bev_grad", _stream(xyz), B, P, C, degree, xyz.data_ptr(), feat.data_ptr(),
+                     sh.data_ptr(), inv2s2.data_ptr(), *g.floats(), g.W, g.H, g.D, *kernel, layout,
+                     dgrid.data_ptr(), dwsum_ptr, dfeat.data_ptr(), dsh.data_ptr(), dinv.data_ptr())
+        return None, dfeat, dsh, dinv, None, None, None, None
+
+
+def pdm_scatter(xyz, feat, sh, inv2s2, grid_spec, kernel, degree, layout=1):
+    return PDMScatter.apply(xyz, feat, sh, inv2s2, grid_spec, tuple(kernel), degree, layout)
+
+
+def bev_normalize_(grid, wsum, C, grid_spec, layout=1, eps=1e-6):
+    """In-place grid /= wsum where |wsum| > eps (inference path; use torch ops when grads are needed)."""
+    g = grid_spec
+    _chk("grid", grid); _chk("wsum", wsum)
+    B = grid.shape[0]
+    _native.call("pdm_bev_normalize", _stream(grid), B, C, g.W, g.H, g.D, layout, float(eps), grid.data_ptr(),
+                 wsum.data_ptr())
+    return grid

@@ -130,6 +130,10 @@ def query_and_group_wrapper(b, n, m, c, radius, nsample, xyz, new_xyz, features,
         _check("features", features, torch.float32)
         _numel_at_least("features", features, b * c * n)
         fptr = features.data_ptr()
-    _run("pdm_query_and_group", xyz, b, n, m, c, float(radius), nsample, xyz.data_ptr(), new_xyz.data_ptr(),
-         fptr, idx.data_ptr(), out.data_ptr())
+    # two native calls (ball query, then the fused gather) so each kernel can be timed on its own;
+    # pdm_query_and_group is the single-call form of the same pair.
+    idx.zero_()
+    _run("pdm_ball_query", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+    _run("pdm_group_concat", xyz, b, n, m, c, nsample, xyz.data_ptr(), new_xyz.data_ptr(), fptr, idx.data_ptr(),
+         out.data_ptr())
     return 1

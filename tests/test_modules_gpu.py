@@ -1,0 +1,121 @@
+"""Module-level parity: SA / FP modules, PointNet2MSG and the PDM neck on the GPU against the CPU
+statement of the same graph (oracle operators + torch-CPU MLPs, oracle/cpu_backbone.py).
+Indices inside are bit-exact (tested per operator); features are fp32 through different GEMM
+implementations (MIOpen/hipBLASLt vs CPU) -> 1e-4, the tolerance north_star states."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from pdm_ssd_amd import synthetic
+from pdm_ssd_amd.pdm_neck import PDMNeck
+from pdm_ssd_amd.pointnet2_backbone import POINTRCNN_MSG_CFG, PointNet2MSG
+from pdm_ssd_amd.pointnet2_batch import pointnet2_modules as pm
+
+pytestmark = pytest.mark.gpu
+
+SMALL_CFG = {
+    'SA_CONFIG': {'NPOINTS': [512, 128, 32, 8],
+                  'RADIUS': [[0.5, 1.0], [1.0, 2.0], [2.0, 4.0], [4.0, 8.0]],
+                  'NSAMPLE': [[16, 32], [16, 32], [16, 32], [8, 16]],
+                  'MLPS': [[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]],
+                           [[128, 196, 256], [128, 196, 256]], [[256, 256, 512], [256, 384, 512]]]},
+    'FP_MLPS': [[128, 128], [256, 256], [512, 512], [512, 512]],
+}
+
+
+def randomize_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+def test_sa_module_msg(dev):
+    from oracle import cpu_backbone
+    torch.manual_seed(0)
+    sa = pm.PointnetSAModuleMSG(npoint=256, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[1, 16, 32], [1, 16, 48]]).eval()
+    randomize_bn(sa, 1)
+    cl = synthetic.lidar_like_clouds(2, 2048, 3)
+    xyz = np.ascontiguousarray(cl[:, :, :3]); feat = np.ascontiguousarray(cl[:, :, 3:].transpose(0, 2, 1))
+    ref_xyz, ref_feat = cpu_backbone.sa_forward(sa, xyz, feat)
+    sa_g = copy.deepcopy(sa).to(dev)
+    with torch.no_grad():
+        nx, nf = sa_g(torch.from_numpy(xyz).to(dev), torch.from_numpy(feat).to(dev))
+    np.testing.assert_array_equal(nx.cpu().numpy(), ref_xyz)
+    assert tuple(nf.shape) == (2, 80, 256)
+    np.testing.assert_allclose(nf.cpu().numpy(), ref_feat, rtol=1e-4, atol=1e-4)
+
+
+def test_fp_module(dev):
+    from oracle import cpu_backbone
+    torch.manual_seed(1)
+    fp = pm.PointnetFPModule(mlp=[40 + 6, 64, 32]).eval()
+    randomize_bn(fp, 2)
+    rng = np.random.default_rng(0)
+    unknown = synthetic.uniform_clouds(2, 1024, 5)[:, :, :3].copy()
+    known = np.ascontiguousarray(unknown[:, :200])
+    uf = rng.standard_normal((2, 6, 1024)).astype(np.float32)
+    kf = rng.standard_normal((2, 40, 200)).astype(np.float32)
+    ref = cpu_backbone.fp_forward(fp, unknown, known, uf, kf)
+    fp_g = copy.deepcopy(fp).to(dev)
+    with torch.no_grad():
+        got = fp_g(*(torch.from_numpy(a).to(dev) for a in (unknown, known, uf, kf)))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_backbone_and_neck_end_to_end(dev):
+    from oracle import cpu_backbone
+    torch.manual_seed(2)
+    bb = PointNet2MSG(SMALL_CFG, input_channels=4).eval()
+    randomize_bn(bb, 3)
+    neck = PDMNeck({'SOURCE_LAYER': 2, 'FEATURE_DIM': 32, 'DILATION': [5, 5, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 16,
+                    'HEIGHT_BINS': 2, 'INPUT_CHANNELS': 256}, grid_size=[1408, 1600, 40],
+                   voxel_size=[0.05, 0.05, 0.1], point_cloud_range=list(synthetic.KITTI_RANGE)).eval()
+    with torch.no_grad():
+        neck.coef.weight.normal_(0, 0.05)
+    randomize_bn(neck, 4)
+    cl = synthetic.lidar_like_clouds(2, 2048, 21)
+    ref = cpu_backbone.backbone_forward(bb, cl)
+    ref_sf = cpu_backbone.neck_forward(neck, ref['sa_xyz'], ref['sa_features'])
+
+    bb_g, neck_g = copy.deepcopy(bb).to(dev), copy.deepcopy(neck).to(dev)
+    pts = torch.from_numpy(synthetic.to_batch_points(cl)).to(dev)
+    with torch.no_grad():
+        bd = neck_g(bb_g({'batch_size': 2, 'points': pts}))
+    assert tuple(bd['point_features'].shape) == (2 * 2048, 128)
+    assert tuple(bd['point_coords'].shape) == (2 * 2048, 4)
+    for k in range(1, 5):
+        np.testing.assert_array_equal(bd['sa_xyz'][k].cpu().numpy(), ref['sa_xyz'][k])
+    np.testing.assert_allclose(bd['point_features'].cpu().numpy(), ref['point_features'], rtol=1e-4, atol=1e-4)
+    sf = bd['spatial_features']
+    assert tuple(sf.shape) == (2, 64, 100, 88) and bd['spatial_features_stride'] == 16
+    np.testing.assert_allclose(sf.cpu().numpy(), ref_sf, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(ref_sf).max()))
+
+
+def test_backbone_rejects_ragged_batches(dev):
+    bb = PointNet2MSG(SMALL_CFG, input_channels=4).to(dev).eval()
+    cl = synthetic.uniform_clouds(2, 1024, 1)
+    pts = torch.from_numpy(synthetic.to_batch_points(cl)[:-5]).to(dev)  # second sample 5 points short
+    with pytest.raises(AssertionError):
+        bb({'batch_size': 2, 'points': pts})
+
+
+def test_training_step_backward_runs(dev):
+    """forward+backward through SA (fused grouping) + FP + neck: gradients reach every parameter."""
+    torch.manual_seed(5)
+    bb = PointNet2MSG(SMALL_CFG, input_channels=4).to(dev).train()
+    neck = PDMNeck({'SOURCE_LAYER': 2, 'FEATURE_DIM': 16, 'DILATION': [3, 3, 1], 'SH_DEGREE': 1, 'BEV_STRIDE': 16,
+                    'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 256}, grid_size=[1408, 1600, 40],
+                   voxel_size=[0.05, 0.05, 0.1], point_cloud_range=list(synthetic.KITTI_RANGE)).to(dev).train()
+    cl = synthetic.lidar_like_clouds(2, 2048, 8)
+    pts = torch.from_numpy(synthetic.to_batch_points(cl)).to(dev)
+    bd = neck(bb({'batch_size': 2, 'points': pts}))
+    loss = bd['point_features'].square().mean() + bd['spatial_features'].square().mean()
+    loss.backward()
+    for name, p in list(bb.named_parameters()) + list(neck.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name

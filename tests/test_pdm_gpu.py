@@ -1,0 +1,117 @@
+"""PDM neck scatter (build-defined spec): HIP kernels vs oracle/pdm_oracle.c.
+
+fp32 with free summation order (atomics) and device transcendental functions -> tolerance 1e-4
+relative to the tensor's scale, as north_star states for features.  Parity is with THIS repo's
+written spec only: the reference snapshot has no PDM source.
+"""
+import numpy as np
+import pytest
+import torch
+
+from pdm_ssd_amd import pdm_ops
+
+pytestmark = pytest.mark.gpu
+
+RANGE = (0.0, -40.0, -3.0, 70.4, 40.0, 1.0)
+
+
+def make_inputs(B, P, C, degree, seed, outliers=True):
+    rng = np.random.default_rng(seed)
+    xyz = np.stack([rng.uniform(0, 70.4, (B, P)), rng.uniform(-40, 40, (B, P)), rng.uniform(-3, 1, (B, P))], -1)
+    xyz = xyz.astype(np.float32)
+    if outliers:
+        xyz[:, 0] = [-0.3, -39.9, 0.9]      # dilation block partly outside
+        xyz[:, 1] = [500.0, 0.0, 0.0]       # far outside: contributes nothing
+        xyz[:, 2] = [np.nan, 0.0, 0.0]      # NaN point: skipped
+        xyz[:, 3] = [70.39, 39.99, 0.99]    # last cell
+        xyz[:, 4] = xyz[:, 5]               # two centres in the same cell (multi-centre fusion)
+    feat = rng.standard_normal((B, P, C)).astype(np.float32)
+    sh = (rng.standard_normal((B, P, (degree + 1) ** 2)) * 0.5).astype(np.float32)
+    sh[..., 0] += 3.0
+    sigma = rng.uniform(0.3, 1.5, (B, P)).astype(np.float32)
+    inv2s2 = (0.5 / (sigma * sigma)).astype(np.float32)
+    return xyz, feat, sh, inv2s2
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("layout", [1, 0])
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+@pytest.mark.parametrize("cell,kernel", [((0.8, 0.8, 4.0), (7, 7, 1)), ((1.6, 1.6, 2.0), (3, 5, 3))])
+def test_scatter_matches_oracle(oracle, dev, layout, degree, cell, kernel):
+    B, P, C = 2, 200, 70
+    xyz, feat, sh, inv2s2 = make_inputs(B, P, C, degree, seed=degree * 10 + layout)
+    g = pdm_ops.BevGrid(RANGE, cell)
+    origin, cellf, inv_cell, dims = oracle.pdm_grid_params(RANGE, cell)
+    assert dims == (g.W, g.H, g.D)
+    np.testing.assert_array_equal(inv_cell, g.inv_cell)
+    ref_grid, ref_wsum = oracle.pdm_scatter(xyz, feat, sh, inv2s2, origin, cellf, inv_cell, dims, kernel, degree, layout)
+    grid, wsum = pdm_ops.pdm_scatter(T(xyz, dev), T(feat, dev), T(sh, dev), T(inv2s2, dev), g, kernel, degree, layout)
+    scale = np.abs(ref_grid).max()
+    np.testing.assert_allclose(grid.cpu().numpy(), ref_grid, rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(wsum.cpu().numpy(), ref_wsum, rtol=1e-4, atol=1e-4 * np.abs(ref_wsum).max())
+    # sparsity: cells no dilation block touches are exactly zero
+    assert (grid.cpu().numpy()[ref_grid == 0] == 0).all()
+    # normalisation
+    ref_n = oracle.pdm_normalize(ref_grid, ref_wsum, C, dims, layout)
+    got_n = pdm_ops.bev_normalize_(grid.clone(), wsum, C, g, layout).cpu().numpy()
+    np.testing.assert_allclose(got_n, ref_n, rtol=2e-3, atol=2e-3 * np.abs(ref_n).max())
+
+
+def test_scatter_linearity_and_zero_features(dev):
+    """Size-independent property: the scatter is linear in the features."""
+    B, P, C = 3, 512, 128
+    xyz, feat, sh, inv2s2 = make_inputs(B, P, C, 2, seed=5)
+    g = pdm_ops.BevGrid(RANGE, (0.4, 0.4, 4.0))
+    args = (T(xyz, dev), None, T(sh, dev), T(inv2s2, dev), g, (7, 7, 1), 2, 1)
+    f1 = T(feat, dev)
+    f2 = torch.randn_like(f1)
+    ga, wa = pdm_ops.pdm_scatter(args[0], f1, *args[2:])
+    gb, wb = pdm_ops.pdm_scatter(args[0], f2, *args[2:])
+    gc, wc = pdm_ops.pdm_scatter(args[0], 2.0 * f1 - 3.0 * f2, *args[2:])
+    torch.testing.assert_close(gc, 2.0 * ga - 3.0 * gb, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(wa, wc, rtol=1e-5, atol=1e-5)
+    gz, _ = pdm_ops.pdm_scatter(args[0], torch.zeros_like(f1), *args[2:])
+    assert float(gz.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("layout", [1, 0])
+@pytest.mark.parametrize("degree,kernel,cell", [(2, (7, 7, 1), (0.8, 0.8, 4.0)), (3, (3, 3, 3), (1.6, 1.6, 2.0))])
+def test_scatter_grad_matches_oracle(oracle, dev, layout, degree, kernel, cell):
+    B, P, C = 2, 150, 70
+    xyz, feat, sh, inv2s2 = make_inputs(B, P, C, degree, seed=77)
+    g = pdm_ops.BevGrid(RANGE, cell)
+    origin, cellf, inv_cell, dims = oracle.pdm_grid_params(RANGE, cell)
+    rng = np.random.default_rng(1)
+    shape = (B, g.H, g.W, C * g.D) if layout == 1 else (B, C * g.D, g.H, g.W)
+    dgrid = rng.standard_normal(shape).astype(np.float32)
+    dwsum = rng.standard_normal((B, g.H, g.W, g.D)).astype(np.float32)
+    rf, rs, ri = oracle.pdm_scatter_grad(xyz, feat, sh, inv2s2, origin, cellf, inv_cell, dims, kernel, degree,
+                                         dgrid, dwsum, layout)
+    f, s, i2 = (T(a, dev).requires_grad_(True) for a in (feat, sh, inv2s2))
+    grid, wsum = pdm_ops.pdm_scatter(T(xyz, dev), f, s, i2, g, kernel, degree, layout)
+    torch.autograd.backward([grid, wsum], [T(dgrid, dev), T(dwsum, dev)])
+    for got, ref in ((f.grad, rf), (s.grad, rs), (i2.grad, ri)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(ref).max()))
+
+
+def test_neck_module_contract(dev):
+    from pdm_ssd_amd.pdm_neck import PDMNeck
+    cfg = {'SOURCE_LAYER': 1, 'FEATURE_DIM': 32, 'DILATION': [5, 5, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 8,
+           'HEIGHT_BINS': 2, 'INPUT_CHANNELS': 24}
+    neck = PDMNeck(cfg, grid_size=[1408, 1600, 40], voxel_size=[0.05, 0.05, 0.1], point_cloud_range=RANGE).to(dev)
+    assert neck.num_bev_features == 64
+    xyz, feat, _, _ = make_inputs(2, 300, 24, 2, seed=3, outliers=False)
+    bd = {'sa_xyz': [None, T(xyz, dev)], 'sa_features': [None, T(feat, dev).transpose(1, 2).contiguous()]}
+    neck.train()
+    out = neck(bd)
+    sf = out['spatial_features']
+    assert tuple(sf.shape) == (2, 64, 200, 176) and out['spatial_features_stride'] == 8
+    sf.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in neck.parameters())
+    neck.eval()
+    with torch.no_grad():
+        sf2 = neck({'sa_xyz': bd['sa_xyz'], 'sa_features': bd['sa_features']})['spatial_features']
+    assert torch.isfinite(sf2).all()
