@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from . import cpu_oracle as o
 
 
+@torch.no_grad()
 def sa_forward(sa_cpu, xyz, features):
     """sa_cpu: a PointnetSAModuleMSG on the CPU (weights only are used).  xyz (B,N,3) np, features (B,C,N) np|None."""
     idx = o.furthest_point_sample(xyz, sa_cpu.npoint)
@@ -30,6 +31,7 @@ def sa_forward(sa_cpu, xyz, features):
     return new_xyz, torch.cat(outs, dim=1).numpy()
 
 
+@torch.no_grad()
 def fp_forward(fp_cpu, unknown, known, unknow_feats, known_feats):
     dist, idx = o.three_nn(unknown, known)
     d = torch.from_numpy(dist)
