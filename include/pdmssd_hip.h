@@ -101,6 +101,27 @@ int pdm_query_and_group(void *stream, int b, int n, int m, int c, float radius, 
 int pdm_group_concat(void *stream, int b, int n, int m, int c, int nsample, const float *xyz,
                      const float *new_xyz, const float *features, const int *idx, float *out);
 
+/* Fused inference forms of one SA scale / one FP module on fp32 MFMA (BatchNorm folded into the
+ * weights by the host; pdm_ssd_amd/fused.py builds `dims`, `wpack`, `bias`).  Features are POINT-MAJOR
+ * here: feat_pm (B,N,cin), out_pm (B,M,out_stride) with this scale's channels at [out_coff, out_coff+cout).
+ * dims = nlayers+1 host ints: padded (multiple-of-16) widths K0, C1..CL.  wpack = per layer, for each
+ * 16x16 block (mb, kb): 64 lanes x float4 = W'[16mb + (lane&15)][16kb + 4(lane>>4) + 0..3]; bias = the
+ * padded per-layer shifts.  SA input channel order is [features(cin), dx, dy, dz, zero pad].
+ *
+ * pdm_sa_mlp_fused == pointnet2_utils.py:250-257 (group xyz/features, subtract centre, cat) +
+ *                     pointnet2_modules.py:40-52 (MLP, max_pool2d over nsample) for a given idx. */
+int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
+                     const float *new_xyz, const float *feat_pm, const int *idx, int nlayers,
+                     const int *dims, const float *wpack, const float *bias, float *out_pm,
+                     int out_stride, int out_coff, int cout);
+
+/* pdm_fp_mlp_fused == pointnet2_modules.py:158-170 (three_interpolate, cat with the skip features, MLP)
+ * for given idx/weight (B,n,3): known_pm (B,m,c_known), skip_pm (B,n,c_skip) or NULL -> out_pm (B,n,out_stride). */
+int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, int c_skip,
+                     const float *known_pm, const float *skip_pm, const int *idx, const float *weight,
+                     int nlayers, const int *dims, const float *wpack, const float *bias,
+                     float *out_pm, int out_stride, int cout);
+
 /* ---- PDM neck (build-defined spec, DESIGN.md "PDM spec"; no reference source exists) ------- */
 
 /* Multi-centre scatter-add of dilated, SH x Gaussian weighted point features into a BEV grid.

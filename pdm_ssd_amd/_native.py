@@ -31,6 +31,9 @@ _SIGNATURES = {
     "pdm_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_query_and_group": [_i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_group_concat": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
+    "pdm_tune_fps_variant": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,
@@ -60,7 +63,7 @@ def lib():
         for name, args in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = _i
-            fn.argtypes = [_vp] + args
+            fn.argtypes = [_i] if args is None else [_vp] + args
         _lib = l
     return _lib
 

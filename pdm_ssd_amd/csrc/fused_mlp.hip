@@ -1,0 +1,434 @@
+// Fused "gather -> shared MLP -> pool/store" kernels on fp32 MFMA for gfx950 (inference: BatchNorm
+// folded into the 1x1-conv weights on the host).
+//
+// Replaces, for one SA scale, the chain of pointnet2_utils.py:250-257 (two grouping_operation calls,
+// subtract, torch.cat) + pointnet2_modules.py:40-52 (3 x [Conv2d 1x1, BatchNorm2d, ReLU], max_pool2d)
+// and, for one FP module, pointnet2_modules.py:158-170 (three_interpolate, cat, 2 x [conv, BN, ReLU]);
+// the (B, C, M, nsample) tensors of the reference never exist in HBM.
+//
+// Design (CDNA4-first, not a CUDA tiling): ONE wave64 = one workgroup = one tile of 16 positions;
+// waves are fully independent (no barriers).  The contraction is computed TRANSPOSED,
+//     H_l^T [C_l x 16 positions] = W_l [C_l x K] * H_{l-1}^T [K x 16],
+// with v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains):
+//   A operand = weights, host-prepacked so lane (oc = l&15, g = l>>4) reads ONE float4 per 16-deep
+//               K block = its A values of 4 consecutive MFMAs (1 KiB coalesced per wave instruction);
+//   B operand = activations: lane (pos = l&15, g) needs H[pos][16kb + 4g + s], s = 0..3 = one
+//               ds_read_b128 from the wave-private LDS tile H[pos][K] (or one 16-byte gather from a
+//               point-major feature row in the first layer);
+//   D         = lane (pos, g) holds output channels 16mb + 4g + i, i = 0..3 = exactly the float4 the
+//               NEXT layer reads as its B operand, so the epilogue is bias + ReLU + one ds_write_b128.
+// Features are point-major ((B, N, C), C contiguous) inside the fused path so a gathered neighbour is
+// one contiguous row.  Max-pool over nsample = DPP row-max over the 16 lanes that share g.
+#include "common.h"
+
+namespace pdm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int FM_MAXL = 4;
+
+struct MlpDesc {
+    int nlayers;
+    int K[FM_MAXL + 1];  // padded (multiple of 16) channel counts: K[0] input, K[l] output of layer l
+    int woff[FM_MAXL];   // float offsets of each layer's packed weights / bias
+    int boff[FM_MAXL];
+    int stage_in;        // 1: layer-1 input is gathered once into LDS; 0: re-gathered per output block pair
+    int lds_p, lds_q;    // LDS tile widths (floats per position, incl. +4 pad) of the two ping-pong buffers
+};
+
+struct SaArgs {
+    int b, n, m, cin, ns;
+    const float *xyz;      // (B,N,3)
+    const float *new_xyz;  // (B,M,3)
+    const float *feat;     // (B,N,cin) point-major, may be null when cin == 0
+    const int *idx;        // (B,M,ns)
+    float *out;            // (B,M,out_stride) point-major
+    int out_stride, out_coff, cout;
+};
+
+struct FpArgs {
+    int b, n, m, c_known, c_skip;
+    const float *known;   // (B,m,c_known) point-major
+    const float *skip;    // (B,n,c_skip) point-major, may be null
+    const int *idx;       // (B,n,3)
+    const float *weight;  // (B,n,3)
+    float *out;           // (B,n,out_stride) point-major
+    int out_stride, cout;
+};
+
+__device__ __forceinline__ f4 mfma4(f4 acc, f4 a, f4 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ f4 relu4(f4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+
+// max over the 16 lanes of a DPP row (values are >= 0 after ReLU, so the integer image orders them)
+__device__ __forceinline__ float row16_max_nonneg(float f) {
+    int v = __builtin_bit_cast(int, f);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_bit_cast(float, v);
+}
+
+// ---- B-operand providers: float4 of channels [16kb + 4g, +4) of this lane's position ------------
+
+struct LdsIn {
+    const float *row;  // &H[pos][4g]
+    __device__ __forceinline__ f4 operator()(int kb) const {
+        return *reinterpret_cast<const f4 *>(row + 16 * kb);
+    }
+};
+
+// SA: virtual row = [gathered feature row (cin), xyz[nb] - centre (3), zeros]
+struct SaIn {
+    const float *frow;  // feature row of this lane's neighbour (or null)
+    float rx, ry, rz;
+    int cin, g;
+    bool vec;           // cin % 4 == 0 and 16-byte aligned rows
+    __device__ __forceinline__ float elem(int c) const {
+        if (c < cin) return frow[c];
+        const int e = c - cin;
+        return e == 0 ? rx : e == 1 ? ry : e == 2 ? rz : 0.0f;
+    }
+    __device__ __forceinline__ f4 operator()(int kb) const {
+        const int c0 = 16 * kb + 4 * g;
+        if (vec && c0 + 4 <= cin) return *reinterpret_cast<const f4 *>(frow + c0);
+        f4 v;
+        v.x = elem(c0); v.y = elem(c0 + 1); v.z = elem(c0 + 2); v.w = elem(c0 + 3);
+        return v;
+    }
+};
+
+// FP: virtual row = [w0*known[i0] + w1*known[i1] + w2*known[i2] (c_known), skip row (c_skip), zeros];
+// the interpolation keeps the oracle's rounding sequence fma(w2,p2, fma(w1,p1, rn(w0*p0))).
+struct FpIn {
+    const float *r0, *r1, *r2, *srow;
+    float w0, w1, w2;
+    int ck, cs, g;
+    bool vec_k, vec_s, live;
+    __device__ __forceinline__ float interp(float a, float b, float c) const {
+        return __fmaf_rn(w2, c, __fmaf_rn(w1, b, __fmul_rn(w0, a)));
+    }
+    __device__ __forceinline__ float elem(int c) const {
+        if (c < ck) return interp(r0[c], r1[c], r2[c]);
+        const int e = c - ck;
+        return e < cs ? srow[e] : 0.0f;
+    }
+    __device__ __forceinline__ f4 operator()(int kb) const {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!live) return v;
+        const int c0 = 16 * kb + 4 * g;
+        if (vec_k && c0 + 4 <= ck) {
+            const f4 a = *reinterpret_cast<const f4 *>(r0 + c0);
+            const f4 b = *reinterpret_cast<const f4 *>(r1 + c0);
+            const f4 c = *reinterpret_cast<const f4 *>(r2 + c0);
+            v.x = interp(a.x, b.x, c.x); v.y = interp(a.y, b.y, c.y);
+            v.z = interp(a.z, b.z, c.z); v.w = interp(a.w, b.w, c.w);
+            return v;
+        }
+        if (vec_s && c0 >= ck && c0 + 4 <= ck + cs) return *reinterpret_cast<const f4 *>(srow + (c0 - ck));
+        v.x = elem(c0); v.y = elem(c0 + 1); v.z = elem(c0 + 2); v.w = elem(c0 + 3);
+        return v;
+    }
+};
+
+// ---- sinks: receive the bias+ReLU'd float4 (channels 16mb + 4g .. +3 of this lane's position) ---
+
+struct LdsOut {
+    float *row;  // &H[pos][4g]
+    __device__ __forceinline__ void operator()(int mb, f4 v) const {
+        *reinterpret_cast<f4 *>(row + 16 * mb) = v;
+    }
+};
+
+// SA epilogue: max over the 16 positions of the tile; tiles of one centre combine through `pool`.
+struct PoolOut {
+    float *pool;   // LDS, K_last floats, wave-private
+    float *orow;   // &out[b][j][coff]
+    int cout, lane, g;
+    bool first_tile, last_tile;
+    __device__ __forceinline__ void operator()(int mb, f4 v) const {
+        v.x = row16_max_nonneg(v.x); v.y = row16_max_nonneg(v.y);
+        v.z = row16_max_nonneg(v.z); v.w = row16_max_nonneg(v.w);
+        if ((lane & 15) != 0) return;
+        float *p = pool + 16 * mb + 4 * g;
+        if (!first_tile) {
+            const f4 o = *reinterpret_cast<const f4 *>(p);
+            v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
+        }
+        if (!last_tile) {
+            *reinterpret_cast<f4 *>(p) = v;
+            return;
+        }
+        const int c0 = 16 * mb + 4 * g;
+        if (c0 + 4 <= cout) {
+            *reinterpret_cast<f4 *>(orow + c0) = v;  // host guarantees 16-byte alignment of orow
+        } else {
+            if (c0 < cout) orow[c0] = v.x;
+            if (c0 + 1 < cout) orow[c0 + 1] = v.y;
+            if (c0 + 2 < cout) orow[c0 + 2] = v.z;
+        }
+    }
+};
+
+struct RowOut {
+    float *orow;  // &out[b][p][0], null for positions past n
+    int cout, g;
+    __device__ __forceinline__ void operator()(int mb, f4 v) const {
+        if (!orow) return;
+        const int c0 = 16 * mb + 4 * g;
+        if (c0 + 4 <= cout) {
+            *reinterpret_cast<f4 *>(orow + c0) = v;
+        } else {
+            if (c0 < cout) orow[c0] = v.x;
+            if (c0 + 1 < cout) orow[c0 + 1] = v.y;
+            if (c0 + 2 < cout) orow[c0 + 2] = v.z;
+        }
+    }
+};
+
+// One layer: for every pair of 16-channel output blocks, a K loop of {1 B fragment, 2 A fragments,
+// 8 MFMAs}; the next iteration's fragments are requested before this iteration's MFMAs issue.
+template <class In, class Out>
+__device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restrict__ wp,
+                                          const float *__restrict__ bias, int lane, const In &in,
+                                          const Out &out) {
+    const int g = lane >> 4;
+    const f4 *__restrict__ w = reinterpret_cast<const f4 *>(wp) + lane;
+    for (int mb = 0; mb < nmb; mb += 2) {
+        const bool two = mb + 1 < nmb;
+        const f4 *__restrict__ w0 = w + (size_t)mb * nkb * 64;
+        const f4 *__restrict__ w1 = two ? w0 + (size_t)nkb * 64 : w0;
+        f4 acc0 = *reinterpret_cast<const f4 *>(bias + 16 * mb + 4 * g);
+        f4 acc1 = two ? *reinterpret_cast<const f4 *>(bias + 16 * (mb + 1) + 4 * g) : acc0;
+        f4 bn = in(0), a0n = w0[0], a1n = w1[0];
+        for (int kb = 0; kb < nkb; ++kb) {
+            const f4 b = bn, a0 = a0n, a1 = a1n;
+            if (kb + 1 < nkb) {
+                bn = in(kb + 1);
+                a0n = w0[(size_t)(kb + 1) * 64];
+                a1n = w1[(size_t)(kb + 1) * 64];
+            }
+            acc0 = mfma4(acc0, a0, b);
+            if (two) acc1 = mfma4(acc1, a1, b);  // wave-uniform
+        }
+        out(mb, relu4(acc0));
+        if (two) out(mb + 1, relu4(acc1));
+    }
+}
+
+// Runs layers 1..nlayers for one tile.  P/Q = the wave's two LDS buffers (widths lds_p / lds_q):
+// layer 1 writes Q, layer 2 writes P, layer 3 writes Q ...; a staged input tile lives in P.
+// The layer loop is unrolled so every descriptor field is read with a constant index (a runtime
+// index into the by-value descriptor would push it to scratch).
+template <int L, class In, class Out>
+__device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restrict__ wpack,
+                                          const float *__restrict__ bias, float *P, float *Q, int lane,
+                                          const In &in, const Out &out) {
+    const int pos = lane & 15, g = lane >> 4;
+    const int nkb = d.K[L - 1] >> 4, nmb = d.K[L] >> 4;
+    const float *wl = wpack + d.woff[L - 1];
+    const float *bl = bias + d.boff[L - 1];
+    const bool last = L == d.nlayers;
+    float *ob = (L & 1) ? Q : P;
+    const int ow = (L & 1) ? d.lds_q : d.lds_p;
+    const LdsOut lo{ob + pos * ow + 4 * g};
+    if (L == 1 && !d.stage_in) {
+        if (last) mlp_layer(nkb, nmb, wl, bl, lane, in, out);
+        else mlp_layer(nkb, nmb, wl, bl, lane, in, lo);
+    } else {
+        float *ib = (L & 1) ? P : Q;  // layer 1 (staged) and layer 3 read P, layer 2 reads Q
+        const int iw = (L & 1) ? d.lds_p : d.lds_q;
+        const LdsIn li{ib + pos * iw + 4 * g};
+        if (last) mlp_layer(nkb, nmb, wl, bl, lane, li, out);
+        else mlp_layer(nkb, nmb, wl, bl, lane, li, lo);
+    }
+    // LDS ops of one wave execute in order; keep the compiler from moving reads above the writes
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class In, class Out>
+__device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restrict__ wpack,
+                                        const float *__restrict__ bias, float *P, float *Q, int lane,
+                                        const In &in, const Out &out) {
+    if (d.stage_in) {
+        // gather the input tile once: P[pos][K0]
+        float *row = P + (lane & 15) * d.lds_p + 4 * (lane >> 4);
+        const int nkb0 = d.K[0] >> 4;
+        for (int kb = 0; kb < nkb0; ++kb) *reinterpret_cast<f4 *>(row + 16 * kb) = in(kb);
+        __builtin_amdgcn_wave_barrier();
+    }
+    run_layer<1>(d, wpack, bias, P, Q, lane, in, out);
+    if (d.nlayers >= 2) run_layer<2>(d, wpack, bias, P, Q, lane, in, out);
+    if (d.nlayers >= 3) run_layer<3>(d, wpack, bias, P, Q, lane, in, out);
+    if (d.nlayers >= 4) run_layer<4>(d, wpack, bias, P, Q, lane, in, out);
+}
+
+__global__ __launch_bounds__(64) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
+                                                          const float *__restrict__ wpack,
+                                                          const float *__restrict__ bias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int pos = lane & 15, g = lane >> 4;
+    float *P = lds;
+    float *Q = P + 16 * d.lds_p;
+    float *pool = Q + 16 * d.lds_q;
+    const int tiles_per_centre = a.ns >> 4;
+    const long long ncentres = (long long)a.b * a.m;
+    for (long long ctr = blockIdx.x; ctr < ncentres; ctr += gridDim.x) {
+        const int b = (int)(ctr / a.m);
+        const float *c3 = a.new_xyz + ctr * 3;
+        const float cx = c3[0], cy = c3[1], cz = c3[2];
+        for (int t = 0; t < tiles_per_centre; ++t) {
+            const int nb = a.idx[ctr * a.ns + t * 16 + pos];
+            const float *p3 = a.xyz + ((size_t)b * a.n + nb) * 3;
+            SaIn in;
+            in.frow = a.cin > 0 ? a.feat + ((size_t)b * a.n + nb) * a.cin : nullptr;
+            in.rx = p3[0] - cx; in.ry = p3[1] - cy; in.rz = p3[2] - cz;  // pointnet2_utils.py:252
+            in.cin = a.cin; in.g = g;
+            in.vec = (a.cin & 3) == 0 && a.cin > 0;
+            PoolOut out;
+            out.pool = pool;
+            out.orow = a.out + ctr * a.out_stride + a.out_coff;
+            out.cout = a.cout; out.lane = lane; out.g = g;
+            out.first_tile = t == 0; out.last_tile = t == tiles_per_centre - 1;
+            run_mlp(d, wpack, bias, P, Q, lane, in, out);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
+                                                          const float *__restrict__ wpack,
+                                                          const float *__restrict__ bias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int pos = lane & 15, g = lane >> 4;
+    float *P = lds;
+    float *Q = P + 16 * d.lds_p;
+    const int tiles_per_sample = (a.n + 15) >> 4;
+    const long long ntiles = (long long)a.b * tiles_per_sample;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_sample);
+        const int p = (int)(tile - (long long)b * tiles_per_sample) * 16 + pos;
+        FpIn in;
+        in.live = p < a.n;
+        const size_t q = (size_t)b * a.n + (in.live ? p : 0);
+        const int *id = a.idx + q * 3;
+        const float *w = a.weight + q * 3;
+        in.r0 = a.known + ((size_t)b * a.m + id[0]) * a.c_known;
+        in.r1 = a.known + ((size_t)b * a.m + id[1]) * a.c_known;
+        in.r2 = a.known + ((size_t)b * a.m + id[2]) * a.c_known;
+        in.w0 = w[0]; in.w1 = w[1]; in.w2 = w[2];
+        in.srow = a.c_skip > 0 ? a.skip + q * a.c_skip : nullptr;
+        in.ck = a.c_known; in.cs = a.c_skip; in.g = g;
+        in.vec_k = (a.c_known & 3) == 0;
+        in.vec_s = (a.c_skip & 3) == 0 && (a.c_known & 3) == 0 && a.c_skip > 0;
+        RowOut out;
+        out.orow = in.live ? a.out + q * a.out_stride : nullptr;
+        out.cout = a.cout; out.g = g;
+        run_mlp(d, wpack, bias, P, Q, lane, in, out);
+    }
+}
+
+static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max) {
+    PDM_REQUIRE(nlayers >= 1 && nlayers <= FM_MAXL, PDM_E_BADARG, "%s: nlayers=%d not in [1,%d]", who, nlayers, FM_MAXL);
+    PDM_REQUIRE(dims, PDM_E_BADARG, "%s: null dims", who);
+    d.nlayers = nlayers;
+    int wo = 0, bo = 0;
+    for (int l = 0; l <= nlayers; ++l) {
+        PDM_REQUIRE(dims[l] > 0 && dims[l] % 16 == 0, PDM_E_BADARG, "%s: padded width %d of level %d is not a positive multiple of 16", who, dims[l], l);
+        d.K[l] = dims[l];
+    }
+    for (int l = 0; l < nlayers; ++l) {
+        d.woff[l] = wo; d.boff[l] = bo;
+        wo += d.K[l] * d.K[l + 1];
+        bo += d.K[l + 1];
+    }
+    PDM_REQUIRE(d.K[0] >= k0_real_max, PDM_E_BADARG, "%s: padded input width %d < %d real channels", who, d.K[0], k0_real_max);
+    // ping-pong buffers: Q holds outputs of layers 1,3; P holds the staged input and outputs of layer 2
+    int q = 0, p = 0;
+    for (int l = 1; l < nlayers; ++l) {
+        if (l & 1) q = q > d.K[l] ? q : d.K[l]; else p = p > d.K[l] ? p : d.K[l];
+    }
+    const int p_staged = p > d.K[0] ? p : d.K[0];
+    // stage the input tile in LDS when that keeps >= 4 waves per CU (<= 40 KB per wave)
+    d.stage_in = (16 * (p_staged + 4 + q + 4) + d.K[nlayers]) * 4 <= 40 * 1024 ? 1 : 0;
+    if (d.stage_in) p = p_staged;
+    d.lds_p = p + 4;  // +4 floats: consecutive positions start 4 banks apart (conflict-free b128 rows)
+    d.lds_q = q + 4;
+    return 0;
+}
+
+}  // namespace pdm
+
+using namespace pdm;
+
+extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample,
+                                const float *xyz, const float *new_xyz, const float *feat_pm,
+                                const int *idx, int nlayers, const int *dims, const float *wpack,
+                                const float *bias, float *out_pm, int out_stride, int out_coff,
+                                int cout) {
+    PDM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && cin >= 0 && nsample > 0, PDM_E_BADARG, "sa_mlp_fused: bad size");
+    PDM_REQUIRE(nsample % 16 == 0, PDM_E_BADARG, "sa_mlp_fused: nsample=%d must be a multiple of 16", nsample);
+    if (b == 0 || m == 0) return 0;
+    PDM_REQUIRE(xyz && new_xyz && idx && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
+                "sa_mlp_fused: null pointer");
+    MlpDesc d;
+    int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3);
+    if (rc) return rc;
+    PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && out_coff >= 0 && out_coff + cout <= out_stride, PDM_E_BADARG,
+                "sa_mlp_fused: cout=%d coff=%d stride=%d", cout, out_coff, out_stride);
+    PDM_REQUIRE(out_stride % 4 == 0 && out_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
+                    (cin % 4 != 0 || (reinterpret_cast<uintptr_t>(feat_pm) & 15) == 0),
+                PDM_E_BADARG, "sa_mlp_fused: out/wpack/bias/feat must be 16-byte aligned, out_stride and out_coff multiples of 4");
+    SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout};
+    const size_t lds_bytes = (size_t)(16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
+    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    const long long ncentres = (long long)b * m;
+    const int blocks = (int)(ncentres < 256 * 64 ? ncentres : 256 * 64);
+    hipLaunchKernelGGL(sa_mlp_fused_kernel, dim3(blocks), dim3(64), lds_bytes, as_stream(stream), d, a, wpack, bias);
+    return check_launch("sa_mlp_fused");
+}
+
+extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, int c_skip,
+                                const float *known_pm, const float *skip_pm, const int *idx,
+                                const float *weight, int nlayers, const int *dims, const float *wpack,
+                                const float *bias, float *out_pm, int out_stride, int cout) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 1 && c_known >= 1 && c_skip >= 0, PDM_E_BADARG, "fp_mlp_fused: bad size");
+    if (b == 0 || n == 0) return 0;
+    PDM_REQUIRE(known_pm && idx && weight && wpack && bias && out_pm && (c_skip == 0 || skip_pm), PDM_E_BADARG,
+                "fp_mlp_fused: null pointer");
+    MlpDesc d;
+    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip);
+    if (rc) return rc;
+    PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && cout <= out_stride, PDM_E_BADARG, "fp_mlp_fused: cout=%d stride=%d", cout, out_stride);
+    PDM_REQUIRE(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
+                    (c_known % 4 != 0 || (reinterpret_cast<uintptr_t>(known_pm) & 15) == 0) &&
+                    (c_skip % 4 != 0 || c_skip == 0 || (reinterpret_cast<uintptr_t>(skip_pm) & 15) == 0),
+                PDM_E_BADARG, "fp_mlp_fused: buffers must be 16-byte aligned and out_stride a multiple of 4");
+    FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout};
+    const size_t lds_bytes = (size_t)(16 * (d.lds_p + d.lds_q)) * sizeof(float);
+    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    const long long ntiles = (long long)b * ((n + 15) / 16);
+    const int blocks = (int)(ntiles < 256 * 64 ? ntiles : 256 * 64);
+    hipLaunchKernelGGL(fp_mlp_fused_kernel, dim3(blocks), dim3(64), lds_bytes, as_stream(stream), d, a, wpack, bias);
+    return check_launch("fp_mlp_fused");
+}

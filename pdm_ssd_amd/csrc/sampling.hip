@@ -19,98 +19,200 @@
 
 namespace pdm {
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---- wave64 cross-lane helpers (DPP: VALU-speed, no LDS crossbar round trips) -----------------
+// Reductions run on the INTEGER image of the floats: every candidate maximum here is either a
+// non-negative float (bit pattern order == value order) or a negative sentinel (-1/-2/-3: inactive
+// lanes, which as signed integers sort below every non-negative float and never need ordering among
+// themselves because at least one active lane always holds a value >= 0).  Integer max needs no NaN
+// canonicalisation and folds into v_max_i32_dpp.
+// Written as one asm block because hipcc neither folds update_dpp into v_max_i32_dpp here nor drops
+// its moves; the s_nop 1 in front of each step is the 2-wait-state VALU-write -> DPP-read hazard,
+// which the compiler does not pad inside an asm statement.
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// max over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ int row_max16(int v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
-
-// Block-wide arg-max with "lowest physical thread wins ties".  Returns the winning point index,
-// uniform across the block.  rec_* are [2][16] LDS arrays, buf alternates per iteration.
-template <int BLOCK>
-__device__ __forceinline__ int block_argmax(float best, int besti, float (*rec_v)[16],
-                                            int (*rec_i)[16], int buf) {
-    constexpr int NW = BLOCK / 64;
-    const int lane = threadIdx.x & 63;
-    const float wmax = wave_max(best);
-    const unsigned long long mask = __ballot(best == wmax);
-    const int wl = __ffsll((long long)mask) - 1;
-    int wbesti = __shfl(besti, wl, 64);
-    if (NW == 1) return __builtin_amdgcn_readfirstlane(wbesti);
-    const int wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        rec_v[buf][wave] = wmax;
-        rec_i[buf][wave] = wbesti;
-    }
-    __syncthreads();
-    float v = lane < NW ? rec_v[buf][lane] : -3.0f;
-    int bi = lane < NW ? rec_i[buf][lane] : 0;
-    float gmax = v;
-#pragma unroll
-    for (int off = NW / 2; off >= 1; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
-    gmax = __shfl(gmax, 0, 64);
-    const unsigned long long mask2 = __ballot(lane < NW && v == gmax);
-    const int wl2 = __ffsll((long long)mask2) - 1;
-    return __builtin_amdgcn_readfirstlane(__shfl(bi, wl2, 64));
+// max over the wave, returned wave-uniform
+__device__ __forceinline__ float wave_max(float f) {
+    int v = row_max16(__builtin_bit_cast(int, f));
+    asm volatile(
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
 }
 
-// S = logical thread count of the reference (power of two, <= BLOCK); threads p >= S idle.
+// v_min_f32 without the canonicalising v_max hipcc puts in front of fminf for an operand it cannot prove
+// quiet: the operands here are a fresh fma result and an earlier v_min result (or the caller's temp),
+// and in the kernel's IEEE mode v_min_f32 returns the non-NaN operand exactly as fminf does.
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct FpsPick {
+    int k;          // winning point index
+    float x, y, z;  // its coordinates
+};
+
+// One per-wave record per iteration: {max value, point index, x, y, z}; double-buffered so a single
+// barrier per iteration is enough (a wave can be at most one iteration ahead of the slowest).
+struct __attribute__((aligned(16))) FpsRec {
+    float v;
+    int k;
+    float x, y, z;
+    float pad[3];
+};
+
+// Block-wide arg-max with "lowest physical thread wins ties"; every argument is wave-uniform.
+template <int BLOCK>
+__device__ __forceinline__ FpsPick block_pick(float wmax, FpsPick mine, FpsRec (*rec)[16], int buf) {
+    constexpr int NW = BLOCK / 64;
+    if (NW == 1) return mine;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        FpsRec r;
+        r.v = wmax; r.k = mine.k; r.x = mine.x; r.y = mine.y; r.z = mine.z;
+        rec[buf][wave] = r;
+    }
+    __syncthreads();
+    const FpsRec r = rec[buf][lane & 15];  // NW <= 16: lanes 0..NW-1 hold the wave records
+    const float v = (lane & 15) < NW ? r.v : -3.0f;
+    const float gmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(row_max16(__builtin_bit_cast(int, v)), 0));
+    const unsigned long long cand = __ballot(v == gmax) & 0xFFFFull;
+    const int w = __ffsll((long long)cand) - 1;  // lowest wave id among equal maxima
+    FpsPick out;
+    out.k = __builtin_amdgcn_readlane(r.k, w);
+    out.x = readlane_f(r.x, w);
+    out.y = readlane_f(r.y, w);
+    out.z = readlane_f(r.z, w);
+    return out;
+}
+
+// Register-resident FPS.  S = the reference's logical thread count (power of two <= 1024).
+// T = min(S, BLOCK) physical threads are active; each plays R = S/T reference threads (the ones the
+// tree's first log2(R) levels merge into one slot, visited in the order those levels prefer) and
+// holds I = PPT/R points of each in registers: visiting index v -> residue bitrev(v / I), step v % I.
 template <int BLOCK, int PPT>
 __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int logS,
                                                         const float *__restrict__ xyz_all,
                                                         float *__restrict__ temp_all,
                                                         int *__restrict__ idx_all) {
-    __shared__ float rec_v[2][16];
-    __shared__ int rec_i[2][16];
+    using vec = float __attribute__((ext_vector_type(PPT)));
+    __shared__ FpsRec rec[2][16];
     const int b = blockIdx.x;
     const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
     float *__restrict__ temp = temp_all + (size_t)b * n;
     int *__restrict__ idxs = idx_all + (size_t)b * m;
 
+    const int T = S < BLOCK ? S : BLOCK;
+    const int logT = S < BLOCK ? logS : __builtin_ctz(BLOCK);
+    const int logR = logS - logT;             // residues per physical thread = 1 << logR
+    const int logI = __builtin_ctz(PPT) - logR;  // points per residue = 1 << logI
     const int p = threadIdx.x;
-    const bool active = p < S;
-    const int t = logS > 0 ? (int)(__brev((unsigned)p) >> (32 - logS)) : 0;
+    const bool active = p < T;
+    const int t = logT > 0 ? (int)(__brev((unsigned)p) >> (32 - logT)) : 0;
 
-    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    auto point_of = [&](int tt, int v) -> int {
+        const int ridx = v >> logI;
+        const int r = logR > 0 ? (int)(__brev((unsigned)ridx) >> (32 - logR)) : 0;
+        return tt + r * T + (v & ((1 << logI) - 1)) * S;
+    };
+
+    vec px, py, pz, tmp;
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int k = t + i * S;
+    for (int v = 0; v < PPT; ++v) {
+        const int k = point_of(t, v);
         if (active && k < n) {
-            px[i] = xyz[(size_t)k * 3 + 0];
-            py[i] = xyz[(size_t)k * 3 + 1];
-            pz[i] = xyz[(size_t)k * 3 + 2];
-            tmp[i] = temp[k];
+            px[v] = xyz[(size_t)k * 3 + 0];
+            py[v] = xyz[(size_t)k * 3 + 1];
+            pz[v] = xyz[(size_t)k * 3 + 2];
+            tmp[v] = temp[k];
         } else {
-            px[i] = py[i] = pz[i] = 0.0f;
-            tmp[i] = -1.0f;  // fminf(d, -1) = -1 never beats best = -1 under strict '>'
+            px[v] = py[v] = pz[v] = 0.0f;
+            tmp[v] = -1.0f;  // fminf(d, -1) = -1 never beats best = -1 under strict '>'
         }
     }
 
-    int old = 0;
+    FpsPick cur;
+    cur.k = 0;
+    cur.x = xyz[0]; cur.y = xyz[1]; cur.z = xyz[2];
     if (p == 0) idxs[0] = 0;
+    const int wave_base = (threadIdx.x >> 6) * 64;
     for (int j = 1; j < m; ++j) {
-        const float x1 = xyz[(size_t)old * 3 + 0];
-        const float y1 = xyz[(size_t)old * 3 + 1];
-        const float z1 = xyz[(size_t)old * 3 + 2];
         float best = active ? -1.0f : -2.0f;
-        int besti = 0;
+        int bestv = 0;
+        if constexpr (PPT >= 2) {
+            const v2f x1 = {cur.x, cur.x}, y1 = {cur.y, cur.y}, z1 = {cur.z, cur.z};
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float d = sqdist(px[i] - x1, py[i] - y1, pz[i] - z1);
-            const float d2 = fminf(d, tmp[i]);
-            tmp[i] = d2;
-            const bool gt = d2 > best;
-            besti = gt ? t + i * S : besti;
-            best = gt ? d2 : best;
+            for (int v = 0; v < PPT; v += 2) {
+                const v2f dx = v2f{px[v], px[v + 1]} - x1;
+                const v2f dy = v2f{py[v], py[v + 1]} - y1;
+                const v2f dz = v2f{pz[v], pz[v + 1]} - z1;
+                v2f d = dx * dx;                              // rn(dx*dx)
+                d = __builtin_elementwise_fma(dy, dy, d);    // fma(dy,dy,.)
+                d = __builtin_elementwise_fma(dz, dz, d);    // fma(dz,dz,.)
+                const float d0 = vmin(d.x, tmp[v]);
+                const float d1 = vmin(d.y, tmp[v + 1]);
+                tmp[v] = d0;
+                tmp[v + 1] = d1;
+                bestv = d0 > best ? v : bestv;
+                best = vmax(best, d0);
+                bestv = d1 > best ? v + 1 : bestv;
+                best = vmax(best, d1);
+            }
+        } else {
+            const float d = sqdist(px[0] - cur.x, py[0] - cur.y, pz[0] - cur.z);
+            const float d0 = vmin(d, tmp[0]);
+            tmp[0] = d0;
+            bestv = 0;
+            best = vmax(best, d0);
         }
-        old = block_argmax<BLOCK>(best, besti, rec_v, rec_i, j & 1);
-        if (p == 0) idxs[j] = old;
+        // wave level: max, lowest lane among equals, that lane's point out of its registers
+        const float wmax = wave_max(best);
+        const unsigned long long mask = __ballot(best == wmax);
+        const int wl = __ffsll((long long)mask) - 1;
+        const int slot = __builtin_amdgcn_readlane(bestv, wl);
+        FpsPick mine;
+        const int tw = logT > 0 ? (int)(__brev((unsigned)(wave_base + wl)) >> (32 - logT)) : 0;
+        mine.k = point_of(tw, slot);
+        mine.x = readlane_f(px[slot], wl);
+        mine.y = readlane_f(py[slot], wl);
+        mine.z = readlane_f(pz[slot], wl);
+        cur = block_pick<BLOCK>(wmax, mine, rec, j & 1);
+        if (p == 0) idxs[j] = cur.k;
     }
 
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int k = t + i * S;
-        if (active && k < n) temp[k] = tmp[i];
+    for (int v = 0; v < PPT; ++v) {
+        const int k = point_of(t, v);
+        if (active && k < n) temp[k] = tmp[v];
     }
 }
 
@@ -121,8 +223,7 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(int n, int m, int S, 
                                                            const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all,
                                                            int *__restrict__ idx_all) {
-    __shared__ float rec_v[2][16];
-    __shared__ int rec_i[2][16];
+    __shared__ FpsRec rec[2][16];
     const int b = blockIdx.x;
     const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
     float *__restrict__ temp = temp_all + (size_t)b * n;
@@ -150,7 +251,13 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(int n, int m, int S, 
                 best = gt ? d2 : best;
             }
         }
-        old = block_argmax<BLOCK>(best, besti, rec_v, rec_i, j & 1);
+        const float wmax = wave_max(best);
+        const unsigned long long mask = __ballot(best == wmax);
+        const int wl = __ffsll((long long)mask) - 1;
+        FpsPick mine;
+        mine.k = __builtin_amdgcn_readlane(besti, wl);
+        mine.x = mine.y = mine.z = 0.0f;
+        old = block_pick<BLOCK>(wmax, mine, rec, j & 1).k;
         if (p == 0) idxs[j] = old;
     }
 }
@@ -189,6 +296,11 @@ static int ref_block_threads(int n, int *logS) {
 
 using namespace pdm;
 
+// Tuning knob (not part of the reference-facing ABI): 0 = 1024 threads x 16 points, 1 = 512 x 32 for
+// 8192 < n <= 16384.  Both give identical indices.
+static int g_fps_variant = 0;
+extern "C" int pdm_tune_fps_variant(int v) { const int old = g_fps_variant; g_fps_variant = v; return old; }
+
 #define FPS_LAUNCH(BLOCK, PPT)                                                                  \
     hipLaunchKernelGGL((fps_reg_kernel<BLOCK, PPT>), dim3(b), dim3(BLOCK), 0, as_stream(stream), \
                        n, m, S, logS, points, temp, idx)
@@ -201,21 +313,23 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     PDM_REQUIRE(points && temp && idx, PDM_E_BADARG, "fps: null pointer");
     int logS = 0;
     const int S = ref_block_threads(n, &logS);
-    const int ppt = (n + S - 1) / S;
+    const int per = (n + S - 1) / S;  // points per reference thread
     if (S <= 64) {
-        if (ppt <= 1) FPS_LAUNCH(64, 1); else FPS_LAUNCH(64, 2);
+        FPS_LAUNCH(64, 2);
     } else if (S <= 256) {
-        if (ppt <= 1) FPS_LAUNCH(256, 1); else FPS_LAUNCH(256, 2);
-    } else if (ppt <= 1) {
+        FPS_LAUNCH(256, 2);
+    } else if (S == 512) {
+        FPS_LAUNCH(512, 2);
+    } else if (per <= 1) {
         FPS_LAUNCH(1024, 1);
-    } else if (ppt <= 2) {
+    } else if (per <= 2) {
         FPS_LAUNCH(1024, 2);
-    } else if (ppt <= 4) {
+    } else if (per <= 4) {
         FPS_LAUNCH(1024, 4);
-    } else if (ppt <= 8) {
+    } else if (per <= 8) {
         FPS_LAUNCH(1024, 8);
-    } else if (ppt <= 16) {
-        FPS_LAUNCH(1024, 16);
+    } else if (per <= 16) {
+        if (g_fps_variant == 1) FPS_LAUNCH(512, 32); else FPS_LAUNCH(1024, 16);
     } else {
         hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n,
                            m, S, logS, points, temp, idx);

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import pointnet2_utils
+from .. import fused
 
 
 def _shared_mlp(spec: List[int]) -> nn.Sequential:
@@ -40,10 +41,55 @@ class _PointnetSAModuleBase(nn.Module):
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         return pointnet2_utils.gather_operation(xyz_flipped, idx).transpose(1, 2).contiguous()
 
+    def _fused_packs(self, xyz, features):
+        """Packed weights per scale when the fused fp32-MFMA inference path applies, else None:
+        eval mode, no autograd, max-pool, QueryAndGroup(use_xyz) groupers, nsample % 16 == 0."""
+        if self.training or torch.is_grad_enabled() or not getattr(self, 'use_fused', True):
+            return None
+        if self.pool_method != 'max_pool' or self.npoint is None or not xyz.is_cuda or xyz.dtype != torch.float32:
+            return None
+        if features is not None and features.dtype != torch.float32:
+            return None
+        cin = 0 if features is None else features.shape[1]
+        packs = []
+        for i, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if not isinstance(grouper, pointnet2_utils.QueryAndGroup) or not grouper.use_xyz or grouper.nsample % 16:
+                return None
+            # reference channel order [xyz(3), features(cin)] -> kernel order [features, xyz]
+            perm = list(range(3, 3 + cin)) + [0, 1, 2]
+            pk = fused.cached_pack(self, i, mlp, xyz.device, perm)
+            if pk is None or pk.cin != cin + 3:
+                return None
+            packs.append(pk)
+        return packs
+
+    def _forward_fused(self, packs, xyz, features, new_xyz):
+        B, M = new_xyz.shape[0], new_xyz.shape[1]
+        feat_pm = None if features is None else features.transpose(1, 2).contiguous()  # (B,N,C) point-major
+        xyz = xyz.contiguous()
+        new_xyz = new_xyz.contiguous()
+        ctot = sum(pk.cout for pk in packs)
+        out_pm = torch.empty((B, M, ctot), dtype=torch.float32, device=xyz.device)
+        coff = 0
+        for grouper, pk in zip(self.groupers, packs):
+            idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            fused.sa_scale_forward(pk, xyz, new_xyz, feat_pm, idx, out_pm, coff)
+            coff += pk.cout
+        return new_xyz, out_pm.transpose(1, 2)  # logical (B, C, M) over point-major storage
+
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B, sum_k mlps[k][-1], npoint)."""
+        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B, sum_k mlps[k][-1], npoint).
+
+        In eval mode without autograd each scale runs as one fused HIP kernel (gather + MLP on fp32 MFMA
+        + max-pool); the returned features are then a (B,C,M) VIEW of point-major (B,M,C) storage.
+        """
         if new_xyz is None:
             new_xyz = self.sample(xyz)
+        packs = self._fused_packs(xyz, features)
+        if packs is not None and all(pk.cout % 4 == 0 for pk in packs):
+            return self._forward_fused(packs, xyz, features, new_xyz)
+        if features is not None:
+            features = features.contiguous()
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             x = mlp(grouper(xyz, new_xyz, features))  # (B, mlp[-1], npoint, nsample)
@@ -99,12 +145,27 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
-        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B, mlp[-1], n)."""
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B, mlp[-1], n).
+
+        In eval mode without autograd, interpolation + concat + MLP run as one fused HIP kernel and the
+        result is a (B,C,n) VIEW of point-major (B,n,C) storage.
+        """
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist, idx = pointnet2_utils.three_nn(unknown.contiguous(), known.contiguous())
             dist_recip = 1.0 / (dist + 1e-8)  # ref :154
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            if not (self.training or torch.is_grad_enabled()) and getattr(self, 'use_fused', True) \
+                    and known_feats.is_cuda and known_feats.dtype == torch.float32:
+                pk = fused.cached_pack(self, 0, self.mlp, known_feats.device)
+                cs = 0 if unknow_feats is None else unknow_feats.shape[1]
+                if pk is not None and pk.cin == known_feats.shape[1] + cs and pk.cout % 4 == 0:
+                    known_pm = known_feats.transpose(1, 2).contiguous()
+                    skip_pm = None if unknow_feats is None else unknow_feats.float().transpose(1, 2).contiguous()
+                    out_pm = torch.empty((unknown.shape[0], unknown.shape[1], pk.cout), dtype=torch.float32,
+                                         device=known_feats.device)
+                    fused.fp_forward(pk, known_pm, skip_pm, idx, weight.contiguous(), out_pm)
+                    return out_pm.transpose(1, 2)
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         x = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
