@@ -203,44 +203,71 @@ struct RowOut {
     }
 };
 
-// One layer: for every pair of 16-channel output blocks, a K loop of {1 B fragment, 2 A fragments,
-// 8 MFMAs}; the next iteration's fragments are requested before this iteration's MFMAs issue.
-template <class In, class Out>
+// One layer for the W waves of a workgroup.  The layer's nmb 16-channel output blocks are dealt to the
+// waves in contiguous shares; a wave walks its share in passes of up to 4 blocks.  Per 16-deep K block
+// a pass issues {1 B fragment, <=4 A fragments, <=16 MFMAs}; the next K block's fragments are requested
+// before the current block's MFMAs issue (>= 512 cycles of matrix work in flight per request at 4 blocks).
+template <int W, class In, class Out>
 __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restrict__ wp,
-                                          const float *__restrict__ bias, int lane, const In &in,
-                                          const Out &out) {
+                                          const float *__restrict__ bias, int lane, int wave,
+                                          const In &in, const Out &out) {
     const int g = lane >> 4;
+    const int share = (nmb + W - 1) / W;                  // blocks per wave
+    const int mb_begin = wave * share;
+    const int mb_end = min(mb_begin + share, nmb);
+    if (mb_begin >= mb_end) return;
+    const int passes = (share + 3) >> 2;
+    const int bpp = (share + passes - 1) / passes;        // blocks per pass, 1..4
     const f4 *__restrict__ w = reinterpret_cast<const f4 *>(wp) + lane;
-    for (int mb = 0; mb < nmb; mb += 2) {
-        const bool two = mb + 1 < nmb;
-        const f4 *__restrict__ w0 = w + (size_t)mb * nkb * 64;
-        const f4 *__restrict__ w1 = two ? w0 + (size_t)nkb * 64 : w0;
-        f4 acc0 = *reinterpret_cast<const f4 *>(bias + 16 * mb + 4 * g);
-        f4 acc1 = two ? *reinterpret_cast<const f4 *>(bias + 16 * (mb + 1) + 4 * g) : acc0;
-        f4 bn = in(0), a0n = w0[0], a1n = w1[0];
+    const size_t bstride = (size_t)nkb * 64;              // f4 elements between consecutive blocks
+    for (int mb = mb_begin; mb < mb_end; mb += bpp) {
+        const int nb = min(bpp, mb_end - mb);             // wave-uniform
+        const f4 *__restrict__ w0 = w + (size_t)mb * bstride;
+        const f4 *__restrict__ w1 = nb > 1 ? w0 + bstride : w0;
+        const f4 *__restrict__ w2 = nb > 2 ? w1 + bstride : w0;
+        const f4 *__restrict__ w3 = nb > 3 ? w2 + bstride : w0;
+        const float *bb = bias + 16 * mb + 4 * g;
+        f4 acc0 = *reinterpret_cast<const f4 *>(bb);
+        f4 acc1 = *reinterpret_cast<const f4 *>(bb + (nb > 1 ? 16 : 0));
+        f4 acc2 = *reinterpret_cast<const f4 *>(bb + (nb > 2 ? 32 : 0));
+        f4 acc3 = *reinterpret_cast<const f4 *>(bb + (nb > 3 ? 48 : 0));
+        f4 bn = in(0), a0n = w0[0], a1n = w1[0], a2n = w2[0], a3n = w3[0];
         for (int kb = 0; kb < nkb; ++kb) {
-            const f4 b = bn, a0 = a0n, a1 = a1n;
+            const f4 b = bn, a0 = a0n, a1 = a1n, a2 = a2n, a3 = a3n;
             if (kb + 1 < nkb) {
+                const size_t o = (size_t)(kb + 1) * 64;
                 bn = in(kb + 1);
-                a0n = w0[(size_t)(kb + 1) * 64];
-                a1n = w1[(size_t)(kb + 1) * 64];
+                a0n = w0[o];
+                if (nb > 1) a1n = w1[o];
+                if (nb > 2) a2n = w2[o];
+                if (nb > 3) a3n = w3[o];
             }
             acc0 = mfma4(acc0, a0, b);
-            if (two) acc1 = mfma4(acc1, a1, b);  // wave-uniform
+            if (nb > 1) acc1 = mfma4(acc1, a1, b);
+            if (nb > 2) acc2 = mfma4(acc2, a2, b);
+            if (nb > 3) acc3 = mfma4(acc3, a3, b);
         }
         out(mb, relu4(acc0));
-        if (two) out(mb + 1, relu4(acc1));
+        if (nb > 1) out(mb + 1, relu4(acc1));
+        if (nb > 2) out(mb + 2, relu4(acc2));
+        if (nb > 3) out(mb + 3, relu4(acc3));
     }
 }
 
-// Runs layers 1..nlayers for one tile.  P/Q = the wave's two LDS buffers (widths lds_p / lds_q):
+template <int W>
+__device__ __forceinline__ void wg_sync() {
+    if (W > 1) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();  // one wave: LDS ops execute in order, only pin the compiler
+}
+
+// Runs layer L for one tile.  P/Q = the workgroup's two LDS buffers (widths lds_p / lds_q):
 // layer 1 writes Q, layer 2 writes P, layer 3 writes Q ...; a staged input tile lives in P.
-// The layer loop is unrolled so every descriptor field is read with a constant index (a runtime
+// The layer sequence is unrolled so every descriptor field is read with a constant index (a runtime
 // index into the by-value descriptor would push it to scratch).
-template <int L, class In, class Out>
+template <int W, int L, class In, class Out>
 __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restrict__ wpack,
                                           const float *__restrict__ bias, float *P, float *Q, int lane,
-                                          const In &in, const Out &out) {
+                                          int wave, const In &in, const Out &out) {
     const int pos = lane & 15, g = lane >> 4;
     const int nkb = d.K[L - 1] >> 4, nmb = d.K[L] >> 4;
     const float *wl = wpack + d.woff[L - 1];
@@ -250,41 +277,41 @@ __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restr
     const int ow = (L & 1) ? d.lds_q : d.lds_p;
     const LdsOut lo{ob + pos * ow + 4 * g};
     if (L == 1 && !d.stage_in) {
-        if (last) mlp_layer(nkb, nmb, wl, bl, lane, in, out);
-        else mlp_layer(nkb, nmb, wl, bl, lane, in, lo);
+        if (last) mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, in, out);
+        else mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, in, lo);
     } else {
         float *ib = (L & 1) ? P : Q;  // layer 1 (staged) and layer 3 read P, layer 2 reads Q
         const int iw = (L & 1) ? d.lds_p : d.lds_q;
         const LdsIn li{ib + pos * iw + 4 * g};
-        if (last) mlp_layer(nkb, nmb, wl, bl, lane, li, out);
-        else mlp_layer(nkb, nmb, wl, bl, lane, li, lo);
+        if (last) mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, li, out);
+        else mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, li, lo);
     }
-    // LDS ops of one wave execute in order; keep the compiler from moving reads above the writes
-    __builtin_amdgcn_wave_barrier();
+    wg_sync<W>();
 }
 
-template <class In, class Out>
+template <int W, class In, class Out>
 __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restrict__ wpack,
                                         const float *__restrict__ bias, float *P, float *Q, int lane,
-                                        const In &in, const Out &out) {
+                                        int wave, const In &in, const Out &out) {
     if (d.stage_in) {
-        // gather the input tile once: P[pos][K0]
+        // gather the input tile once, K blocks dealt round-robin to the waves: P[pos][K0]
         float *row = P + (lane & 15) * d.lds_p + 4 * (lane >> 4);
         const int nkb0 = d.K[0] >> 4;
-        for (int kb = 0; kb < nkb0; ++kb) *reinterpret_cast<f4 *>(row + 16 * kb) = in(kb);
-        __builtin_amdgcn_wave_barrier();
+        for (int kb = wave; kb < nkb0; kb += W) *reinterpret_cast<f4 *>(row + 16 * kb) = in(kb);
+        wg_sync<W>();
     }
-    run_layer<1>(d, wpack, bias, P, Q, lane, in, out);
-    if (d.nlayers >= 2) run_layer<2>(d, wpack, bias, P, Q, lane, in, out);
-    if (d.nlayers >= 3) run_layer<3>(d, wpack, bias, P, Q, lane, in, out);
-    if (d.nlayers >= 4) run_layer<4>(d, wpack, bias, P, Q, lane, in, out);
+    run_layer<W, 1>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 2) run_layer<W, 2>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 3) run_layer<W, 3>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 4) run_layer<W, 4>(d, wpack, bias, P, Q, lane, wave, in, out);
 }
 
-__global__ __launch_bounds__(64) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
-                                                          const float *__restrict__ wpack,
-                                                          const float *__restrict__ bias) {
+template <int W>
+__global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
+                                                              const float *__restrict__ wpack,
+                                                              const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = lane & 15, g = lane >> 4;
     float *P = lds;
     float *Q = P + 16 * d.lds_p;
@@ -308,16 +335,17 @@ __global__ __launch_bounds__(64) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
             out.orow = a.out + ctr * a.out_stride + a.out_coff;
             out.cout = a.cout; out.lane = lane; out.g = g;
             out.first_tile = t == 0; out.last_tile = t == tiles_per_centre - 1;
-            run_mlp(d, wpack, bias, P, Q, lane, in, out);
+            run_mlp<W>(d, wpack, bias, P, Q, lane, wave, in, out);
         }
     }
 }
 
-__global__ __launch_bounds__(64) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
-                                                          const float *__restrict__ wpack,
-                                                          const float *__restrict__ bias) {
+template <int W>
+__global__ __launch_bounds__(64 * W) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
+                                                              const float *__restrict__ wpack,
+                                                              const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = lane & 15, g = lane >> 4;
     float *P = lds;
     float *Q = P + 16 * d.lds_p;
@@ -342,11 +370,14 @@ __global__ __launch_bounds__(64) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
         RowOut out;
         out.orow = in.live ? a.out + q * a.out_stride : nullptr;
         out.cout = a.cout; out.g = g;
-        run_mlp(d, wpack, bias, P, Q, lane, in, out);
+        run_mlp<W>(d, wpack, bias, P, Q, lane, wave, in, out);
     }
 }
 
-static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max) {
+static int g_fused_waves = 0;
+
+static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max, int pool_floats,
+                     int *waves) {
     PDM_REQUIRE(nlayers >= 1 && nlayers <= FM_MAXL, PDM_E_BADARG, "%s: nlayers=%d not in [1,%d]", who, nlayers, FM_MAXL);
     PDM_REQUIRE(dims, PDM_E_BADARG, "%s: null dims", who);
     d.nlayers = nlayers;
@@ -366,9 +397,16 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     for (int l = 1; l < nlayers; ++l) {
         if (l & 1) q = q > d.K[l] ? q : d.K[l]; else p = p > d.K[l] ? p : d.K[l];
     }
+    // waves per workgroup: wide layers split their output blocks over more waves (more parallelism per
+    // tile, LDS tile shared); narrow layers keep waves independent.
+    int maxmb = 0;
+    for (int l = 1; l <= nlayers; ++l) maxmb = maxmb > (d.K[l] >> 4) ? maxmb : (d.K[l] >> 4);
+    const int W = g_fused_waves > 0 ? g_fused_waves : maxmb >= 24 ? 8 : maxmb >= 12 ? 4 : maxmb >= 6 ? 2 : 1;
+    *waves = W;
+    // stage the gathered input tile in LDS when the workgroup still fits >= 8 waves per CU (160 KB LDS)
     const int p_staged = p > d.K[0] ? p : d.K[0];
-    // stage the input tile in LDS when that keeps >= 4 waves per CU (<= 40 KB per wave)
-    d.stage_in = (16 * (p_staged + 4 + q + 4) + d.K[nlayers]) * 4 <= 40 * 1024 ? 1 : 0;
+    const int budget = (W == 1 ? 20 : W == 2 ? 40 : W == 4 ? 52 : 80) * 1024;
+    d.stage_in = (16 * (p_staged + 4 + q + 4) + pool_floats) * 4 <= budget ? 1 : 0;
     if (d.stage_in) p = p_staged;
     d.lds_p = p + 4;  // +4 floats: consecutive positions start 4 banks apart (conflict-free b128 rows)
     d.lds_q = q + 4;
@@ -378,6 +416,12 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
 }  // namespace pdm
 
 using namespace pdm;
+
+// Tuning knob (not part of the reference-facing ABI): force the waves-per-workgroup choice (0 = auto).
+extern "C" int pdm_tune_fused_waves(int w) { const int old = g_fused_waves; g_fused_waves = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; return old; }
+
+#define FUSED_LAUNCH(KERNEL, W, blocks, lds_bytes, ...)                                                        \
+    hipLaunchKernelGGL((KERNEL<W>), dim3(blocks), dim3(64 * W), lds_bytes, as_stream(stream), __VA_ARGS__)
 
 extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample,
                                 const float *xyz, const float *new_xyz, const float *feat_pm,
@@ -390,7 +434,8 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     PDM_REQUIRE(xyz && new_xyz && idx && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
                 "sa_mlp_fused: null pointer");
     MlpDesc d;
-    int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3);
+    int W = 1;
+    int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3, dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, &W);
     if (rc) return rc;
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && out_coff >= 0 && out_coff + cout <= out_stride, PDM_E_BADARG,
                 "sa_mlp_fused: cout=%d coff=%d stride=%d", cout, out_coff, out_stride);
@@ -402,8 +447,11 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     const size_t lds_bytes = (size_t)(16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const long long ncentres = (long long)b * m;
-    const int blocks = (int)(ncentres < 256 * 64 ? ncentres : 256 * 64);
-    hipLaunchKernelGGL(sa_mlp_fused_kernel, dim3(blocks), dim3(64), lds_bytes, as_stream(stream), d, a, wpack, bias);
+    const int blocks = (int)(ncentres < 256 * 32 ? ncentres : 256 * 32);
+    if (W == 1) FUSED_LAUNCH(sa_mlp_fused_kernel, 1, blocks, lds_bytes, d, a, wpack, bias);
+    else if (W == 2) FUSED_LAUNCH(sa_mlp_fused_kernel, 2, blocks, lds_bytes, d, a, wpack, bias);
+    else if (W == 4) FUSED_LAUNCH(sa_mlp_fused_kernel, 4, blocks, lds_bytes, d, a, wpack, bias);
+    else FUSED_LAUNCH(sa_mlp_fused_kernel, 8, blocks, lds_bytes, d, a, wpack, bias);
     return check_launch("sa_mlp_fused");
 }
 
@@ -416,7 +464,8 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
     PDM_REQUIRE(known_pm && idx && weight && wpack && bias && out_pm && (c_skip == 0 || skip_pm), PDM_E_BADARG,
                 "fp_mlp_fused: null pointer");
     MlpDesc d;
-    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip);
+    int W = 1;
+    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, &W);
     if (rc) return rc;
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && cout <= out_stride, PDM_E_BADARG, "fp_mlp_fused: cout=%d stride=%d", cout, out_stride);
     PDM_REQUIRE(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
@@ -428,7 +477,10 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
     const size_t lds_bytes = (size_t)(16 * (d.lds_p + d.lds_q)) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const long long ntiles = (long long)b * ((n + 15) / 16);
-    const int blocks = (int)(ntiles < 256 * 64 ? ntiles : 256 * 64);
-    hipLaunchKernelGGL(fp_mlp_fused_kernel, dim3(blocks), dim3(64), lds_bytes, as_stream(stream), d, a, wpack, bias);
+    const int blocks = (int)(ntiles < 256 * 32 ? ntiles : 256 * 32);
+    if (W == 1) FUSED_LAUNCH(fp_mlp_fused_kernel, 1, blocks, lds_bytes, d, a, wpack, bias);
+    else if (W == 2) FUSED_LAUNCH(fp_mlp_fused_kernel, 2, blocks, lds_bytes, d, a, wpack, bias);
+    else if (W == 4) FUSED_LAUNCH(fp_mlp_fused_kernel, 4, blocks, lds_bytes, d, a, wpack, bias);
+    else FUSED_LAUNCH(fp_mlp_fused_kernel, 8, blocks, lds_bytes, d, a, wpack, bias);
     return check_launch("fp_mlp_fused");
 }

@@ -32,7 +32,11 @@ def main():
     ap.add_argument("--ops", default="fps,bq,group,nn,interp")
     ap.add_argument("--clouds", default="uniform")
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--model", action="store_true", help="per-call breakdown of one bench step")
     args = ap.parse_args()
+    if args.model:
+        model_breakdown(args.clouds, args.batch)
+        return
     ops = args.ops.split(",")
     dev = torch.device("cuda:0")
     B = args.batch
@@ -87,6 +91,48 @@ def main():
                 ms = timeit(lambda: pu.three_interpolate(f, i, w))
                 by = B * (24 * n + 4 * C * m + 4 * C * n)
                 print(f"three_interpolate C={C:5d} n={n:6d}: {ms:8.3f} ms  {by / 1e9 / (ms / 1e3):8.1f} GB/s")
+
+
+
+
+def model_breakdown(clouds="uniform", B=32, iters=5):
+    """Per-call timing of one bench step (eager), every native call bracketed by HIP events."""
+    import bench
+    dev = torch.device("cuda:0")
+    backbone, neck = bench.build_models(dev)
+    _, points = bench.make_batch(B, 16384, clouds, 1234, dev)
+
+    def step():
+        bd = {'batch_size': B, 'points': points, 'points_per_sample_checked': True}
+        return neck(backbone(bd))
+
+    with torch.no_grad():
+        step(); step()
+        torch.cuda.synchronize()
+        orig = _native.call
+        recs = []
+
+        def timed(name, stream, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, stream, *args)
+            e1.record()
+            recs.append((name, [a for a in args[:6] if isinstance(a, (int, float))], e0, e1))
+
+        _native.call = timed
+        try:
+            for _ in range(iters):
+                step()
+        finally:
+            _native.call = orig
+        torch.cuda.synchronize()
+    per = len(recs) // iters
+    tot = 0.0
+    for i in range(per):
+        ms = sum(recs[i + k * per][2].elapsed_time(recs[i + k * per][3]) for k in range(iters)) / iters
+        tot += ms
+        print(f"{recs[i][0]:30s} {str(recs[i][1]):42s} {ms:8.3f} ms")
+    print(f"sum of native calls: {tot:.3f} ms")
 
 
 if __name__ == "__main__":
