@@ -25,6 +25,8 @@
 #ifndef PDMSSD_HIP_H
 #define PDMSSD_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -94,6 +96,15 @@ int pdm_three_interpolate_grad(void *stream, int b, int c, int n, int m, const f
 int pdm_query_and_group(void *stream, int b, int n, int m, int c, float radius, int nsample,
                         const float *xyz, const float *new_xyz, const float *features, int *idx,
                         float *out);
+
+/* Grid-accelerated form of pdm_ball_query: identical idx, bit for bit (same caller-zeroed contract),
+ * O(candidates near each centre) instead of O(N) per centre.  Needs scratch memory, which this stateless
+ * ABI takes from the caller: `workspace` of at least pdm_ball_query_grid_workspace_bytes(b, n) bytes,
+ * contents irrelevant before and after the call. */
+size_t pdm_ball_query_grid_workspace_bytes(int b, int n);
+int pdm_ball_query_grid(void *stream, int b, int n, int m, float radius, int nsample,
+                        const float *new_xyz, const float *xyz, int *idx, void *workspace,
+                        size_t workspace_bytes);
 
 /* The gather half of the above for a given idx (B,M,nsample): grouped xyz minus centre, grouped
  * features, concatenated on the channel axis -> out (B, 3+C, M, nsample)

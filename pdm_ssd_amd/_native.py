@@ -21,6 +21,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # name -> argtypes (after the leading `void *stream`); mirrors include/pdmssd_hip.h
 _SIGNATURES = {
     "pdm_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp],
+    "pdm_ball_query_grid": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp],
@@ -39,7 +40,7 @@ _SIGNATURES = {
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,
 }
-EXPORTS = ["pdm_abi_version", "pdm_last_error"] + list(_SIGNATURES)
+EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -58,6 +59,8 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.pdm_abi_version.restype = _i
         l.pdm_last_error.restype = ctypes.c_char_p
+        l.pdm_ball_query_grid_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
         if l.pdm_abi_version() != ABI_VERSION:
             raise NativeLibraryError(
                 f"libpdmssd_hip.so ABI {l.pdm_abi_version()} != expected {ABI_VERSION}; rebuild it")

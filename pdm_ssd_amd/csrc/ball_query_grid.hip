@@ -1,0 +1,288 @@
+// Grid-accelerated ball query for gfx950 — same result, bit for bit, as the exhaustive scan of
+// ball_query.hip / the reference kernel (ball_query_gpu.cu:15-51): per centre the first `nsample`
+// indices in ASCENDING index order with d2 < r^2, padded with the first hit.
+//
+// Why: the scan is N*M distance evaluations (SA1 at bs=32: 2.1 G per radius) while the answer depends
+// on the few points near each centre.  A uniform grid over the cloud bounds the candidates; the
+// "first nsample by index" rule is then restored exactly and independently of visiting order:
+//   build  (one 1024-thread workgroup per sample): bounding box -> cell size h >= 2r (grown until the
+//          grid has <= BQG_CAP cells) -> LDS histogram -> scan -> points scattered into cell order as
+//          float4 {x, y, z, index}, so the query streams candidates with coalesced 16-byte loads;
+//   query  (one wave64 per centre): the cells overlapping [c - R, c + R] (R = r plus a rounding margin)
+//          form at most a few x-contiguous runs; lanes test one candidate each, a hit sets bit `index`
+//          in a wave-private LDS bitmap; the bitmap is then read back in index order (per-lane popcount,
+//          wave prefix sum) and the first nsample set bits are written.
+// Exactness argument (DESIGN.md "ball query"): the cell function is monotone in the coordinate, and
+// every point that passes the fp32 test lies in [fl(c - R), fl(c + R)] per axis, so it is in a visited
+// cell whatever h is; the distance arithmetic is the same pinned sequence as everywhere else.
+#include "common.h"
+
+namespace pdm {
+
+constexpr int BQG_CAP = 15360;      // max cells per sample (LDS histogram: 60 KB)
+constexpr int BQG_BUILD_T = 1024;
+constexpr int BQG_HDR = 16;         // floats per sample header
+
+struct GridHdr {                    // lives in the workspace, one per sample (BQG_HDR floats)
+    float minx, miny, minz, inv_h;
+    int gx, gy, gz, ncells;
+};
+
+__device__ __forceinline__ int cell_of(float v, float mn, float inv_h, int g) {
+    // monotone non-decreasing in v; NaN maps to cell 0
+    const float t = __fmul_rn(v - mn, inv_h);
+    return (int)fminf(fmaxf(floorf(t), 0.0f), (float)(g - 1));
+}
+
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+// workspace layout per call: [B headers][B * (CAP+1) cell starts][B * n float4 sorted points]
+__global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float radius,
+                                                                    const float *__restrict__ xyz_all,
+                                                                    float *__restrict__ hdr_all,
+                                                                    int *__restrict__ cell_start_all,
+                                                                    float4 *__restrict__ sorted_all) {
+    __shared__ int hist[BQG_CAP];
+    __shared__ float red[6][BQG_BUILD_T / 64];
+    __shared__ int wsum[BQG_BUILD_T / 64];
+    __shared__ GridHdr sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
+    int *__restrict__ cell_start = cell_start_all + (size_t)b * (BQG_CAP + 1);
+    float4 *__restrict__ sorted = sorted_all + (size_t)b * n;
+
+    // ---- bounding box
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = tid; k < n; k += BQG_BUILD_T) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[(size_t)k * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], shfl_xor_f(mn[a], off));
+            mx[a] = fmaxf(mx[a], shfl_xor_f(mx[a], off));
+        }
+        if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = red[a][0]; hi[a] = red[3 + a][0];
+            for (int w = 1; w < BQG_BUILD_T / 64; ++w) { lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]); }
+            if (!(lo[a] <= hi[a])) { lo[a] = 0.0f; hi[a] = 0.0f; }  // empty / all-NaN axis
+        }
+        float h = fmaxf(2.02f * fabsf(radius), 1e-30f);
+        if (!(h == h) || h > 3.0e38f) h = 3.0e38f;
+        int g[3];
+        for (int it = 0; it < 200; ++it) {
+            long long total = 1;
+            for (int a = 0; a < 3; ++a) {
+                const float q = (hi[a] - lo[a]) / h;
+                g[a] = q < 1023.0f ? (int)q + 1 : 1024;   // NaN/inf extents fall to 1024 then shrink
+                if (!(q == q)) g[a] = 1;
+                total *= g[a];
+            }
+            if (total <= BQG_CAP) break;
+            h *= 1.26f;
+        }
+        if ((long long)g[0] * g[1] * g[2] > BQG_CAP) { g[0] = g[1] = g[2] = 1; }
+        sh.minx = lo[0]; sh.miny = lo[1]; sh.minz = lo[2];
+        sh.inv_h = 1.0f / h;
+        sh.gx = g[0]; sh.gy = g[1]; sh.gz = g[2];
+        sh.ncells = g[0] * g[1] * g[2];
+        float *hp = hdr_all + (size_t)b * BQG_HDR;
+        hp[0] = sh.minx; hp[1] = sh.miny; hp[2] = sh.minz; hp[3] = sh.inv_h;
+        reinterpret_cast<int *>(hp)[4] = sh.gx; reinterpret_cast<int *>(hp)[5] = sh.gy;
+        reinterpret_cast<int *>(hp)[6] = sh.gz; reinterpret_cast<int *>(hp)[7] = sh.ncells;
+    }
+    __syncthreads();
+    const GridHdr H = sh;
+
+    // ---- histogram
+    for (int c = tid; c < H.ncells; c += BQG_BUILD_T) hist[c] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += BQG_BUILD_T) {
+        const int cx = cell_of(xyz[(size_t)k * 3 + 0], H.minx, H.inv_h, H.gx);
+        const int cy = cell_of(xyz[(size_t)k * 3 + 1], H.miny, H.inv_h, H.gy);
+        const int cz = cell_of(xyz[(size_t)k * 3 + 2], H.minz, H.inv_h, H.gz);
+        atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+    }
+    __syncthreads();
+
+    // ---- exclusive scan of hist[0..ncells) -> hist (running cursor) and cell_start (global)
+    const int per = (H.ncells + BQG_BUILD_T - 1) / BQG_BUILD_T;
+    const int c0 = tid * per, c1 = min(c0 + per, H.ncells);
+    int local = 0;
+    for (int c = c0; c < c1; ++c) local += hist[c];
+    int incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int v = lane < BQG_BUILD_T / 64 ? wsum[lane] : 0;
+        int inc = v;
+        for (int off = 1; off < BQG_BUILD_T / 64; off <<= 1) {
+            const int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane < BQG_BUILD_T / 64) wsum[lane] = inc - v;  // exclusive wave offsets
+    }
+    __syncthreads();
+    int run = wsum[wave] + incl - local;
+    for (int c = c0; c < c1; ++c) {
+        const int cnt = hist[c];
+        hist[c] = run;
+        cell_start[c] = run;
+        run += cnt;
+    }
+    if (tid == 0) cell_start[H.ncells] = n;
+    __syncthreads();
+
+    // ---- scatter into cell order (order inside a cell is arbitrary; the query does not depend on it)
+    for (int k = tid; k < n; k += BQG_BUILD_T) {
+        const float x = xyz[(size_t)k * 3 + 0], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
+        const int cx = cell_of(x, H.minx, H.inv_h, H.gx);
+        const int cy = cell_of(y, H.miny, H.inv_h, H.gy);
+        const int cz = cell_of(z, H.minz, H.inv_h, H.gz);
+        const int slot = atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+        sorted[slot] = make_float4(x, y, z, __int_as_float(k));
+    }
+}
+
+constexpr int BQG_QWAVES = 4;
+
+// per-axis search half-width with rounding margins: every point passing the fp32 test has
+// |c - x| < r (1 + 2^-21); R exceeds that by r 2^-10 plus 4x the rounding error of forming c +- R.
+__device__ __forceinline__ float search_halfwidth(float c, float absr) {
+    return __fmaf_rn(fabsf(c), 2.384185791015625e-07f /* 2^-22 */, absr * 1.0009765625f);
+}
+
+__global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
+    int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
+    const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+    const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
+    extern __shared__ unsigned int bitmap_all[];  // BQG_QWAVES * wpl * 64 words
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int *bm = bitmap_all + (size_t)wave * wpl * 64;
+    for (int w = lane; w < wpl * 64; w += 64) bm[w] = 0u;  // once; every centre leaves it clean
+
+    const float *hp = hdr_all + (size_t)b * BQG_HDR;
+    const float minx = hp[0], miny = hp[1], minz = hp[2], inv_h = hp[3];
+    const int gx = reinterpret_cast<const int *>(hp)[4], gy = reinterpret_cast<const int *>(hp)[5],
+              gz = reinterpret_cast<const int *>(hp)[6];
+    const int *__restrict__ cell_start = cell_start_all + (size_t)b * (BQG_CAP + 1);
+    const float4 *__restrict__ sorted = sorted_all + (size_t)b * n;
+    const float radius2 = radius * radius;  // ball_query_gpu.cu:29
+    const float absr = fabsf(radius);
+
+    const int j = blockIdx.x * BQG_QWAVES + wave;
+    if (j >= m) return;  // whole wave; no block-level barrier below
+    const float *c3 = new_xyz + ((size_t)b * m + j) * 3;
+    const float cx = c3[0], cy = c3[1], cz = c3[2];
+    const float rx = search_halfwidth(cx, absr), ry = search_halfwidth(cy, absr), rz = search_halfwidth(cz, absr);
+    const int x0 = cell_of(cx - rx, minx, inv_h, gx), x1 = cell_of(cx + rx, minx, inv_h, gx);
+    const int y0 = cell_of(cy - ry, miny, inv_h, gy), y1 = cell_of(cy + ry, miny, inv_h, gy);
+    const int z0 = cell_of(cz - rz, minz, inv_h, gz), z1 = cell_of(cz + rz, minz, inv_h, gz);
+
+    int hits = 0;  // wave-uniform
+    for (int z = z0; z <= z1; ++z) {
+        for (int y = y0; y <= y1; ++y) {
+            const int base = (z * gy + y) * gx;
+            const int s = cell_start[base + x0], e = cell_start[base + x1 + 1];
+            for (int p0 = s; p0 < e; p0 += 64) {  // wave-uniform trip count
+                const int p = p0 + lane;
+                bool hit = false;
+                int k = 0;
+                if (p < e) {
+                    const float4 q = sorted[p];
+                    const float d2 = sqdist(cx - q.x, cy - q.y, cz - q.z);
+                    hit = d2 < radius2;
+                    k = __float_as_int(q.w);
+                }
+                if (hit) atomicOr(&bm[k >> 5], 1u << (k & 31));
+                hits += __popcll(__ballot(hit));
+            }
+        }
+    }
+    if (hits == 0) return;  // row stays as the caller zero-filled it (pointnet2_utils.py:218)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // LDS atomics of this wave are done before it reads them back
+
+    // lane owns bitmap words [lane*wpl, (lane+1)*wpl) = indices [lane*wpl*32, ...): ascending with lane
+    unsigned int *mine = bm + lane * wpl;
+    int cnt = 0;
+    for (int w = 0; w < wpl; ++w) cnt += __popc(mine[w]);
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    int pos = incl - cnt;  // hits in lower lanes
+    int *out = idx + ((size_t)b * m + j) * nsample;
+    int first_local = -1;
+    if (cnt > 0) {
+        for (int w = 0; w < wpl; ++w) {
+            unsigned int bits = mine[w];
+            if (bits == 0u) continue;
+            mine[w] = 0u;  // leave the bitmap clean for the next launch-resident centre
+            if (first_local < 0) first_local = (lane * wpl + w) * 32 + (__ffs(bits) - 1);
+            while (bits != 0u && pos < nsample) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1u;
+                out[pos++] = (lane * wpl + w) * 32 + bit;
+            }
+        }
+    }
+    // slots beyond the hit count hold the first hit (ball_query_gpu.cu:41-45)
+    const unsigned long long have = __ballot(cnt > 0);
+    const int fl = __ffsll((long long)have) - 1;
+    const int first = __shfl(first_local, fl, 64);
+    for (int l = hits + lane; l < nsample; l += 64) out[l] = first;
+}
+
+}  // namespace pdm
+
+using namespace pdm;
+
+extern "C" size_t pdm_ball_query_grid_workspace_bytes(int b, int n) {
+    if (b <= 0 || n <= 0) return 0;
+    return (size_t)b * (BQG_HDR * sizeof(float) + (size_t)(BQG_CAP + 1) * sizeof(int) + (size_t)n * sizeof(float4)) + 64;
+}
+
+extern "C" int pdm_ball_query_grid(void *stream, int b, int n, int m, float radius, int nsample,
+                                   const float *new_xyz, const float *xyz, int *idx, void *workspace,
+                                   size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, PDM_E_BADARG,
+                "ball_query_grid: negative size b=%d n=%d m=%d nsample=%d", b, n, m, nsample);
+    if (b == 0 || m == 0 || nsample == 0 || n == 0) return 0;
+    PDM_REQUIRE(new_xyz && xyz && idx && workspace, PDM_E_BADARG, "ball_query_grid: null pointer");
+    PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "ball_query_grid: b=%d exceeds grid", b);
+    PDM_REQUIRE(workspace_bytes >= pdm_ball_query_grid_workspace_bytes(b, n), PDM_E_BADARG,
+                "ball_query_grid: workspace of %zu bytes, need %zu", workspace_bytes,
+                pdm_ball_query_grid_workspace_bytes(b, n));
+    const int wpl = (n + 2047) / 2048;  // bitmap words per lane: 64 lanes x wpl words x 32 bits >= n
+    const size_t lds = (size_t)BQG_QWAVES * wpl * 64 * sizeof(unsigned int);
+    PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "ball_query_grid: n=%d needs %zu bytes of LDS bitmap", n, lds);
+    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+    float4 *sorted = reinterpret_cast<float4 *>(base);
+    float *hdr = reinterpret_cast<float *>(sorted + (size_t)b * n);
+    int *cell_start = reinterpret_cast<int *>(hdr + (size_t)b * BQG_HDR);
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BQG_BUILD_T), 0, as_stream(stream), n, radius, xyz,
+                       hdr, cell_start, sorted);
+    int rc = check_launch("ball_query_grid(build)");
+    if (rc) return rc;
+    dim3 grid(divup(m, BQG_QWAVES), b);
+    hipLaunchKernelGGL(bq_grid_query_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius,
+                       nsample, wpl, new_xyz, hdr, cell_start, sorted, idx);
+    return check_launch("ball_query_grid(query)");
+}

@@ -39,10 +39,22 @@ def _run(fn, ref, *args):
         _native.call(fn, torch.cuda.current_stream(dev).cuda_stream, *args)
 
 
+# Clouds at least this large go through the grid-accelerated kernel (identical indices); smaller ones
+# are cheaper to scan exhaustively.  GRID_MAX_N is the LDS-bitmap limit of the grid kernel.
+GRID_MIN_N = 2048
+GRID_MAX_N = 131072
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     _check("new_xyz", new_xyz, torch.float32); _check("xyz", xyz, torch.float32); _check("idx", idx, torch.int32)
     _numel_at_least("new_xyz", new_xyz, b * m * 3); _numel_at_least("xyz", xyz, b * n * 3)
     _numel_at_least("idx", idx, b * m * nsample)
+    if GRID_MIN_N <= n <= GRID_MAX_N and b > 0 and m > 0:
+        nbytes = _native.lib().pdm_ball_query_grid_workspace_bytes(b, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+        _run("pdm_ball_query_grid", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+             idx.data_ptr(), ws.data_ptr(), nbytes)
+        return 1
     _run("pdm_ball_query", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
     return 1
 
@@ -133,7 +145,7 @@ def query_and_group_wrapper(b, n, m, c, radius, nsample, xyz, new_xyz, features,
     # two native calls (ball query, then the fused gather) so each kernel can be timed on its own;
     # pdm_query_and_group is the single-call form of the same pair.
     idx.zero_()
-    _run("pdm_ball_query", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+    ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
     _run("pdm_group_concat", xyz, b, n, m, c, nsample, xyz.data_ptr(), new_xyz.data_ptr(), fptr, idx.data_ptr(),
          out.data_ptr())
     return 1

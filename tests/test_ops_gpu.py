@@ -240,3 +240,68 @@ def test_ops_run_on_non_default_stream(oracle, dev):
         got = pu.furthest_point_sample(x, 128)
     s.synchronize()
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ grid-accelerated ball query
+
+@pytest.fixture
+def force_grid(monkeypatch):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    monkeypatch.setattr(ext, "GRID_MIN_N", 1)
+    return ext
+
+
+@pytest.fixture
+def force_scan(monkeypatch):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    monkeypatch.setattr(ext, "GRID_MIN_N", 1 << 30)
+    return ext
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lidar"])
+@pytest.mark.parametrize("N,M", [(16384, 1024), (4096, 1024), (1000, 77), (70, 70)])
+@pytest.mark.parametrize("radius,ns", [(0.1, 16), (0.5, 32), (2.0, 16), (4.0, 32), (200.0, 48), (0.0, 8)])
+def test_ball_query_grid_index_exact(oracle, dev, force_grid, kind, N, M, radius, ns):
+    xyz = clouds(kind, 2, N, seed=41)
+    fidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.take_along_axis(xyz, fidx[:, :, None].astype(np.int64), 1)
+    new_xyz[:, ::7] += np.float32(radius * 0.6)  # centres that are not cloud points
+    ref = oracle.ball_query(radius, ns, xyz, new_xyz)
+    got = pu.ball_query(radius, ns, T(xyz, dev), T(new_xyz, dev))
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_ball_query_grid_degenerate_clouds(oracle, dev, force_grid):
+    rng = np.random.default_rng(5)
+    # all points identical; points on a line; far outliers stretching the bounding box; duplicates
+    same = np.ones((1, 300, 3), dtype=np.float32) * 3.25
+    line = np.zeros((1, 300, 3), dtype=np.float32); line[0, :, 0] = np.linspace(0, 30, 300)
+    outl = rng.uniform(0, 5, (1, 300, 3)).astype(np.float32); outl[0, 7] = [1e6, -1e6, 1e5]
+    dup = np.repeat(rng.uniform(0, 5, (1, 150, 3)).astype(np.float32), 2, axis=1)
+    for xyz in (same, line, outl, dup):
+        new_xyz = np.ascontiguousarray(xyz[:, ::3])
+        for radius, ns in [(0.5, 16), (3.0, 64), (1e7, 32)]:
+            ref = oracle.ball_query(radius, ns, xyz, new_xyz)
+            got = pu.ball_query(radius, ns, T(xyz, dev), T(new_xyz, dev))
+            np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_ball_query_grid_equals_scan_at_full_size(dev, monkeypatch):
+    """Size-independent property at BASELINE's full size: both kernels give identical indices."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    xyz = T(clouds("lidar", 8, 16384, seed=51), dev)
+    new_xyz = xyz[:, :4096].contiguous()
+    for radius, ns in [(0.1, 16), (0.5, 32), (1.0, 32)]:
+        monkeypatch.setattr(ext, "GRID_MIN_N", 1)
+        a = pu.ball_query(radius, ns, xyz, new_xyz)
+        monkeypatch.setattr(ext, "GRID_MIN_N", 1 << 30)
+        b = pu.ball_query(radius, ns, xyz, new_xyz)
+        assert torch.equal(a, b)
+
+
+def test_ball_query_scan_path_still_exact(oracle, dev, force_scan):
+    xyz = clouds("lidar", 2, 4096, seed=61)
+    new_xyz = np.ascontiguousarray(xyz[:, :512])
+    ref = oracle.ball_query(0.8, 32, xyz, new_xyz)
+    got = pu.ball_query(0.8, 32, T(xyz, dev), T(new_xyz, dev))
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
