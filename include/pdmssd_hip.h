@@ -106,6 +106,12 @@ int pdm_ball_query_grid(void *stream, int b, int n, int m, float radius, int nsa
                         const float *new_xyz, const float *xyz, int *idx, void *workspace,
                         size_t workspace_bytes);
 
+/* Grid-accelerated form of pdm_three_nn: identical dist2 / idx, bit for bit; needs m >= 1 and a
+ * caller-provided workspace of pdm_three_nn_grid_workspace_bytes(b, m) bytes. */
+size_t pdm_three_nn_grid_workspace_bytes(int b, int m);
+int pdm_three_nn_grid(void *stream, int b, int n, int m, const float *unknown, const float *known,
+                      float *dist2, int *idx, void *workspace, size_t workspace_bytes);
+
 /* The gather half of the above for a given idx (B,M,nsample): grouped xyz minus centre, grouped
  * features, concatenated on the channel axis -> out (B, 3+C, M, nsample)
  * (pointnet2_utils.py:250-257: two grouping_operation calls, the in-place subtract and torch.cat). */

@@ -22,6 +22,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGNATURES = {
     "pdm_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp],
     "pdm_ball_query_grid": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_three_nn_grid": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp],
@@ -40,7 +41,8 @@ _SIGNATURES = {
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,
 }
-EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes"] + list(_SIGNATURES)
+EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes",
+           "pdm_three_nn_grid_workspace_bytes"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -61,6 +63,8 @@ def lib():
         l.pdm_last_error.restype = ctypes.c_char_p
         l.pdm_ball_query_grid_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
+        l.pdm_three_nn_grid_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_three_nn_grid_workspace_bytes.argtypes = [_i, _i]
         if l.pdm_abi_version() != ABI_VERSION:
             raise NativeLibraryError(
                 f"libpdmssd_hip.so ABI {l.pdm_abi_version()} != expected {ABI_VERSION}; rebuild it")

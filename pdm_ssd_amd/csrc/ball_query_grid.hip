@@ -15,29 +15,14 @@
 // Exactness argument (DESIGN.md "ball query"): the cell function is monotone in the coordinate, and
 // every point that passes the fp32 test lies in [fl(c - R), fl(c + R)] per axis, so it is in a visited
 // cell whatever h is; the distance arithmetic is the same pinned sequence as everywhere else.
-#include "common.h"
+#include "grid.h"
 
 namespace pdm {
-
-constexpr int BQG_CAP = 15360;      // max cells per sample (LDS histogram: 60 KB)
-constexpr int BQG_BUILD_T = 1024;
-constexpr int BQG_HDR = 16;         // floats per sample header
-
-struct GridHdr {                    // lives in the workspace, one per sample (BQG_HDR floats)
-    float minx, miny, minz, inv_h;
-    int gx, gy, gz, ncells;
-};
-
-__device__ __forceinline__ int cell_of(float v, float mn, float inv_h, int g) {
-    // monotone non-decreasing in v; NaN maps to cell 0
-    const float t = __fmul_rn(v - mn, inv_h);
-    return (int)fminf(fmaxf(floorf(t), 0.0f), (float)(g - 1));
-}
 
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
 // workspace layout per call: [B headers][B * (CAP+1) cell starts][B * n float4 sorted points]
-__global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float radius,
+__global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float radius, int max_cells,
                                                                     const float *__restrict__ xyz_all,
                                                                     float *__restrict__ hdr_all,
                                                                     int *__restrict__ cell_start_all,
@@ -77,7 +62,10 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
             for (int w = 1; w < BQG_BUILD_T / 64; ++w) { lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]); }
             if (!(lo[a] <= hi[a])) { lo[a] = 0.0f; hi[a] = 0.0f; }  // empty / all-NaN axis
         }
-        float h = fmaxf(2.02f * fabsf(radius), 1e-30f);
+        // start from the larger of 2r and the finest grid the index range allows (<= 1024 cells per axis),
+        // then coarsen by 2x in volume per step until the cell budget is met
+        const float max_ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        float h = fmaxf(fmaxf(2.02f * fabsf(radius), max_ext * (1.0f / 1024.0f)), 1e-30f);
         if (!(h == h) || h > 3.0e38f) h = 3.0e38f;
         int g[3];
         for (int it = 0; it < 200; ++it) {
@@ -88,10 +76,10 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
                 if (!(q == q)) g[a] = 1;
                 total *= g[a];
             }
-            if (total <= BQG_CAP) break;
+            if (total <= max_cells) break;
             h *= 1.26f;
         }
-        if ((long long)g[0] * g[1] * g[2] > BQG_CAP) { g[0] = g[1] = g[2] = 1; }
+        if ((long long)g[0] * g[1] * g[2] > max_cells) { g[0] = g[1] = g[2] = 1; }
         sh.minx = lo[0]; sh.miny = lo[1]; sh.minz = lo[2];
         sh.inv_h = 1.0f / h;
         sh.gx = g[0]; sh.gy = g[1]; sh.gz = g[2];
@@ -159,12 +147,6 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
 }
 
 constexpr int BQG_QWAVES = 4;
-
-// per-axis search half-width with rounding margins: every point passing the fp32 test has
-// |c - x| < r (1 + 2^-21); R exceeds that by r 2^-10 plus 4x the rounding error of forming c +- R.
-__device__ __forceinline__ float search_halfwidth(float c, float absr) {
-    return __fmaf_rn(fabsf(c), 2.384185791015625e-07f /* 2^-22 */, absr * 1.0009765625f);
-}
 
 __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
     int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
@@ -250,13 +232,21 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
     for (int l = hits + lane; l < nsample; l += 64) out[l] = first;
 }
 
+int launch_grid_build(hipStream_t stream, int b, int n, float radius, int max_cells, const float *xyz,
+                      const GridWs &ws) {
+    if (max_cells > BQG_CAP) max_cells = BQG_CAP;
+    if (max_cells < 1) max_cells = 1;
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
+                       ws.hdr, ws.cell_start, ws.sorted);
+    return check_launch("grid_build");
+}
+
 }  // namespace pdm
 
 using namespace pdm;
 
 extern "C" size_t pdm_ball_query_grid_workspace_bytes(int b, int n) {
-    if (b <= 0 || n <= 0) return 0;
-    return (size_t)b * (BQG_HDR * sizeof(float) + (size_t)(BQG_CAP + 1) * sizeof(int) + (size_t)n * sizeof(float4)) + 64;
+    return grid_workspace_bytes(b, n);
 }
 
 extern "C" int pdm_ball_query_grid(void *stream, int b, int n, int m, float radius, int nsample,
@@ -273,16 +263,11 @@ extern "C" int pdm_ball_query_grid(void *stream, int b, int n, int m, float radi
     const int wpl = (n + 2047) / 2048;  // bitmap words per lane: 64 lanes x wpl words x 32 bits >= n
     const size_t lds = (size_t)BQG_QWAVES * wpl * 64 * sizeof(unsigned int);
     PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "ball_query_grid: n=%d needs %zu bytes of LDS bitmap", n, lds);
-    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
-    float4 *sorted = reinterpret_cast<float4 *>(base);
-    float *hdr = reinterpret_cast<float *>(sorted + (size_t)b * n);
-    int *cell_start = reinterpret_cast<int *>(hdr + (size_t)b * BQG_HDR);
-    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BQG_BUILD_T), 0, as_stream(stream), n, radius, xyz,
-                       hdr, cell_start, sorted);
-    int rc = check_launch("ball_query_grid(build)");
+    const GridWs ws = grid_carve(workspace, b, n);
+    int rc = launch_grid_build(as_stream(stream), b, n, radius, BQG_CAP, xyz, ws);
     if (rc) return rc;
     dim3 grid(divup(m, BQG_QWAVES), b);
     hipLaunchKernelGGL(bq_grid_query_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius,
-                       nsample, wpl, new_xyz, hdr, cell_start, sorted, idx);
+                       nsample, wpl, new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
     return check_launch("ball_query_grid(query)");
 }

@@ -43,6 +43,8 @@ def _run(fn, ref, *args):
 # are cheaper to scan exhaustively.  GRID_MAX_N is the LDS-bitmap limit of the grid kernel.
 GRID_MIN_N = 2048
 GRID_MAX_N = 131072
+# three_nn: known sets at least this large use the grid kernel (identical results)
+NN_GRID_MIN_M = 512
 
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
@@ -108,6 +110,12 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     _check("dist2", dist2, torch.float32); _check("idx", idx, torch.int32)
     _numel_at_least("unknown", unknown, b * n * 3); _numel_at_least("known", known, b * m * 3)
     _numel_at_least("dist2", dist2, b * n * 3); _numel_at_least("idx", idx, b * n * 3)
+    if NN_GRID_MIN_M <= m and b > 0 and n > 0:
+        nbytes = _native.lib().pdm_three_nn_grid_workspace_bytes(b, m)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=unknown.device)
+        _run("pdm_three_nn_grid", unknown, b, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(),
+             idx.data_ptr(), ws.data_ptr(), nbytes)
+        return
     _run("pdm_three_nn", unknown, b, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(), idx.data_ptr())
 
 

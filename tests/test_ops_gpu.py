@@ -305,3 +305,47 @@ def test_ball_query_scan_path_still_exact(oracle, dev, force_scan):
     ref = oracle.ball_query(0.8, 32, xyz, new_xyz)
     got = pu.ball_query(0.8, 32, T(xyz, dev), T(new_xyz, dev))
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ grid-accelerated three_nn
+
+@pytest.mark.parametrize("kind", ["uniform", "lidar"])
+@pytest.mark.parametrize("n,m", [(16384, 4096), (4096, 1024), (1000, 600), (300, 3), (50, 1), (64, 2)])
+def test_three_nn_grid_index_exact(oracle, dev, monkeypatch, kind, n, m):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    monkeypatch.setattr(ext, "NN_GRID_MIN_M", 1)
+    unknown = clouds(kind, 2, n, seed=71)
+    known = np.ascontiguousarray(unknown[:, :m]) if m >= 600 else clouds(kind, 2, m, seed=72)
+    ref_d2, ref_i = oracle.three_nn_dist2(unknown, known)
+    d, i = pu.three_nn(T(unknown, dev), T(known, dev))
+    np.testing.assert_array_equal(i.cpu().numpy(), ref_i)
+    np.testing.assert_array_equal(d.cpu().numpy(), np.sqrt(ref_d2))
+
+
+def test_three_nn_grid_ties_duplicates_and_outliers(oracle, dev, monkeypatch):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    monkeypatch.setattr(ext, "NN_GRID_MIN_M", 1)
+    rng = np.random.default_rng(9)
+    lattice = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(4), indexing="ij"), -1).reshape(1, -1, 3)
+    lattice = lattice.astype(np.float32)                       # many exactly equal distances
+    dup = np.repeat(rng.uniform(0, 9, (1, 200, 3)).astype(np.float32), 3, axis=1)   # triplicated points
+    same = np.full((1, 100, 3), 2.5, dtype=np.float32)          # zero extent
+    outl = rng.uniform(0, 5, (1, 400, 3)).astype(np.float32); outl[0, 11] = [1e6, 1e6, -1e6]
+    for known in (lattice, dup, same, outl):
+        unknown = np.concatenate([known[:, ::2] + np.float32(0.5), rng.uniform(-3, 14, (1, 333, 3)).astype(np.float32)], 1)
+        unknown = np.ascontiguousarray(unknown)
+        ref_d2, ref_i = oracle.three_nn_dist2(unknown, known)
+        d, i = pu.three_nn(T(unknown, dev), T(known, dev))
+        np.testing.assert_array_equal(i.cpu().numpy(), ref_i)
+        np.testing.assert_array_equal(d.cpu().numpy(), np.sqrt(ref_d2))
+
+
+def test_three_nn_grid_equals_scan_at_full_size(dev, monkeypatch):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    xyz = T(clouds("lidar", 8, 16384, seed=81), dev)
+    known = xyz[:, :4096].contiguous()
+    monkeypatch.setattr(ext, "NN_GRID_MIN_M", 1)
+    d1, i1 = pu.three_nn(xyz, known)
+    monkeypatch.setattr(ext, "NN_GRID_MIN_M", 1 << 30)
+    d2, i2 = pu.three_nn(xyz, known)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
