@@ -29,6 +29,7 @@ import torch.distributed as dist
 
 from pdm_ssd_amd import _native, synthetic
 from pdm_ssd_amd.pdm_neck import PDMNeck
+from pdm_ssd_amd.pipeline import PipelinedHotPath
 from pdm_ssd_amd.pointnet2_backbone import POINTRCNN_MSG_CFG, PointNet2MSG
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -168,6 +169,7 @@ def main():
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
@@ -187,11 +189,20 @@ def main():
     backbone, neck = build_models(device)
     _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
 
-    def step():
+    def step_serial():
         bd = {'batch_size': B, 'points': points, 'points_per_sample_checked': True}
         bd = backbone(bd)
         bd = neck(bd)
         return bd['spatial_features'], bd['point_features']
+
+    pipe = PipelinedHotPath(backbone, neck)
+
+    def step_pipelined():
+        # features of this batch || FPS chain of the next batch (same synthetic cloud every step)
+        bd = pipe.step(points, points, B, extra={'points_per_sample_checked': True})
+        return bd['spatial_features'], bd['point_features']
+
+    step = step_serial if args.serial else step_pipelined
 
     def barrier():
         if world > 1:
@@ -203,6 +214,7 @@ def main():
         # per-sample point-count check of the backbone (host sync) done once, outside the timed region
         counts = torch.bincount(points[:, 0].long(), minlength=B)
         assert int(counts.min()) == int(counts.max()) == N
+        pipe.prime(points, B)
         for _ in range(max(1, args.warmup)):
             step()
         torch.cuda.synchronize()
@@ -247,8 +259,13 @@ def main():
             psteps = max(3, min(args.steps, 10))
             with OpTimer() as timer:
                 for _ in range(psteps):
-                    step()
+                    step_serial()
                 ops = timer.summary(psteps)
+            t0s = time.perf_counter()
+            for _ in range(psteps):
+                step_serial()
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - t0s) / psteps * 1e3
 
     if rank != 0:
         if world > 1:
@@ -287,7 +304,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[2]: PointNet2MSG backbone + PDM neck forward, bs={B}/GPU x {N} pts, "
                                f"{args.clouds} KITTI-range clouds, fp32 inference, inputs resident in HBM",
-                   "launch": mode, "parallelism": f"dp{world}"},
+                   "launch": mode, "parallelism": f"dp{world}",
+                   "overlap": "none" if args.serial else "FPS chain of batch i+1 on a side stream under the "
+                              "feature half of batch i (pdm_ssd_amd/pipeline.py)",
+                   "ms_per_step_eager_serial": round(serial_ms, 4)},
         "roofline": roofline,
         "ball_query_plus_group": {"ms_per_step": round(bq_ms, 4), "alg_MB_per_step": round(bq_mb, 2),
                                   "GBps": round(bq_mb / 1e3 / (bq_ms / 1e3), 1) if bq_ms > 0 else None,

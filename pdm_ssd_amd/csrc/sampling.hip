@@ -168,6 +168,9 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int
     for (int j = 1; j < m; ++j) {
         float best = active ? -1.0f : -2.0f;
         int bestv = 0;
+#if defined(FPS_DIAG) && FPS_DIAG == 2
+        best = tmp[0] + cur.x; bestv = 0;  // timing-only build: no distance pass (results are wrong)
+#else
         if constexpr (PPT >= 2) {
             const v2f x1 = {cur.x, cur.x}, y1 = {cur.y, cur.y}, z1 = {cur.z, cur.z};
 #pragma unroll
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int
             bestv = 0;
             best = vmax(best, d0);
         }
+#endif
         // wave level: max, lowest lane among equals, that lane's point out of its registers
         const float wmax = wave_max(best);
         const unsigned long long mask = __ballot(best == wmax);
@@ -205,7 +209,11 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int
         mine.x = readlane_f(px[slot], wl);
         mine.y = readlane_f(py[slot], wl);
         mine.z = readlane_f(pz[slot], wl);
+#if defined(FPS_DIAG) && FPS_DIAG == 1
+        cur = mine;  // timing-only build: no cross-wave exchange (results are wrong)
+#else
         cur = block_pick<BLOCK>(wmax, mine, rec, j & 1);
+#endif
         if (p == 0) idxs[j] = cur.k;
     }
 

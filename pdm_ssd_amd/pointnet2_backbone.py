@@ -60,9 +60,22 @@ class PointNet2MSG(nn.Module):
         features = pc[:, 4:].contiguous() if pc.size(-1) > 4 else None
         return batch_idx, xyz, features
 
+    @torch.no_grad()
+    def sample_chain(self, xyz):
+        """The coordinate-only half of the SA stack: FPS + gather for every layer, xyz (B,N,3) ->
+        [new_xyz_1 .. new_xyz_L].  It depends on no feature, so a caller may run it ahead of time (e.g. on
+        a side stream for the NEXT batch, see pdm_ssd_amd/pipeline.py) and hand the result to forward()
+        as batch_dict['sampled_xyz']."""
+        out = []
+        for sa in self.SA_modules:
+            xyz = sa.sample(xyz)
+            out.append(xyz)
+        return out
+
     def forward(self, batch_dict):
         """batch_dict['points'] (sum N, 1+3+C) with column 0 = sample index -> adds
-        'point_features' (B*N, C_out) and 'point_coords' (B*N, 4)."""
+        'point_features' (B*N, C_out) and 'point_coords' (B*N, 4).
+        Optional batch_dict['sampled_xyz'] = sample_chain(xyz) computed earlier."""
         batch_size = batch_dict['batch_size']
         points = batch_dict['points']
         batch_idx, xyz, features = self.break_up_pc(points)
@@ -74,8 +87,10 @@ class PointNet2MSG(nn.Module):
             features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
 
         l_xyz, l_features = [xyz], [features]
-        for sa in self.SA_modules:
-            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+        presampled = batch_dict.get('sampled_xyz', None)
+        for k, sa in enumerate(self.SA_modules):
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1],
+                                     new_xyz=None if presampled is None else presampled[k])
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         batch_dict['sa_xyz'] = list(l_xyz)
