@@ -27,12 +27,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from pdm_ssd_amd import _native, synthetic
+from pdm_ssd_amd import _native, dist_utils, synthetic
 from pdm_ssd_amd.pdm_neck import PDMNeck
 from pdm_ssd_amd.pipeline import PipelinedHotPath
 from pdm_ssd_amd.pointnet2_backbone import POINTRCNN_MSG_CFG, PointNet2MSG
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
 VOXEL = [0.05, 0.05, 0.1]
 NECK_CFG = {'SOURCE_LAYER': 2, 'FEATURE_DIM': 128, 'DILATION': [7, 7, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 8,
             'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 256, 'NORMALIZE': True}
@@ -59,7 +60,7 @@ def make_batch(B, N, kind, seed0, device):
 
 def algorithmic_bytes(name, a):
     """SURVEY.md section 8 D4 formulas; `a` = the integer/float arguments of the C-ABI call."""
-    if name == "pdm_ball_query":
+    if name in ("pdm_ball_query", "pdm_ball_query_grid"):
         b, n, m, _r, ns = a[:5]
         return b * (12 * n + 12 * m + 4 * m * ns)
     if name == "pdm_group_concat":
@@ -75,7 +76,7 @@ def algorithmic_bytes(name, a):
     if name == "pdm_furthest_point_sampling":
         b, n, m = a[:3]
         return b * (12 * n + 4 * m)
-    if name == "pdm_three_nn":
+    if name in ("pdm_three_nn", "pdm_three_nn_grid"):
         b, n, m = a[:3]
         return b * (12 * n + 12 * m + 24 * n)
     if name == "pdm_three_interpolate":
@@ -135,6 +136,56 @@ class OpTimer:
         return out
 
 
+def mlp_flops(seq):
+    """2 * sum(cin * cout) of the 1x1 convs of a shared MLP = algorithmic FLOPs per position (unpadded)."""
+    return 2 * sum(m.in_channels * m.out_channels for m in seq if isinstance(m, (torch.nn.Conv1d, torch.nn.Conv2d)))
+
+
+def model_flops(backbone, B, N):
+    """Algorithmic GFLOP per step of the SA and FP shared MLPs."""
+    sa, fp, n = 0.0, 0.0, N
+    level_n = [N]
+    for m in backbone.SA_modules:
+        for g, mlp in zip(m.groupers, m.mlps):
+            sa += B * m.npoint * g.nsample * mlp_flops(mlp)
+        level_n.append(m.npoint)
+    for k, m in enumerate(backbone.FP_modules):
+        fp += B * level_n[k] * mlp_flops(m.mlp)
+    return sa / 1e9, fp / 1e9
+
+
+def reference_op_section(backbone, points, B, iters=5):
+    """The API-exact operators at the PointNet2MSG shapes, as the reference's QueryAndGroup issues them:
+    per SA scale one ball_query and two grouping_operation calls (xyz^T and features).  This is the
+    'ball_query + group_points vs HBM' figure of BASELINE.json, measured with HIP events per call."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    xyz = points[:, 1:4].contiguous().view(B, -1, 3)
+    feats = points[:, 4:].contiguous().view(B, -1, 1).permute(0, 2, 1).contiguous()
+    chans = [1, 96, 256, 512]
+    plan = []
+    for k, m in enumerate(backbone.SA_modules):
+        new_xyz = m.sample(xyz)
+        f = feats if k == 0 else torch.randn(B, chans[k], xyz.shape[1], device=xyz.device)
+        for g in m.groupers:
+            plan.append((g.radius, g.nsample, xyz, new_xyz, f, xyz.transpose(1, 2).contiguous()))
+        xyz = new_xyz
+    with OpTimer() as t:
+        for it in range(iters + 1):
+            if it == 1:
+                t.records.clear()  # first pass = warm-up
+            for radius, ns, x, nx, f, xt in plan:
+                idx = pu.ball_query(radius, ns, x, nx)
+                pu.grouping_operation(xt, idx)
+                pu.grouping_operation(f, idx)
+        ops = t.summary(iters)
+    ms = sum(o["ms_per_step"] for o in ops)
+    mb = sum(o["alg_MB_per_step"] for o in ops)
+    gp = [o for o in ops if o["op"] == "pdm_group_points"][0]
+    return {"ops": ops, "ms_per_step": round(ms, 4), "alg_MB_per_step": round(mb, 2),
+            "GBps": round(mb / ms, 1), "frac_of_hbm_peak": round(mb / ms / HBM_PEAK_GBS, 4),
+            "note": "8 ball_query + 16 group_points launches at bs=%d; target >= 0.60" % B}, gp
+
+
 # ----------------------------------------------------------------------------- CPU baseline
 
 def cpu_baseline(backbone, neck, N, kind, frames=2):
@@ -174,12 +225,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    rank, world, local_rank = dist_utils.init_from_env(backend="nccl")  # 'nccl' is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -204,10 +250,7 @@ def main():
 
     step = step_serial if args.serial else step_pipelined
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = dist_utils.barrier
 
     mode = "eager"
     with torch.no_grad():
@@ -248,10 +291,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
 
-        if world > 1:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = dist_utils.max_over_ranks(elapsed, device)
 
         # per-kernel pass (eager, instrumented with HIP events on the launch stream); rank 0 only
         ops = []
@@ -276,23 +316,42 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * B * args.steps / elapsed
 
-    # roofline of the dominant HBM-bound kernel of the path (BASELINE.json: ball_query+group_points vs HBM)
-    hbm_ops = [o for o in ops if o["op"] in ("pdm_group_concat", "pdm_group_points", "pdm_three_interpolate",
-                                              "pdm_scatter_bev", "pdm_bev_normalize")]
-    dom = max(hbm_ops, key=lambda o: o["ms_per_step"]) if hbm_ops else None
+    sa_gf, fp_gf = model_flops(backbone, B, N)
+    for o in ops:
+        if o["op"] == "pdm_sa_mlp_fused":
+            o["alg_GFLOP_per_step"] = round(sa_gf, 2)
+            o["TFLOPs"] = round(sa_gf / o["ms_per_step"], 1)
+        if o["op"] == "pdm_fp_mlp_fused":
+            o["alg_GFLOP_per_step"] = round(fp_gf, 2)
+            o["TFLOPs"] = round(fp_gf / o["ms_per_step"], 1)
+    # dominant roofline-bounded kernel of the step: the fused SA kernel (fp32 MFMA).  FPS takes longer but is
+    # a latency-bound dependency chain (one workgroup per cloud) with no bandwidth or matrix roofline; it is
+    # listed under "ops" with its iteration rate.
+    sa_op = [o for o in ops if o["op"] == "pdm_sa_mlp_fused"]
     roofline = None
-    if dom:
-        per_launch_bytes = dom["alg_MB_per_step"] * 1e6 / dom["calls_per_step"]
-        per_launch_s = dom["ms_per_step"] / 1e3 / dom["calls_per_step"]
-        ach = per_launch_bytes / per_launch_s / 1e9
-        roofline = {"bound": "hbm", "kernel": dom["op"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launches_per_step": dom["calls_per_step"],
-                    "avg_launch_us": round(per_launch_s * 1e6, 2),
-                    "alg_bytes_per_launch": int(per_launch_bytes)}
-    bq = [o for o in ops if o["op"] in ("pdm_ball_query", "pdm_group_concat", "pdm_group_points")]
-    bq_ms = sum(o["ms_per_step"] for o in bq)
-    bq_mb = sum(o["alg_MB_per_step"] for o in bq)
+    if sa_op:
+        o = sa_op[0]
+        per_launch_flop = sa_gf * 1e9 / o["calls_per_step"]
+        per_launch_s = o["ms_per_step"] / 1e3 / o["calls_per_step"]
+        ach = per_launch_flop / per_launch_s / 1e12
+        roofline = {"bound": "mfma", "kernel": "pdm::sa_mlp_fused_kernel (pdm_sa_mlp_fused)", "achieved": round(ach, 2),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": o["calls_per_step"],
+                    "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop)}
+    with torch.no_grad():
+        refops, gp = reference_op_section(backbone, points, B)
+    gp_launch_bytes = gp["alg_MB_per_step"] * 1e6 / gp["calls_per_step"]
+    gp_launch_s = gp["ms_per_step"] / 1e3 / gp["calls_per_step"]
+    roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_v4_kernel (pdm_group_points, API-exact operator)",
+                    "achieved": round(gp_launch_bytes / gp_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gp_launch_bytes / gp_launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": gp["calls_per_step"], "avg_launch_us": round(gp_launch_s * 1e6, 2),
+                    "alg_bytes_per_launch": int(gp_launch_bytes)}
+    fps_op = [o for o in ops if o["op"] == "pdm_furthest_point_sampling"]
+    if fps_op:
+        iters = B * 0 + sum(m.npoint - 1 for m in backbone.SA_modules)
+        fps_op[0]["serial_iterations_per_step"] = iters
+        fps_op[0]["us_per_iteration"] = round(fps_op[0]["ms_per_step"] * 1e3 / iters, 3)
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -309,9 +368,8 @@ def main():
                               "feature half of batch i (pdm_ssd_amd/pipeline.py)",
                    "ms_per_step_eager_serial": round(serial_ms, 4)},
         "roofline": roofline,
-        "ball_query_plus_group": {"ms_per_step": round(bq_ms, 4), "alg_MB_per_step": round(bq_mb, 2),
-                                  "GBps": round(bq_mb / 1e3 / (bq_ms / 1e3), 1) if bq_ms > 0 else None,
-                                  "frac_of_hbm_peak": round(bq_mb / 1e3 / (bq_ms / 1e3) / HBM_PEAK_GBS, 4) if bq_ms > 0 else None},
+        "roofline_hbm": roofline_hbm,
+        "ball_query_plus_group": refops,
         "ops": ops,
         "cpu_baseline": cpu,
     }

@@ -1,0 +1,132 @@
+"""Oracle and module restatement against the committed fixtures under tests/golden/."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_backbone
+from oracle import cpu_oracle as o
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return np.load(os.path.join(G, "oracle_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return np.load(os.path.join(G, "ref_modules.npz"))
+
+
+def test_oracle_regression_vectors(vec):
+    xyz, feat = vec['xyz'], vec['feat']
+    fidx = o.furthest_point_sample(xyz, 128)
+    np.testing.assert_array_equal(fidx, vec['fps_idx'])
+    new_xyz = np.ascontiguousarray(np.take_along_axis(xyz, fidx[:, :, None].astype(np.int64), 1))
+    np.testing.assert_array_equal(o.gather_operation(np.ascontiguousarray(xyz.transpose(0, 2, 1)), fidx), vec['gather_xyz'])
+    for r, ns in [(0.5, 16), (1.0, 32), (2.0, 16), (4.0, 32)]:
+        np.testing.assert_array_equal(o.ball_query(r, ns, xyz, new_xyz), vec[f'ball_r{r}_ns{ns}'])
+    idx = vec['ball_r1.0_ns32']
+    np.testing.assert_array_equal(o.grouping_operation(feat, idx), vec['group_feat'])
+    np.testing.assert_array_equal(o.grouping_operation_grad(vec['group_grad_in'], idx, 1024), vec['group_grad'])
+    d2, i3 = o.three_nn_dist2(xyz, new_xyz)
+    np.testing.assert_array_equal(i3, vec['nn_idx']); np.testing.assert_array_equal(d2, vec['nn_dist2'])
+    np.testing.assert_array_equal(o.three_interpolate(vec['interp_feat'], i3, vec['interp_w']), vec['interp_out'])
+    np.testing.assert_array_equal(o.three_interpolate_grad(vec['interp_grad_in'], i3, vec['interp_w'], 128), vec['interp_grad'])
+
+
+def test_pdm_regression_vectors(vec):
+    origin, cell, inv_cell, dims = o.pdm_grid_params((0, -40, -3, 70.4, 40, 1), (1.6, 1.6, 2.0))
+    g, ws = o.pdm_scatter(vec['pdm_xyz'], vec['pdm_feat'], vec['pdm_sh'], vec['pdm_is2'], origin, cell, inv_cell,
+                          dims, (5, 5, 3), 2, layout=1)
+    assert tuple(g.shape) == tuple(vec['pdm_grid_shape'])
+    nz = np.flatnonzero(g)
+    np.testing.assert_array_equal(nz, vec['pdm_nz_index'])
+    np.testing.assert_allclose(g.reshape(-1)[nz], vec['pdm_nz_value'], rtol=1e-6, atol=1e-7)
+    assert abs(float(ws.sum()) - float(vec['pdm_wsum_sum'])) < 1e-3
+    # layout 0 holds the same numbers in (B, C*D, H, W) order
+    g0, _ = o.pdm_scatter(vec['pdm_xyz'], vec['pdm_feat'], vec['pdm_sh'], vec['pdm_is2'], origin, cell, inv_cell,
+                          dims, (5, 5, 3), 2, layout=0)
+    np.testing.assert_array_equal(g0, g.transpose(0, 3, 1, 2))
+
+
+def _load(module, ref, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(ref[k]) for k in ref.files if k.startswith(prefix)}
+    missing = module.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return module.eval()
+
+
+def test_sa_module_matches_reference_module(ref):
+    """The reference's PointnetSAModuleMSG.forward (run through gen_module_fixtures.py) == this repo's
+    module weights + CPU statement of the SA graph; state_dict loads with strict=True (same key names)."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_modules as pm
+    sa = pm.PointnetSAModuleMSG(npoint=32, radii=[0.4, 0.8], nsamples=[8, 16], mlps=[[3, 8, 16], [3, 8, 24]])
+    _load(sa, ref, 'sa_state.')
+    new_xyz, new_feat = cpu_backbone.sa_forward(sa, ref['sa_xyz'], ref['sa_feat'])
+    np.testing.assert_array_equal(new_xyz, ref['sa_new_xyz'])
+    np.testing.assert_allclose(new_feat, ref['sa_new_feat'], rtol=1e-5, atol=1e-5)
+
+
+def test_fp_module_matches_reference_module(ref):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_modules as pm
+    fp = _load(pm.PointnetFPModule(mlp=[29, 16, 12]), ref, 'fp_state.')
+    out = cpu_backbone.fp_forward(fp, ref['fp_unknown'], ref['fp_known'], ref['fp_uf'], ref['fp_kf'])
+    np.testing.assert_allclose(out, ref['fp_out'], rtol=1e-5, atol=1e-5)
+
+
+def test_query_and_group_matches_reference_glue(ref):
+    out, _ = o.query_and_group(0.5, 8, ref['sa_xyz'], ref['qg_new_xyz'], ref['sa_feat'])
+    np.testing.assert_array_equal(out, ref['qg_out'])
+    ga = np.concatenate([ref['sa_xyz'].transpose(0, 2, 1)[:, :, None], ref['sa_feat'][:, :, None]], 1)
+    np.testing.assert_array_equal(ga, ref['groupall_out'])
+
+
+def test_backbone_state_dict_keys_match_reference():
+    from pdm_ssd_amd.pointnet2_backbone import POINTRCNN_MSG_CFG, PointNet2MSG
+    manifest = json.load(open(os.path.join(G, "ref_state_dict_manifest.json")))
+    want = manifest['PointNet2MSG(pointrcnn, input_channels=4)']
+    got = {k: list(v.shape) for k, v in PointNet2MSG(POINTRCNN_MSG_CFG, input_channels=4).state_dict().items()}
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_gpu_modules_match_reference_fixtures(ref, dev):
+    """Same fixtures, HIP path: unfused autograd graph and fused MFMA kernels."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_modules as pm
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    sa = pm.PointnetSAModuleMSG(npoint=32, radii=[0.4, 0.8], nsamples=[8, 16], mlps=[[3, 8, 16], [3, 8, 24]])
+    sa = _load(sa, ref, 'sa_state.').to(dev)
+    with torch.no_grad():
+        nx, nf = sa(t(ref['sa_xyz']), t(ref['sa_feat']))
+    np.testing.assert_array_equal(nx.cpu().numpy(), ref['sa_new_xyz'])
+    np.testing.assert_allclose(nf.cpu().numpy(), ref['sa_new_feat'], rtol=1e-4, atol=1e-4)
+    fp = _load(pm.PointnetFPModule(mlp=[29, 16, 12]), ref, 'fp_state.').to(dev)
+    with torch.no_grad():
+        fo = fp(t(ref['fp_unknown']), t(ref['fp_known']), t(ref['fp_uf']), t(ref['fp_kf']))
+    np.testing.assert_allclose(fo.cpu().numpy(), ref['fp_out'], rtol=1e-4, atol=1e-4)
+    qg = pu.QueryAndGroup(0.5, 8)(t(ref['sa_xyz']), t(ref['qg_new_xyz']), t(ref['sa_feat']))
+    np.testing.assert_array_equal(qg.cpu().numpy(), ref['qg_out'])
+    ga = pu.GroupAll(True)(t(ref['sa_xyz']), None, t(ref['sa_feat']))
+    np.testing.assert_array_equal(ga.cpu().numpy(), ref['groupall_out'])
+
+
+@pytest.mark.gpu
+def test_gpu_ops_match_regression_vectors(vec, dev):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xyz = t(vec['xyz'])
+    fidx = pu.furthest_point_sample(xyz, 128)
+    np.testing.assert_array_equal(fidx.cpu().numpy(), vec['fps_idx'])
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), fidx).transpose(1, 2).contiguous()
+    for r, ns in [(0.5, 16), (1.0, 32), (2.0, 16), (4.0, 32)]:
+        np.testing.assert_array_equal(pu.ball_query(r, ns, xyz, new_xyz).cpu().numpy(), vec[f'ball_r{r}_ns{ns}'])
+    np.testing.assert_array_equal(pu.grouping_operation(t(vec['feat']), t(vec['ball_r1.0_ns32'])).cpu().numpy(), vec['group_feat'])
+    d, i3 = pu.three_nn(xyz, new_xyz)
+    np.testing.assert_array_equal(i3.cpu().numpy(), vec['nn_idx'])
+    np.testing.assert_array_equal(pu.three_interpolate(t(vec['interp_feat']), i3, t(vec['interp_w'])).cpu().numpy(), vec['interp_out'])

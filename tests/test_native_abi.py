@@ -1,0 +1,62 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/pdmssd_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pdmssd_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_extension_surface():
+    names = declared_symbols()
+    # the nine functions of pointnet2_api.cpp:10-24, under their pdm_ names
+    for n in ["pdm_ball_query", "pdm_group_points", "pdm_group_points_grad", "pdm_gather_points",
+              "pdm_gather_points_grad", "pdm_furthest_point_sampling", "pdm_three_nn", "pdm_three_interpolate",
+              "pdm_three_interpolate_grad"]:
+        assert n in names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from pdm_ssd_amd import _native
+    lib = _native.lib()
+    assert lib.pdm_abi_version() == _native.ABI_VERSION
+    raw = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), f"{name} declared in include/pdmssd_hip.h but not exported"
+    # and the Python binding table covers the header (tuning knobs are extra, undeclared on purpose)
+    bound = set(_native.EXPORTS)
+    assert set(declared_symbols()) <= bound, set(declared_symbols()) - bound
+
+
+def test_extension_module_mirrors_reference_function_table():
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    for n in ["ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper", "gather_points_wrapper",
+              "gather_points_grad_wrapper", "farthest_point_sampling_wrapper", "three_nn_wrapper",
+              "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]:
+        assert callable(getattr(ext, n))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from pdm_ssd_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError):
+        _native.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pdm_ssd_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libpdmssd_oracle" not in src, f
