@@ -203,10 +203,48 @@ struct RowOut {
     }
 };
 
-// One layer for the W waves of a workgroup.  The layer's nmb 16-channel output blocks are dealt to the
-// waves in contiguous shares; a wave walks its share in passes of up to 4 blocks.  Per 16-deep K block
-// a pass issues {1 B fragment, <=4 A fragments, <=16 MFMAs}; the next K block's fragments are requested
-// before the current block's MFMAs issue (>= 512 cycles of matrix work in flight per request at 4 blocks).
+// One pass = NB (1..4) 16-channel output blocks starting at block mb, over the whole K range.
+// Per 16-deep K block: 1 B fragment + NB A fragments feed 4*NB MFMAs, issued round-robin over the NB
+// independent accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, the pipe issues one per
+// 32); the next K block's fragments are requested before the current block's MFMAs.
+template <int NB, class In, class Out>
+__device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__ w, size_t bstride,
+                                         const float *__restrict__ bias, int g, const In &in,
+                                         const Out &out) {
+    const f4 *__restrict__ wb[NB];
+    f4 acc[NB], a[NB], an[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        wb[i] = w + (size_t)(mb + i) * bstride;
+        acc[i] = *reinterpret_cast<const f4 *>(bias + 16 * (mb + i) + 4 * g);
+        an[i] = wb[i][0];
+    }
+    f4 bn = in(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const f4 b = bn;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a[i] = an[i];
+        if (kb + 1 < nkb) {
+            const size_t o = (size_t)(kb + 1) * 64;
+            bn = in(kb + 1);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) an[i] = wb[i][o];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) out(mb + i, relu4(acc[i]));
+}
+
+// One layer for the W waves of a workgroup: the nmb output blocks are dealt to the waves in contiguous
+// shares; a wave walks its share in passes of up to 4 blocks.  `wave` must be wave-uniform (SGPR).
 template <int W, class In, class Out>
 __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restrict__ wp,
                                           const float *__restrict__ bias, int lane, int wave,
@@ -222,35 +260,10 @@ __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restr
     const size_t bstride = (size_t)nkb * 64;              // f4 elements between consecutive blocks
     for (int mb = mb_begin; mb < mb_end; mb += bpp) {
         const int nb = min(bpp, mb_end - mb);             // wave-uniform
-        const f4 *__restrict__ w0 = w + (size_t)mb * bstride;
-        const f4 *__restrict__ w1 = nb > 1 ? w0 + bstride : w0;
-        const f4 *__restrict__ w2 = nb > 2 ? w1 + bstride : w0;
-        const f4 *__restrict__ w3 = nb > 3 ? w2 + bstride : w0;
-        const float *bb = bias + 16 * mb + 4 * g;
-        f4 acc0 = *reinterpret_cast<const f4 *>(bb);
-        f4 acc1 = *reinterpret_cast<const f4 *>(bb + (nb > 1 ? 16 : 0));
-        f4 acc2 = *reinterpret_cast<const f4 *>(bb + (nb > 2 ? 32 : 0));
-        f4 acc3 = *reinterpret_cast<const f4 *>(bb + (nb > 3 ? 48 : 0));
-        f4 bn = in(0), a0n = w0[0], a1n = w1[0], a2n = w2[0], a3n = w3[0];
-        for (int kb = 0; kb < nkb; ++kb) {
-            const f4 b = bn, a0 = a0n, a1 = a1n, a2 = a2n, a3 = a3n;
-            if (kb + 1 < nkb) {
-                const size_t o = (size_t)(kb + 1) * 64;
-                bn = in(kb + 1);
-                a0n = w0[o];
-                if (nb > 1) a1n = w1[o];
-                if (nb > 2) a2n = w2[o];
-                if (nb > 3) a3n = w3[o];
-            }
-            acc0 = mfma4(acc0, a0, b);
-            if (nb > 1) acc1 = mfma4(acc1, a1, b);
-            if (nb > 2) acc2 = mfma4(acc2, a2, b);
-            if (nb > 3) acc3 = mfma4(acc3, a3, b);
-        }
-        out(mb, relu4(acc0));
-        if (nb > 1) out(mb + 1, relu4(acc1));
-        if (nb > 2) out(mb + 2, relu4(acc2));
-        if (nb > 3) out(mb + 3, relu4(acc3));
+        if (nb == 4) mlp_pass<4>(nkb, mb, w, bstride, bias, g, in, out);
+        else if (nb == 3) mlp_pass<3>(nkb, mb, w, bstride, bias, g, in, out);
+        else if (nb == 2) mlp_pass<2>(nkb, mb, w, bstride, bias, g, in, out);
+        else mlp_pass<1>(nkb, mb, w, bstride, bias, g, in, out);
     }
 }
 
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs 
                                                               const float *__restrict__ wpack,
                                                               const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pos = lane & 15, g = lane >> 4;
     float *P = lds;
     float *Q = P + 16 * d.lds_p;
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(64 * W) void fp_mlp_fused_kernel(MlpDesc d, FpArgs 
                                                               const float *__restrict__ wpack,
                                                               const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pos = lane & 15, g = lane >> 4;
     float *P = lds;
     float *Q = P + 16 * d.lds_p;

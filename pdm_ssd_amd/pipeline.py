@@ -6,6 +6,8 @@ Why: FPS is one workgroup per cloud — at bs=32 it occupies 32 of the 256 CUs f
 the longest dependency chain of the step, while everything else is wide.  Nothing in the sampling
 chain depends on features, so it is hoisted one batch ahead; every step still does one full batch of
 every kind of work (the sampling it consumes was produced by the previous step).
+The PDM neck, which reads only SA outputs, is likewise started on its own stream as soon as the SA stack
+is done and runs beside the feature-propagation layers.
 Works eagerly and under hipGraph capture (fork/join of the two streams inside the captured region;
 the hand-over buffers are static).
 """
@@ -17,6 +19,7 @@ class PipelinedHotPath:
         self.backbone = backbone
         self.neck = neck
         self.side = torch.cuda.Stream()
+        self.neck_stream = torch.cuda.Stream()
         self.cur = None  # static hand-over buffers: sampled xyz of the batch about to be processed
 
     @staticmethod
@@ -39,9 +42,16 @@ class PipelinedHotPath:
         bd = {'batch_size': batch_size, 'points': points_cur, 'sampled_xyz': self.cur}
         if extra:
             bd.update(extra)
+        if self.neck is not None:
+            # the neck reads only SA outputs: run it (atomic-bound scatter) beside the FP layers (MFMA-bound)
+            def start_neck(d):
+                self.neck_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.neck_stream):
+                    self.neck(d)
+            bd['after_sa_hook'] = start_neck
         bd = self.backbone(bd)
         if self.neck is not None:
-            bd = self.neck(bd)
+            main.wait_stream(self.neck_stream)
         main.wait_stream(self.side)
         for c, n in zip(self.cur, nxt):
             c.copy_(n)

@@ -95,6 +95,11 @@ class PointNet2MSG(nn.Module):
             l_features.append(li_features)
         batch_dict['sa_xyz'] = list(l_xyz)
         batch_dict['sa_features'] = list(l_features)
+        after_sa = batch_dict.get('after_sa_hook', None)
+        if after_sa is not None:
+            # everything the PDM neck reads exists now; a caller may start it on another stream so it runs
+            # beside the feature-propagation layers (pdm_ssd_amd/pipeline.py)
+            after_sa(batch_dict)
 
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
             l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
