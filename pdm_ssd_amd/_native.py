@@ -37,6 +37,8 @@ _SIGNATURES = {
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_tune_fps_variant": None,
     "pdm_tune_fused_waves": None,
+    "pdm_tune_fused_tiles": None,
+    "pdm_tune_fused_wg_per_cu": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,

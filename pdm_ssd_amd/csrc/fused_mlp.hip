@@ -166,7 +166,7 @@ struct PoolOut {
     __device__ __forceinline__ void operator()(int mb, f4 v) const {
         v.x = row16_max_nonneg(v.x); v.y = row16_max_nonneg(v.y);
         v.z = row16_max_nonneg(v.z); v.w = row16_max_nonneg(v.w);
-        if ((lane & 15) != 0) return;
+        if ((lane & 15) != 0 || !orow) return;
         float *p = pool + 16 * mb + 4 * g;
         if (!first_tile) {
             const f4 o = *reinterpret_cast<const f4 *>(p);
@@ -203,49 +203,101 @@ struct RowOut {
     }
 };
 
-// One pass = NB (1..4) 16-channel output blocks starting at block mb, over the whole K range.
-// Per 16-deep K block: 1 B fragment + NB A fragments feed 4*NB MFMAs, issued round-robin over the NB
-// independent accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, the pipe issues one per
-// 32); the next K block's fragments are requested before the current block's MFMAs.
-template <int NB, class In, class Out>
+// A workgroup iteration covers NT (1 or 2) tiles of 16 positions that share every A (weight) fragment.
+template <class T, int NT>
+struct Tiles {
+    T t[NT];
+};
+template <int NT>
+struct LdsTilesIn {
+    const float *row;  // &H[pos][4g] of tile 0; tile t is 16 positions further
+    int tile_stride;   // floats between tiles = 16 * width
+    __device__ __forceinline__ f4 operator()(int t, int kb) const {
+        return *reinterpret_cast<const f4 *>(row + t * tile_stride + 16 * kb);
+    }
+};
+template <int NT>
+struct LdsTilesOut {
+    float *row;
+    int tile_stride;
+    __device__ __forceinline__ void operator()(int t, int mb, f4 v) const {
+        *reinterpret_cast<f4 *>(row + t * tile_stride + 16 * mb) = v;
+    }
+};
+template <class T, int NT>
+struct TilesIn {
+    const Tiles<T, NT> *p;
+    __device__ __forceinline__ f4 operator()(int t, int kb) const { return p->t[t](kb); }
+};
+template <class T, int NT>
+struct TilesOut {
+    const Tiles<T, NT> *p;
+    __device__ __forceinline__ void operator()(int t, int mb, f4 v) const { p->t[t](mb, v); }
+};
+
+// One pass = NB (1..4) 16-channel output blocks starting at block mb, over the whole K range, for NT
+// position tiles.  Per 16-deep K block: NT B fragments + NB A fragments feed 4*NB*NT MFMAs, issued
+// round-robin over the NB*NT independent accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40
+// cycles, the pipe issues one per 32); the next K block's fragments are requested before the current
+// block's MFMAs.
+template <int NB, int NT, class In, class Out>
 __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__ w, size_t bstride,
                                          const float *__restrict__ bias, int g, const In &in,
                                          const Out &out) {
     const f4 *__restrict__ wb[NB];
-    f4 acc[NB], a[NB], an[NB];
+    f4 acc[NB][NT], a[NB], an[NB], b[NT], bn[NT];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         wb[i] = w + (size_t)(mb + i) * bstride;
-        acc[i] = *reinterpret_cast<const f4 *>(bias + 16 * (mb + i) + 4 * g);
+        const f4 bi = *reinterpret_cast<const f4 *>(bias + 16 * (mb + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = bi;
         an[i] = wb[i][0];
     }
-    f4 bn = in(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bn[t] = in(t, 0);
     for (int kb = 0; kb < nkb; ++kb) {
-        const f4 b = bn;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = bn[t];
 #pragma unroll
         for (int i = 0; i < NB; ++i) a[i] = an[i];
         if (kb + 1 < nkb) {
             const size_t o = (size_t)(kb + 1) * 64;
-            bn = in(kb + 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[t] = in(t, kb + 1);
 #pragma unroll
             for (int i = 0; i < NB; ++i) an[i] = wb[i][o];
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[t].x, acc[i][t], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[t].y, acc[i][t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[t].z, acc[i][t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[t].w, acc[i][t], 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) out(mb + i, relu4(acc[i]));
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) out(t, mb + i, relu4(acc[i][t]));
 }
 
 // One layer for the W waves of a workgroup: the nmb output blocks are dealt to the waves in contiguous
 // shares; a wave walks its share in passes of up to 4 blocks.  `wave` must be wave-uniform (SGPR).
-template <int W, class In, class Out>
+template <int W, int NT, int MAXNB, class In, class Out>
 __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restrict__ wp,
                                           const float *__restrict__ bias, int lane, int wave,
                                           const In &in, const Out &out) {
@@ -254,16 +306,16 @@ __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restr
     const int mb_begin = wave * share;
     const int mb_end = min(mb_begin + share, nmb);
     if (mb_begin >= mb_end) return;
-    const int passes = (share + 3) >> 2;
-    const int bpp = (share + passes - 1) / passes;        // blocks per pass, 1..4
+    const int passes = (share + MAXNB - 1) / MAXNB;
+    const int bpp = (share + passes - 1) / passes;        // blocks per pass, 1..MAXNB
     const f4 *__restrict__ w = reinterpret_cast<const f4 *>(wp) + lane;
     const size_t bstride = (size_t)nkb * 64;              // f4 elements between consecutive blocks
     for (int mb = mb_begin; mb < mb_end; mb += bpp) {
         const int nb = min(bpp, mb_end - mb);             // wave-uniform
-        if (nb == 4) mlp_pass<4>(nkb, mb, w, bstride, bias, g, in, out);
-        else if (nb == 3) mlp_pass<3>(nkb, mb, w, bstride, bias, g, in, out);
-        else if (nb == 2) mlp_pass<2>(nkb, mb, w, bstride, bias, g, in, out);
-        else mlp_pass<1>(nkb, mb, w, bstride, bias, g, in, out);
+        if (MAXNB >= 4 && nb == 4) mlp_pass<4, NT>(nkb, mb, w, bstride, bias, g, in, out);
+        else if (MAXNB >= 3 && nb == 3) mlp_pass<3, NT>(nkb, mb, w, bstride, bias, g, in, out);
+        else if (MAXNB >= 2 && nb == 2) mlp_pass<2, NT>(nkb, mb, w, bstride, bias, g, in, out);
+        else mlp_pass<1, NT>(nkb, mb, w, bstride, bias, g, in, out);
     }
 }
 
@@ -273,11 +325,11 @@ __device__ __forceinline__ void wg_sync() {
     else __builtin_amdgcn_wave_barrier();  // one wave: LDS ops execute in order, only pin the compiler
 }
 
-// Runs layer L for one tile.  P/Q = the workgroup's two LDS buffers (widths lds_p / lds_q):
-// layer 1 writes Q, layer 2 writes P, layer 3 writes Q ...; a staged input tile lives in P.
-// The layer sequence is unrolled so every descriptor field is read with a constant index (a runtime
-// index into the by-value descriptor would push it to scratch).
-template <int W, int L, class In, class Out>
+// Runs layer L for the NT tiles of one workgroup iteration.  P/Q = the workgroup's two LDS buffers
+// (NT*16 positions x lds_p / lds_q floats): layer 1 writes Q, layer 2 writes P, layer 3 writes Q ...; a
+// staged input lives in P.  The layer sequence is unrolled so every descriptor field is read with a
+// constant index (a runtime index into the by-value descriptor would push it to scratch).
+template <int W, int NT, int MAXNB, int L, class In, class Out>
 __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restrict__ wpack,
                                           const float *__restrict__ bias, float *P, float *Q, int lane,
                                           int wave, const In &in, const Out &out) {
@@ -288,38 +340,40 @@ __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restr
     const bool last = L == d.nlayers;
     float *ob = (L & 1) ? Q : P;
     const int ow = (L & 1) ? d.lds_q : d.lds_p;
-    const LdsOut lo{ob + pos * ow + 4 * g};
+    const LdsTilesOut<NT> lo{ob + pos * ow + 4 * g, 16 * ow};
     if (L == 1 && !d.stage_in) {
-        if (last) mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, in, out);
-        else mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, in, lo);
+        if (last) mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, in, out);
+        else mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, in, lo);
     } else {
         float *ib = (L & 1) ? P : Q;  // layer 1 (staged) and layer 3 read P, layer 2 reads Q
         const int iw = (L & 1) ? d.lds_p : d.lds_q;
-        const LdsIn li{ib + pos * iw + 4 * g};
-        if (last) mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, li, out);
-        else mlp_layer<W>(nkb, nmb, wl, bl, lane, wave, li, lo);
+        const LdsTilesIn<NT> li{ib + pos * iw + 4 * g, 16 * iw};
+        if (last) mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, li, out);
+        else mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, li, lo);
     }
     wg_sync<W>();
 }
 
-template <int W, class In, class Out>
+template <int W, int NT, int MAXNB, class In, class Out>
 __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restrict__ wpack,
                                         const float *__restrict__ bias, float *P, float *Q, int lane,
                                         int wave, const In &in, const Out &out) {
     if (d.stage_in) {
-        // gather the input tile once, K blocks dealt round-robin to the waves: P[pos][K0]
+        // gather the input tiles once, K blocks dealt round-robin to the waves: P[tile*16 + pos][K0]
         float *row = P + (lane & 15) * d.lds_p + 4 * (lane >> 4);
         const int nkb0 = d.K[0] >> 4;
-        for (int kb = wave; kb < nkb0; kb += W) *reinterpret_cast<f4 *>(row + 16 * kb) = in(kb);
+        for (int kb = wave; kb < nkb0; kb += W)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<f4 *>(row + t * 16 * d.lds_p + 16 * kb) = in(t, kb);
         wg_sync<W>();
     }
-    run_layer<W, 1>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 2) run_layer<W, 2>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 3) run_layer<W, 3>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 4) run_layer<W, 4>(d, wpack, bias, P, Q, lane, wave, in, out);
+    run_layer<W, NT, MAXNB, 1>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 2) run_layer<W, NT, MAXNB, 2>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 3) run_layer<W, NT, MAXNB, 3>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 4) run_layer<W, NT, MAXNB, 4>(d, wpack, bias, P, Q, lane, wave, in, out);
 }
 
-template <int W>
+template <int W, int NT, int MAXNB>
 __global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
                                                               const float *__restrict__ wpack,
                                                               const float *__restrict__ bias) {
@@ -327,33 +381,45 @@ __global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pos = lane & 15, g = lane >> 4;
     float *P = lds;
-    float *Q = P + 16 * d.lds_p;
-    float *pool = Q + 16 * d.lds_q;
-    const int tiles_per_centre = a.ns >> 4;
+    float *Q = P + NT * 16 * d.lds_p;
+    float *pool = Q + NT * 16 * d.lds_q;
+    const int tpc = a.ns >> 4;  // tiles per centre
     const long long ncentres = (long long)a.b * a.m;
-    for (long long ctr = blockIdx.x; ctr < ncentres; ctr += gridDim.x) {
-        const int b = (int)(ctr / a.m);
-        const float *c3 = a.new_xyz + ctr * 3;
-        const float cx = c3[0], cy = c3[1], cz = c3[2];
-        for (int t = 0; t < tiles_per_centre; ++t) {
-            const int nb = a.idx[ctr * a.ns + t * 16 + pos];
-            const float *p3 = a.xyz + ((size_t)b * a.n + nb) * 3;
-            SaIn in;
-            in.frow = a.cin > 0 ? a.feat + ((size_t)b * a.n + nb) * a.cin : nullptr;
-            in.rx = p3[0] - cx; in.ry = p3[1] - cy; in.rz = p3[2] - cz;  // pointnet2_utils.py:252
-            in.cin = a.cin; in.g = g;
-            in.vec = (a.cin & 3) == 0 && a.cin > 0;
-            PoolOut out;
-            out.pool = pool;
-            out.orow = a.out + ctr * a.out_stride + a.out_coff;
-            out.cout = a.cout; out.lane = lane; out.g = g;
-            out.first_tile = t == 0; out.last_tile = t == tiles_per_centre - 1;
-            run_mlp<W>(d, wpack, bias, P, Q, lane, wave, in, out);
+    // Work unit = whole centres, so the tiles of one centre (pooled through `pool`) stay in one workgroup:
+    // tpc >= NT: one centre per unit, walked in ceil(tpc/NT) sub-steps; tpc < NT: NT centres per unit.
+    const int cpu_ = tpc >= NT ? 1 : NT / tpc;          // centres per unit
+    const int nsub = tpc >= NT ? (tpc + NT - 1) / NT : 1;
+    const long long nunits = (ncentres + cpu_ - 1) / cpu_;
+    for (long long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+        for (int sub = 0; sub < nsub; ++sub) {
+            Tiles<SaIn, NT> in;
+            Tiles<PoolOut, NT> out;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long ctr_raw = tpc >= NT ? unit : unit * cpu_ + t / tpc;
+                const int tic = tpc >= NT ? sub * NT + t : t % tpc;
+                const bool live = ctr_raw < ncentres && tic < tpc;
+                const long long ctr = live ? ctr_raw : 0;
+                const int tl = live ? tic : 0;
+                const int b = (int)(ctr / a.m);
+                const float *c3 = a.new_xyz + ctr * 3;
+                const int nb = a.idx[ctr * a.ns + tl * 16 + pos];
+                const float *p3 = a.xyz + ((size_t)b * a.n + nb) * 3;
+                in.t[t].frow = a.cin > 0 ? a.feat + ((size_t)b * a.n + nb) * a.cin : nullptr;
+                in.t[t].rx = p3[0] - c3[0]; in.t[t].ry = p3[1] - c3[1]; in.t[t].rz = p3[2] - c3[2];  // pointnet2_utils.py:252
+                in.t[t].cin = a.cin; in.t[t].g = g;
+                in.t[t].vec = (a.cin & 3) == 0 && a.cin > 0;
+                out.t[t].pool = pool;
+                out.t[t].orow = live ? a.out + ctr * a.out_stride + a.out_coff : nullptr;
+                out.t[t].cout = a.cout; out.t[t].lane = lane; out.t[t].g = g;
+                out.t[t].first_tile = tic == 0; out.t[t].last_tile = tic == tpc - 1;
+            }
+            run_mlp<W, NT, MAXNB>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn, NT>{&in}, TilesOut<PoolOut, NT>{&out});
         }
     }
 }
 
-template <int W>
+template <int W, int NT, int MAXNB>
 __global__ __launch_bounds__(64 * W) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
                                                               const float *__restrict__ wpack,
                                                               const float *__restrict__ bias) {
@@ -361,36 +427,44 @@ __global__ __launch_bounds__(64 * W) void fp_mlp_fused_kernel(MlpDesc d, FpArgs 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pos = lane & 15, g = lane >> 4;
     float *P = lds;
-    float *Q = P + 16 * d.lds_p;
-    const int tiles_per_sample = (a.n + 15) >> 4;
-    const long long ntiles = (long long)a.b * tiles_per_sample;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = (int)(tile / tiles_per_sample);
-        const int p = (int)(tile - (long long)b * tiles_per_sample) * 16 + pos;
-        FpIn in;
-        in.live = p < a.n;
-        const size_t q = (size_t)b * a.n + (in.live ? p : 0);
-        const int *id = a.idx + q * 3;
-        const float *w = a.weight + q * 3;
-        in.r0 = a.known + ((size_t)b * a.m + id[0]) * a.c_known;
-        in.r1 = a.known + ((size_t)b * a.m + id[1]) * a.c_known;
-        in.r2 = a.known + ((size_t)b * a.m + id[2]) * a.c_known;
-        in.w0 = w[0]; in.w1 = w[1]; in.w2 = w[2];
-        in.srow = a.c_skip > 0 ? a.skip + q * a.c_skip : nullptr;
-        in.ck = a.c_known; in.cs = a.c_skip; in.g = g;
-        in.vec_k = (a.c_known & 3) == 0;
-        in.vec_s = (a.c_skip & 3) == 0 && (a.c_known & 3) == 0 && a.c_skip > 0;
-        RowOut out;
-        out.orow = in.live ? a.out + q * a.out_stride : nullptr;
-        out.cout = a.cout; out.g = g;
-        run_mlp<W>(d, wpack, bias, P, Q, lane, wave, in, out);
+    float *Q = P + NT * 16 * d.lds_p;
+    const int tps = (a.n + 15) >> 4;  // tiles per sample
+    const long long ntiles = (long long)a.b * tps;
+    const long long niter = (ntiles + NT - 1) / NT;
+    for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+        Tiles<FpIn, NT> in;
+        Tiles<RowOut, NT> out;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const long long tile = it * NT + t;
+            const int b = tile < ntiles ? (int)(tile / tps) : 0;
+            const int p = (int)(tile - (long long)b * tps) * 16 + pos;
+            FpIn &f = in.t[t];
+            f.live = tile < ntiles && p < a.n;
+            const size_t q = (size_t)b * a.n + (f.live ? p : 0);
+            const int *id = a.idx + q * 3;
+            const float *w = a.weight + q * 3;
+            f.r0 = a.known + ((size_t)b * a.m + id[0]) * a.c_known;
+            f.r1 = a.known + ((size_t)b * a.m + id[1]) * a.c_known;
+            f.r2 = a.known + ((size_t)b * a.m + id[2]) * a.c_known;
+            f.w0 = w[0]; f.w1 = w[1]; f.w2 = w[2];
+            f.srow = a.c_skip > 0 ? a.skip + q * a.c_skip : nullptr;
+            f.ck = a.c_known; f.cs = a.c_skip; f.g = g;
+            f.vec_k = (a.c_known & 3) == 0;
+            f.vec_s = (a.c_skip & 3) == 0 && (a.c_known & 3) == 0 && a.c_skip > 0;
+            out.t[t].orow = f.live ? a.out + q * a.out_stride : nullptr;
+            out.t[t].cout = a.cout; out.t[t].g = g;
+        }
+        run_mlp<W, NT, MAXNB>(d, wpack, bias, P, Q, lane, wave, TilesIn<FpIn, NT>{&in}, TilesOut<RowOut, NT>{&out});
     }
 }
 
 static int g_fused_waves = 0;
+static int g_fused_tiles = 0;
+static int g_fused_wg_per_cu = 32;  // grid cap = 256 CUs x this many workgroups (grid-stride loop beyond)
 
 static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max, int pool_floats,
-                     int *waves) {
+                     long long ntiles, int *waves, int *tiles_per_wg) {
     PDM_REQUIRE(nlayers >= 1 && nlayers <= FM_MAXL, PDM_E_BADARG, "%s: nlayers=%d not in [1,%d]", who, nlayers, FM_MAXL);
     PDM_REQUIRE(dims, PDM_E_BADARG, "%s: null dims", who);
     d.nlayers = nlayers;
@@ -418,8 +492,14 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     *waves = W;
     // stage the gathered input tile in LDS when the workgroup still fits >= 8 waves per CU (160 KB LDS)
     const int p_staged = p > d.K[0] ? p : d.K[0];
-    const int budget = (W == 1 ? 20 : W == 2 ? 40 : W == 4 ? 52 : 80) * 1024;
-    d.stage_in = (16 * (p_staged + 4 + q + 4) + pool_floats) * 4 <= budget ? 1 : 0;
+    // two 16-position tiles per workgroup share every weight fragment (half the A traffic, twice the MFMA
+    // work per pass); keep one when the problem has few tiles or the LDS tiles would not fit 64 KB
+    int NT = g_fused_tiles > 0 ? g_fused_tiles : 1;  // 2 measured no faster (more VGPRs, fewer waves)
+    (void)ntiles;
+    if ((NT * 16 * (p + 4 + q + 4) + pool_floats) * 4 > 64 * 1024) NT = 1;
+    *tiles_per_wg = NT;
+    const int budget = (W == 1 ? 20 : W == 2 ? 40 : W == 4 ? 52 : 64) * 1024;
+    d.stage_in = (NT * 16 * (p_staged + 4 + q + 4) + pool_floats) * 4 <= budget ? 1 : 0;
     if (d.stage_in) p = p_staged;
     d.lds_p = p + 4;  // +4 floats: consecutive positions start 4 banks apart (conflict-free b128 rows)
     d.lds_q = q + 4;
@@ -433,8 +513,15 @@ using namespace pdm;
 // Tuning knob (not part of the reference-facing ABI): force the waves-per-workgroup choice (0 = auto).
 extern "C" int pdm_tune_fused_waves(int w) { const int old = g_fused_waves; g_fused_waves = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; return old; }
 
+extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
+extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = (t == 1 || t == 2) ? t : 0; return old; }
+
 #define FUSED_LAUNCH(KERNEL, W, blocks, lds_bytes, ...)                                                        \
-    hipLaunchKernelGGL((KERNEL<W>), dim3(blocks), dim3(64 * W), lds_bytes, as_stream(stream), __VA_ARGS__)
+    do {                                                                                                       \
+        constexpr int MAXNB = (W <= 2) ? 2 : 4; /* narrow layers: fewer registers, more waves in flight */ \
+        if (NT == 2) hipLaunchKernelGGL((KERNEL<W, 2, MAXNB>), dim3(blocks), dim3(64 * W), lds_bytes, as_stream(stream), __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<W, 1, MAXNB>), dim3(blocks), dim3(64 * W), lds_bytes, as_stream(stream), __VA_ARGS__);        \
+    } while (0)
 
 extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample,
                                 const float *xyz, const float *new_xyz, const float *feat_pm,
@@ -447,8 +534,10 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     PDM_REQUIRE(xyz && new_xyz && idx && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
                 "sa_mlp_fused: null pointer");
     MlpDesc d;
-    int W = 1;
-    int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3, dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, &W);
+    int W = 1, NT = 1;
+    const long long sa_tiles = (long long)b * m * (nsample / 16);
+    int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3,
+                       dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, sa_tiles, &W, &NT);
     if (rc) return rc;
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && out_coff >= 0 && out_coff + cout <= out_stride, PDM_E_BADARG,
                 "sa_mlp_fused: cout=%d coff=%d stride=%d", cout, out_coff, out_stride);
@@ -457,10 +546,12 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
                     (cin % 4 != 0 || (reinterpret_cast<uintptr_t>(feat_pm) & 15) == 0),
                 PDM_E_BADARG, "sa_mlp_fused: out/wpack/bias/feat must be 16-byte aligned, out_stride and out_coff multiples of 4");
     SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout};
-    const size_t lds_bytes = (size_t)(16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
-    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    const long long ncentres = (long long)b * m;
-    const int blocks = (int)(ncentres < 256 * 32 ? ncentres : 256 * 32);
+    const size_t lds_bytes = (size_t)(NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
+    PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    const int tpc = nsample / 16;
+    const long long niter = tpc >= NT ? (long long)b * m : ((long long)b * m + NT / tpc - 1) / (NT / tpc);
+    const long long cap = (long long)256 * g_fused_wg_per_cu;
+    const int blocks = (int)(niter < cap ? niter : cap);
     if (W == 1) FUSED_LAUNCH(sa_mlp_fused_kernel, 1, blocks, lds_bytes, d, a, wpack, bias);
     else if (W == 2) FUSED_LAUNCH(sa_mlp_fused_kernel, 2, blocks, lds_bytes, d, a, wpack, bias);
     else if (W == 4) FUSED_LAUNCH(sa_mlp_fused_kernel, 4, blocks, lds_bytes, d, a, wpack, bias);
@@ -477,8 +568,9 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
     PDM_REQUIRE(known_pm && idx && weight && wpack && bias && out_pm && (c_skip == 0 || skip_pm), PDM_E_BADARG,
                 "fp_mlp_fused: null pointer");
     MlpDesc d;
-    int W = 1;
-    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, &W);
+    int W = 1, NT = 1;
+    const long long ntiles = (long long)b * ((n + 15) / 16);
+    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, ntiles, &W, &NT);
     if (rc) return rc;
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && cout <= out_stride, PDM_E_BADARG, "fp_mlp_fused: cout=%d stride=%d", cout, out_stride);
     PDM_REQUIRE(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
@@ -487,10 +579,11 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
                     (c_skip % 4 != 0 || c_skip == 0 || (reinterpret_cast<uintptr_t>(skip_pm) & 15) == 0),
                 PDM_E_BADARG, "fp_mlp_fused: buffers must be 16-byte aligned and out_stride a multiple of 4");
     FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout};
-    const size_t lds_bytes = (size_t)(16 * (d.lds_p + d.lds_q)) * sizeof(float);
-    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    const long long ntiles = (long long)b * ((n + 15) / 16);
-    const int blocks = (int)(ntiles < 256 * 32 ? ntiles : 256 * 32);
+    const size_t lds_bytes = (size_t)(NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
+    PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    const long long niter = (ntiles + NT - 1) / NT;
+    const long long cap = (long long)256 * g_fused_wg_per_cu;
+    const int blocks = (int)(niter < cap ? niter : cap);
     if (W == 1) FUSED_LAUNCH(fp_mlp_fused_kernel, 1, blocks, lds_bytes, d, a, wpack, bias);
     else if (W == 2) FUSED_LAUNCH(fp_mlp_fused_kernel, 2, blocks, lds_bytes, d, a, wpack, bias);
     else if (W == 4) FUSED_LAUNCH(fp_mlp_fused_kernel, 4, blocks, lds_bytes, d, a, wpack, bias);
