@@ -38,6 +38,7 @@ _SIGNATURES = {
     "pdm_tune_fps_variant": None,
     "pdm_tune_fused_waves": None,
     "pdm_tune_fused_tiles": None,
+    "pdm_tune_fused_groups": None,
     "pdm_tune_fused_wg_per_cu": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],

@@ -33,6 +33,7 @@ struct MlpDesc {
     int woff[FM_MAXL];   // float offsets of each layer's packed weights / bias
     int boff[FM_MAXL];
     int stage_in;        // 1: layer-1 input is gathered once into LDS; 0: re-gathered per output block pair
+    int pool_floats;     // SA: width of the last layer (max-pool combine buffer), FP: 0
     int lds_p, lds_q;    // LDS tile widths (floats per position, incl. +4 pad) of the two ping-pong buffers
 };
 
@@ -252,6 +253,9 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
         const f4 bi = *reinterpret_cast<const f4 *>(bias + 16 * (mb + i) + 4 * g);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = bi;
+#if defined(FUSED_DIAG) && FUSED_DIAG == 1
+        wb[i] = w;  // timing-only: every pass re-reads the same L1-resident weight fragments
+#endif
         an[i] = wb[i][0];
     }
 #pragma unroll
@@ -262,12 +266,25 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
 #pragma unroll
         for (int i = 0; i < NB; ++i) a[i] = an[i];
         if (kb + 1 < nkb) {
+#if defined(FUSED_DIAG) && FUSED_DIAG == 1
+            const size_t o = 0;
+#else
             const size_t o = (size_t)(kb + 1) * 64;
+#endif
+#if !(defined(FUSED_DIAG) && FUSED_DIAG == 2)
 #pragma unroll
             for (int t = 0; t < NT; ++t) bn[t] = in(t, kb + 1);
+#endif
 #pragma unroll
             for (int i = 0; i < NB; ++i) an[i] = wb[i][o];
         }
+#if defined(FUSED_DIAG) && FUSED_DIAG == 3
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t] += a[i] * b[t];  // timing-only: no MFMA
+        continue;
+#endif
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -329,7 +346,7 @@ __device__ __forceinline__ void wg_sync() {
 // (NT*16 positions x lds_p / lds_q floats): layer 1 writes Q, layer 2 writes P, layer 3 writes Q ...; a
 // staged input lives in P.  The layer sequence is unrolled so every descriptor field is read with a
 // constant index (a runtime index into the by-value descriptor would push it to scratch).
-template <int W, int NT, int MAXNB, int L, class In, class Out>
+template <int W, int NT, int MAXNB, int PSW, int L, class In, class Out>
 __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restrict__ wpack,
                                           const float *__restrict__ bias, float *P, float *Q, int lane,
                                           int wave, const In &in, const Out &out) {
@@ -351,10 +368,10 @@ __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restr
         if (last) mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, li, out);
         else mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, li, lo);
     }
-    wg_sync<W>();
+    wg_sync<W * PSW>();
 }
 
-template <int W, int NT, int MAXNB, class In, class Out>
+template <int W, int NT, int MAXNB, int PSW, class In, class Out>
 __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restrict__ wpack,
                                         const float *__restrict__ bias, float *P, float *Q, int lane,
                                         int wave, const In &in, const Out &out) {
@@ -365,22 +382,28 @@ __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restric
         for (int kb = wave; kb < nkb0; kb += W)
 #pragma unroll
             for (int t = 0; t < NT; ++t) *reinterpret_cast<f4 *>(row + t * 16 * d.lds_p + 16 * kb) = in(t, kb);
-        wg_sync<W>();
+        wg_sync<W * PSW>();
     }
-    run_layer<W, NT, MAXNB, 1>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 2) run_layer<W, NT, MAXNB, 2>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 3) run_layer<W, NT, MAXNB, 3>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 4) run_layer<W, NT, MAXNB, 4>(d, wpack, bias, P, Q, lane, wave, in, out);
+    run_layer<W, NT, MAXNB, PSW, 1>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 2) run_layer<W, NT, MAXNB, PSW, 2>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 3) run_layer<W, NT, MAXNB, PSW, 3>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 4) run_layer<W, NT, MAXNB, PSW, 4>(d, wpack, bias, P, Q, lane, wave, in, out);
 }
 
-template <int W, int NT, int MAXNB>
-__global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
-                                                              const float *__restrict__ wpack,
-                                                              const float *__restrict__ bias) {
+// Workgroup = PSW position groups x W channel-split waves.  The W waves of a group share one LDS tile
+// set and split each layer's output blocks; the PSW groups work on different tiles but walk the same
+// (layer, block, K) sequence, so the weight fragments one group pulls from L2 are L1 hits for the others
+// (the workgroup-wide barrier after every layer keeps them together).
+template <int W, int NT, int MAXNB, int PSW>
+__global__ __launch_bounds__(64 * W * PSW) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
+                                                                    const float *__restrict__ wpack,
+                                                                    const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_all % W, grp = wave_all / W;
     const int pos = lane & 15, g = lane >> 4;
-    float *P = lds;
+    const int region = NT * 16 * (d.lds_p + d.lds_q) + d.pool_floats;
+    float *P = lds + grp * region;
     float *Q = P + NT * 16 * d.lds_p;
     float *pool = Q + NT * 16 * d.lds_q;
     const int tpc = a.ns >> 4;  // tiles per centre
@@ -390,7 +413,8 @@ __global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs 
     const int cpu_ = tpc >= NT ? 1 : NT / tpc;          // centres per unit
     const int nsub = tpc >= NT ? (tpc + NT - 1) / NT : 1;
     const long long nunits = (ncentres + cpu_ - 1) / cpu_;
-    for (long long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    for (long long base = (long long)blockIdx.x * PSW; base < nunits; base += (long long)gridDim.x * PSW) {
+        const long long unit = base + grp;  // groups past the end run dead tiles so barriers still match
         for (int sub = 0; sub < nsub; ++sub) {
             Tiles<SaIn, NT> in;
             Tiles<PoolOut, NT> out;
@@ -398,7 +422,7 @@ __global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs 
             for (int t = 0; t < NT; ++t) {
                 const long long ctr_raw = tpc >= NT ? unit : unit * cpu_ + t / tpc;
                 const int tic = tpc >= NT ? sub * NT + t : t % tpc;
-                const bool live = ctr_raw < ncentres && tic < tpc;
+                const bool live = unit < nunits && ctr_raw < ncentres && tic < tpc;
                 const long long ctr = live ? ctr_raw : 0;
                 const int tl = live ? tic : 0;
                 const int b = (int)(ctr / a.m);
@@ -414,29 +438,31 @@ __global__ __launch_bounds__(64 * W) void sa_mlp_fused_kernel(MlpDesc d, SaArgs 
                 out.t[t].cout = a.cout; out.t[t].lane = lane; out.t[t].g = g;
                 out.t[t].first_tile = tic == 0; out.t[t].last_tile = tic == tpc - 1;
             }
-            run_mlp<W, NT, MAXNB>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn, NT>{&in}, TilesOut<PoolOut, NT>{&out});
+            run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn, NT>{&in}, TilesOut<PoolOut, NT>{&out});
         }
     }
 }
 
-template <int W, int NT, int MAXNB>
-__global__ __launch_bounds__(64 * W) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
-                                                              const float *__restrict__ wpack,
-                                                              const float *__restrict__ bias) {
+template <int W, int NT, int MAXNB, int PSW>
+__global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
+                                                                    const float *__restrict__ wpack,
+                                                                    const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_all % W, grp = wave_all / W;
     const int pos = lane & 15, g = lane >> 4;
-    float *P = lds;
+    float *P = lds + grp * (NT * 16 * (d.lds_p + d.lds_q));
     float *Q = P + NT * 16 * d.lds_p;
     const int tps = (a.n + 15) >> 4;  // tiles per sample
     const long long ntiles = (long long)a.b * tps;
     const long long niter = (ntiles + NT - 1) / NT;
-    for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+    for (long long base = (long long)blockIdx.x * PSW; base < niter; base += (long long)gridDim.x * PSW) {
+        const long long it = base + grp;
         Tiles<FpIn, NT> in;
         Tiles<RowOut, NT> out;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const long long tile = it * NT + t;
+            const long long tile = it < niter ? it * NT + t : ntiles;
             const int b = tile < ntiles ? (int)(tile / tps) : 0;
             const int p = (int)(tile - (long long)b * tps) * 16 + pos;
             FpIn &f = in.t[t];
@@ -455,16 +481,17 @@ __global__ __launch_bounds__(64 * W) void fp_mlp_fused_kernel(MlpDesc d, FpArgs 
             out.t[t].orow = f.live ? a.out + q * a.out_stride : nullptr;
             out.t[t].cout = a.cout; out.t[t].g = g;
         }
-        run_mlp<W, NT, MAXNB>(d, wpack, bias, P, Q, lane, wave, TilesIn<FpIn, NT>{&in}, TilesOut<RowOut, NT>{&out});
+        run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, TilesIn<FpIn, NT>{&in}, TilesOut<RowOut, NT>{&out});
     }
 }
 
 static int g_fused_waves = 0;
 static int g_fused_tiles = 0;
+static int g_fused_groups = 0;      // 0 = auto
 static int g_fused_wg_per_cu = 32;  // grid cap = 256 CUs x this many workgroups (grid-stride loop beyond)
 
 static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max, int pool_floats,
-                     long long ntiles, int *waves, int *tiles_per_wg) {
+                     long long ntiles, int *waves, int *tiles_per_wg, int *groups) {
     PDM_REQUIRE(nlayers >= 1 && nlayers <= FM_MAXL, PDM_E_BADARG, "%s: nlayers=%d not in [1,%d]", who, nlayers, FM_MAXL);
     PDM_REQUIRE(dims, PDM_E_BADARG, "%s: null dims", who);
     d.nlayers = nlayers;
@@ -494,7 +521,7 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     const int p_staged = p > d.K[0] ? p : d.K[0];
     // two 16-position tiles per workgroup share every weight fragment (half the A traffic, twice the MFMA
     // work per pass); keep one when the problem has few tiles or the LDS tiles would not fit 64 KB
-    int NT = g_fused_tiles > 0 ? g_fused_tiles : 1;  // 2 measured no faster (more VGPRs, fewer waves)
+    int NT = 1;  // 2 tiles per group measured no faster (more VGPRs, fewer waves); code path kept generic
     (void)ntiles;
     if ((NT * 16 * (p + 4 + q + 4) + pool_floats) * 4 > 64 * 1024) NT = 1;
     *tiles_per_wg = NT;
@@ -503,6 +530,12 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     if (d.stage_in) p = p_staged;
     d.lds_p = p + 4;  // +4 floats: consecutive positions start 4 banks apart (conflict-free b128 rows)
     d.lds_q = q + 4;
+    d.pool_floats = pool_floats;
+    // position-split groups per workgroup: as many as fit 8 waves and 64 KB of LDS
+    const int region_bytes = (NT * 16 * (d.lds_p + d.lds_q) + pool_floats) * 4;
+    int G = g_fused_groups > 0 ? g_fused_groups : 8;
+    while (G > 1 && (G * W > 8 || (long long)G * region_bytes > 64 * 1024 || (long long)G * NT * 4 > ntiles)) G >>= 1;
+    *groups = G;
     return 0;
 }
 
@@ -514,13 +547,30 @@ using namespace pdm;
 extern "C" int pdm_tune_fused_waves(int w) { const int old = g_fused_waves; g_fused_waves = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; return old; }
 
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
-extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = (t == 1 || t == 2) ? t : 0; return old; }
+extern "C" int pdm_tune_fused_groups(int n) { const int old = g_fused_groups; g_fused_groups = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0; return old; }
+extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = t; return old; }  // kept for ABI stability; no effect
 
-#define FUSED_LAUNCH(KERNEL, W, blocks, lds_bytes, ...)                                                        \
+#define FUSED_LAUNCH1(KERNEL, W, G, blocks, lds_bytes, ...)                                                   \
     do {                                                                                                       \
-        constexpr int MAXNB = (W <= 2) ? 2 : 4; /* narrow layers: fewer registers, more waves in flight */ \
-        if (NT == 2) hipLaunchKernelGGL((KERNEL<W, 2, MAXNB>), dim3(blocks), dim3(64 * W), lds_bytes, as_stream(stream), __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<W, 1, MAXNB>), dim3(blocks), dim3(64 * W), lds_bytes, as_stream(stream), __VA_ARGS__);        \
+        constexpr int MAXNB = (W <= 2) ? 2 : 4; /* narrow layers: fewer registers, more waves in flight */     \
+        hipLaunchKernelGGL((KERNEL<W, 1, MAXNB, G>), dim3(blocks), dim3(64 * W * G), lds_bytes,               \
+                           as_stream(stream), __VA_ARGS__);                                                    \
+    } while (0)
+
+// (W channel-split waves, G position groups), W * G <= 8; NT = 1 (NT = 2 measured no faster)
+#define FUSED_DISPATCH(KERNEL, W, G, blocks, lds_bytes, ...)                                                   \
+    do {                                                                                                       \
+        const int key = W * 16 + G;                                                                            \
+        if (key == 1 * 16 + 1) FUSED_LAUNCH1(KERNEL, 1, 1, blocks, lds_bytes, __VA_ARGS__);                    \
+        else if (key == 1 * 16 + 2) FUSED_LAUNCH1(KERNEL, 1, 2, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 1 * 16 + 4) FUSED_LAUNCH1(KERNEL, 1, 4, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 1 * 16 + 8) FUSED_LAUNCH1(KERNEL, 1, 8, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 2 * 16 + 1) FUSED_LAUNCH1(KERNEL, 2, 1, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 2 * 16 + 2) FUSED_LAUNCH1(KERNEL, 2, 2, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 2 * 16 + 4) FUSED_LAUNCH1(KERNEL, 2, 4, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 4 * 16 + 1) FUSED_LAUNCH1(KERNEL, 4, 1, blocks, lds_bytes, __VA_ARGS__);               \
+        else if (key == 4 * 16 + 2) FUSED_LAUNCH1(KERNEL, 4, 2, blocks, lds_bytes, __VA_ARGS__);               \
+        else FUSED_LAUNCH1(KERNEL, 8, 1, blocks, lds_bytes, __VA_ARGS__);                                      \
     } while (0)
 
 extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample,
@@ -534,10 +584,10 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     PDM_REQUIRE(xyz && new_xyz && idx && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
                 "sa_mlp_fused: null pointer");
     MlpDesc d;
-    int W = 1, NT = 1;
+    int W = 1, NT = 1, G = 1;
     const long long sa_tiles = (long long)b * m * (nsample / 16);
     int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3,
-                       dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, sa_tiles, &W, &NT);
+                       dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, sa_tiles, &W, &NT, &G);
     if (rc) return rc;
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && out_coff >= 0 && out_coff + cout <= out_stride, PDM_E_BADARG,
                 "sa_mlp_fused: cout=%d coff=%d stride=%d", cout, out_coff, out_stride);
@@ -546,16 +596,12 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
                     (cin % 4 != 0 || (reinterpret_cast<uintptr_t>(feat_pm) & 15) == 0),
                 PDM_E_BADARG, "sa_mlp_fused: out/wpack/bias/feat must be 16-byte aligned, out_stride and out_coff multiples of 4");
     SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout};
-    const size_t lds_bytes = (size_t)(NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
+    const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    const int tpc = nsample / 16;
-    const long long niter = tpc >= NT ? (long long)b * m : ((long long)b * m + NT / tpc - 1) / (NT / tpc);
+    const long long niter = ((long long)b * m + G - 1) / G;  // NT = 1: one centre per group per step
     const long long cap = (long long)256 * g_fused_wg_per_cu;
     const int blocks = (int)(niter < cap ? niter : cap);
-    if (W == 1) FUSED_LAUNCH(sa_mlp_fused_kernel, 1, blocks, lds_bytes, d, a, wpack, bias);
-    else if (W == 2) FUSED_LAUNCH(sa_mlp_fused_kernel, 2, blocks, lds_bytes, d, a, wpack, bias);
-    else if (W == 4) FUSED_LAUNCH(sa_mlp_fused_kernel, 4, blocks, lds_bytes, d, a, wpack, bias);
-    else FUSED_LAUNCH(sa_mlp_fused_kernel, 8, blocks, lds_bytes, d, a, wpack, bias);
+    FUSED_DISPATCH(sa_mlp_fused_kernel, W, G, blocks, lds_bytes, d, a, wpack, bias);
     return check_launch("sa_mlp_fused");
 }
 
@@ -568,9 +614,9 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
     PDM_REQUIRE(known_pm && idx && weight && wpack && bias && out_pm && (c_skip == 0 || skip_pm), PDM_E_BADARG,
                 "fp_mlp_fused: null pointer");
     MlpDesc d;
-    int W = 1, NT = 1;
+    int W = 1, NT = 1, G = 1;
     const long long ntiles = (long long)b * ((n + 15) / 16);
-    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, ntiles, &W, &NT);
+    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, ntiles, &W, &NT, &G);
     if (rc) return rc;
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && cout <= out_stride, PDM_E_BADARG, "fp_mlp_fused: cout=%d stride=%d", cout, out_stride);
     PDM_REQUIRE(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
@@ -579,14 +625,11 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
                     (c_skip % 4 != 0 || c_skip == 0 || (reinterpret_cast<uintptr_t>(skip_pm) & 15) == 0),
                 PDM_E_BADARG, "fp_mlp_fused: buffers must be 16-byte aligned and out_stride a multiple of 4");
     FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout};
-    const size_t lds_bytes = (size_t)(NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
+    const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    const long long niter = (ntiles + NT - 1) / NT;
+    const long long niter = (ntiles + G - 1) / G;
     const long long cap = (long long)256 * g_fused_wg_per_cu;
     const int blocks = (int)(niter < cap ? niter : cap);
-    if (W == 1) FUSED_LAUNCH(fp_mlp_fused_kernel, 1, blocks, lds_bytes, d, a, wpack, bias);
-    else if (W == 2) FUSED_LAUNCH(fp_mlp_fused_kernel, 2, blocks, lds_bytes, d, a, wpack, bias);
-    else if (W == 4) FUSED_LAUNCH(fp_mlp_fused_kernel, 4, blocks, lds_bytes, d, a, wpack, bias);
-    else FUSED_LAUNCH(fp_mlp_fused_kernel, 8, blocks, lds_bytes, d, a, wpack, bias);
+    FUSED_DISPATCH(fp_mlp_fused_kernel, W, G, blocks, lds_bytes, d, a, wpack, bias);
     return check_launch("fp_mlp_fused");
 }

@@ -22,12 +22,13 @@ def measure():
             ops = {o["op"]: o["ms_per_step"] for o in t.summary(3)}
     return ops.get("pdm_sa_mlp_fused"), ops.get("pdm_fp_mlp_fused")
 
-for tiles in (1, 2):
-    for wg in (32, 8, 4, 3, 2):
-        lib.pdm_tune_fused_tiles(tiles); lib.pdm_tune_fused_wg_per_cu(wg)
-        sa, fp = measure()
-        print(f"tiles={tiles} wg_per_cu={wg:3d}: SA {sa:.3f} ms  FP {fp:.3f} ms")
-for waves in (1, 2, 4, 8):
-    lib.pdm_tune_fused_tiles(1); lib.pdm_tune_fused_wg_per_cu(32); lib.pdm_tune_fused_waves(waves)
+for groups in (0, 1, 2, 4, 8):
+    lib.pdm_tune_fused_groups(groups)
     sa, fp = measure()
-    print(f"forced waves={waves}: SA {sa:.3f} ms  FP {fp:.3f} ms")
+    print(f"groups={groups} (0=auto): SA {sa:.3f} ms  FP {fp:.3f} ms")
+for waves in (1, 2, 4):
+    for groups in (0, 1):
+        lib.pdm_tune_fused_waves(waves); lib.pdm_tune_fused_groups(groups)
+        sa, fp = measure()
+        print(f"forced waves={waves} groups={groups}: SA {sa:.3f} ms  FP {fp:.3f} ms")
+lib.pdm_tune_fused_waves(0); lib.pdm_tune_fused_groups(0)
