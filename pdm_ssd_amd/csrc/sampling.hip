@@ -270,6 +270,341 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(int n, int m, int S, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pruned FPS (exact).  Same selection as fps_reg_kernel / the reference, for 1024 < n <= 1024 * PPT.
+//
+// Observation: adding sample c lowers temp[p] only where d(p, c) < temp[p].  If the points a wave
+// holds lie in a box B and dist^2(c, B) >= the wave's largest temp, none of them changes and the
+// wave's (max, arg-max) of the previous iteration is still valid: the wave skips its distance pass.
+// To make that happen often, the workgroup first sorts its cloud by a 12-bit Morton cell code (LDS
+// counting sort) and deals contiguous runs of 64*PPT sorted points to the waves, so each wave owns a
+// compact region.  After the first few hundred samples only the one to three waves near c compute.
+//
+// Tie order without positional tricks: a point's priority among equal maxima is
+//     rank(k) = bitrev10(k mod 1024) * 16 + k div 1024       (the reference's tree order, see above);
+// each lane sorts its PPT points by rank once, so strict '>' in slot order is right inside a lane;
+// between lanes and between waves ties are rare and resolved explicitly by comparing ranks.
+// The skip test is conservative under rounding: the bound is scaled by (1 - 2^-18), far more than the
+// <= 5 roundings (2^-24 each) that separate it from any computed distance.
+__device__ __forceinline__ int row_min16_i(int v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = row_min16_i(v);
+    asm volatile(
+        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ int fps_rank1024(int k) {  // reference priority for block size 1024
+    return (int)((__brev((unsigned)(k & 1023)) >> 22) << 4) | (k >> 10);
+}
+
+__device__ __forceinline__ unsigned morton12(unsigned cx, unsigned cy, unsigned cz) {
+    unsigned key = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        key |= ((cx >> b) & 1u) << (3 * b) | ((cy >> b) & 1u) << (3 * b + 1) | ((cz >> b) & 1u) << (3 * b + 2);
+    return key;
+}
+
+struct __attribute__((aligned(16))) FpsRecR {
+    float v;
+    int k;
+    float x, y, z;
+    int rank;
+    float pad[2];
+};
+
+template <int BLOCK, int PPT>
+__global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz_all,
+                                                          float *__restrict__ temp_all,
+                                                          int *__restrict__ idx_all) {
+    constexpr int NW = BLOCK / 64, HPT = 4096 / BLOCK;  // waves, histogram bins per thread
+    using vec = float __attribute__((ext_vector_type(PPT)));
+    __shared__ FpsRecR rec[2][16];
+    __shared__ int hist[4096];
+    __shared__ unsigned short order[BLOCK * PPT];  // sorted point indices, then (slot, thread) -> index
+    __shared__ float red[6][NW];
+    __shared__ int wsum[NW];
+    const int b = blockIdx.x;
+    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
+    float *__restrict__ temp = temp_all + (size_t)b * n;
+    int *__restrict__ idxs = idx_all + (size_t)b * m;
+    const int p = threadIdx.x, lane = p & 63, wave = __builtin_amdgcn_readfirstlane(p >> 6);
+
+    // ---- bounding box of the cloud
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = p; k < n; k += BLOCK)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[(size_t)k * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+        if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
+    }
+    for (int c = p; c < 4096; c += BLOCK) hist[c] = 0;
+    __syncthreads();
+    // 12 key bits, dealt one at a time to the axis whose cells are currently longest, most significant first:
+    // the top bits split the long axes, so every run of n/16 sorted points is a compact box even for flat
+    // scenes (a plain 4+4+4 Morton code would slice a 70 x 80 x 4 m cloud into thin z layers).
+    float lo[3], sc[3];
+    int nbits[3] = {0, 0, 0};
+    unsigned seq = 0;  // 2 bits per step: axis of key bit 11, 10, ...
+    {
+        float ext[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = red[a][0], h = red[3 + a][0];
+            for (int w = 1; w < NW; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            if (!(l <= h)) { l = 0.0f; h = 0.0f; }
+            lo[a] = l;
+            ext[a] = h - l;
+            if (!(ext[a] < INFINITY)) ext[a] = 0.0f;
+        }
+        float cur_ext[3] = {ext[0], ext[1], ext[2]};
+        for (int s_ = 0; s_ < 12; ++s_) {
+            int a = cur_ext[0] >= cur_ext[1] ? (cur_ext[0] >= cur_ext[2] ? 0 : 2) : (cur_ext[1] >= cur_ext[2] ? 1 : 2);
+            seq |= (unsigned)a << (2 * s_);
+            nbits[a] += 1;
+            cur_ext[a] *= 0.5f;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sc[a] = ext[a] > 0.0f ? (float)(1 << nbits[a]) / ext[a] : 0.0f;
+    }
+    auto key_of = [&](int k) -> unsigned {
+        unsigned c[3];
+        int used[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t = (xyz[(size_t)k * 3 + a] - lo[a]) * sc[a];
+            c[a] = (unsigned)fminf(fmaxf(t, 0.0f), (float)((1 << nbits[a]) - 1));  // NaN -> 0
+        }
+        unsigned key = 0;
+        for (int s_ = 0; s_ < 12; ++s_) {
+            const int a = (seq >> (2 * s_)) & 3;
+            used[a] += 1;
+            key = (key << 1) | ((c[a] >> (nbits[a] - used[a])) & 1u);
+        }
+        return key;
+    };
+    // ---- counting sort by Morton cell (order inside a cell is irrelevant)
+    for (int k = p; k < n; k += BLOCK) atomicAdd(&hist[key_of(k)], 1);
+    __syncthreads();
+    {
+        int local[HPT], sum = 0;
+#pragma unroll
+        for (int i = 0; i < HPT; ++i) { local[i] = hist[p * HPT + i]; sum += local[i]; }
+        int incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            const int v = lane < NW ? wsum[lane] : 0;
+            int inc = v;
+            for (int off = 1; off < NW; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            if (lane < NW) wsum[lane] = inc - v;
+        }
+        __syncthreads();
+        int run = wsum[wave] + incl - sum;
+#pragma unroll
+        for (int i = 0; i < HPT; ++i) { hist[p * HPT + i] = run; run += local[i]; }
+    }
+    __syncthreads();
+    for (int k = p; k < n; k += BLOCK) order[atomicAdd(&hist[key_of(k)], 1)] = (unsigned short)k;
+    __syncthreads();
+
+    // ---- this lane's PPT points: a contiguous run of the sorted order, then sorted by reference rank
+    vec px, py, pz;   // ext vectors: the winner's coordinates are fetched with a wave-uniform dynamic index
+    float tmp[PPT];   // plain scalars: only ever indexed statically, and updated on one branch of the loop
+    int kk[PPT], rk[PPT];
+#pragma unroll
+    for (int v = 0; v < PPT; ++v) {
+        const int sp = (wave * 64 + lane) * PPT + v;
+        if (sp < n) {
+            const int k = order[sp];
+            kk[v] = k;
+            rk[v] = fps_rank1024(k);
+            px[v] = xyz[(size_t)k * 3 + 0];
+            py[v] = xyz[(size_t)k * 3 + 1];
+            pz[v] = xyz[(size_t)k * 3 + 2];
+            tmp[v] = temp[k];
+        } else {
+            kk[v] = 0xFFFF;
+            rk[v] = 0x7FFFFFFF;  // invalid slots sort last
+            px[v] = py[v] = pz[v] = 0.0f;
+            tmp[v] = -1.0f;      // fminf(d, -1) = -1 never beats a real distance
+        }
+    }
+#pragma unroll
+    for (int k2 = 2; k2 <= PPT; k2 <<= 1)
+#pragma unroll
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const int l = i ^ j2;
+                if (l > i) {
+                    const bool up = (i & k2) == 0;
+                    const bool sw = (rk[i] > rk[l]) == up;
+                    const int tr = rk[i], tk = kk[i];
+                    const float tx = px[i], ty = py[i], tz = pz[i], tt = tmp[i];
+                    rk[i] = sw ? rk[l] : tr; rk[l] = sw ? tr : rk[l];
+                    kk[i] = sw ? kk[l] : tk; kk[l] = sw ? tk : kk[l];
+                    px[i] = sw ? px[l] : tx; px[l] = sw ? tx : px[l];
+                    py[i] = sw ? py[l] : ty; py[l] = sw ? ty : py[l];
+                    pz[i] = sw ? pz[l] : tz; pz[l] = sw ? tz : pz[l];
+                    tmp[i] = sw ? tmp[l] : tt; tmp[l] = sw ? tt : tmp[l];
+                }
+            }
+    __syncthreads();  // every thread has read its run of `order`
+#pragma unroll
+    for (int v = 0; v < PPT; ++v) order[v * BLOCK + p] = (unsigned short)kk[v];
+
+    // ---- box of this wave's points (wave-uniform)
+    float blo[3], bhi[3];
+    {
+        float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int v = 0; v < PPT; ++v)
+            if (kk[v] != 0xFFFF) {
+                l[0] = fminf(l[0], px[v]); h[0] = fmaxf(h[0], px[v]);
+                l[1] = fminf(l[1], py[v]); h[1] = fmaxf(h[1], py[v]);
+                l[2] = fminf(l[2], pz[v]); h[2] = fmaxf(h[2], pz[v]);
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            for (int off = 32; off >= 1; off >>= 1) {
+                l[a] = fminf(l[a], __shfl_xor(l[a], off, 64));
+                h[a] = fmaxf(h[a], __shfl_xor(h[a], off, 64));
+            }
+            blo[a] = readlane_f(l[a], 0);
+            bhi[a] = readlane_f(h[a], 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- iterations
+    FpsPick cur;
+    cur.k = 0;
+    cur.x = xyz[0]; cur.y = xyz[1]; cur.z = xyz[2];
+    if (p == 0) idxs[0] = 0;
+    // cached wave result (uniform)
+    bool have = false;
+    float wmax = -1.0f;
+    FpsPick mine;
+    mine.k = 0; mine.x = mine.y = mine.z = 0.0f;
+    int mrank = 0x7FFFFFFF;
+    for (int j = 1; j < m; ++j) {
+        // lower bound of every computed distance between cur and a point of this wave's box
+        const float gx = fmaxf(0.0f, fmaxf(blo[0] - cur.x, cur.x - bhi[0]));
+        const float gy = fmaxf(0.0f, fmaxf(blo[1] - cur.y, cur.y - bhi[1]));
+        const float gz = fmaxf(0.0f, fmaxf(blo[2] - cur.z, cur.z - bhi[2]));
+        const float lb = (gx * gx + gy * gy + gz * gz) * 0.99999618530273438f;  // 1 - 2^-18
+#if defined(FPS_DIAG) && FPS_DIAG == 2
+        if (!have) {  // timing-only build: distance pass in the first iteration only (results are wrong)
+#else
+        if (!have || !(lb >= wmax)) {  // wave-uniform; also taken when anything is NaN
+#endif
+            have = true;
+#if defined(FPS_DIAG) && FPS_DIAG == 3
+            if (lane == 0 && b == 0) atomicAdd(&temp_all[(size_t)gridDim.x * n - 1 - (j >> 8)], 1.0f);  // diag only
+#endif
+            float best = -1.0f;
+            int bestv = 0;
+            const v2f x1 = {cur.x, cur.x}, y1 = {cur.y, cur.y}, z1 = {cur.z, cur.z};
+#pragma unroll
+            for (int v = 0; v < PPT; v += 2) {
+                const v2f dx = v2f{px[v], px[v + 1]} - x1;
+                const v2f dy = v2f{py[v], py[v + 1]} - y1;
+                const v2f dz = v2f{pz[v], pz[v + 1]} - z1;
+                v2f d = dx * dx;
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                const float d0 = vmin(d.x, tmp[v]);
+                const float d1 = vmin(d.y, tmp[v + 1]);
+                tmp[v] = d0;
+                tmp[v + 1] = d1;
+                bestv = d0 > best ? v : bestv;
+                best = vmax(best, d0);
+                bestv = d1 > best ? v + 1 : bestv;
+                best = vmax(best, d1);
+            }
+            wmax = wave_max(best);
+            const unsigned long long cand = __ballot(best == wmax);
+            int wl = __ffsll((long long)cand) - 1;
+            if (__popcll(cand) > 1) {  // equal maxima in several lanes: the reference order decides
+                const int myk = order[bestv * BLOCK + p];
+                const int r = best == wmax ? fps_rank1024(myk) : 0x7FFFFFFF;
+                const int rmin = wave_min_i(r);
+                wl = __ffsll((long long)__ballot(r == rmin)) - 1;
+            }
+            const int slot = __builtin_amdgcn_readlane(bestv, wl);
+            mine.k = order[slot * BLOCK + wave * 64 + wl];
+            mrank = fps_rank1024(mine.k);
+            mine.x = readlane_f(px[slot], wl);
+            mine.y = readlane_f(py[slot], wl);
+            mine.z = readlane_f(pz[slot], wl);
+        }
+        // exchange: one record per wave, max value then min rank
+        const int buf = j & 1;
+        if (lane == 0) {
+            FpsRecR r;
+            r.v = wmax; r.k = mine.k; r.x = mine.x; r.y = mine.y; r.z = mine.z; r.rank = mrank;
+            rec[buf][wave] = r;
+        }
+        __syncthreads();
+        FpsRecR r = rec[buf][lane & 15];
+        if ((lane & 15) >= NW) r.v = -3.0f;  // fewer than 16 waves: unused record slots never win
+        const float gmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(row_max16(__builtin_bit_cast(int, r.v)), 0));
+        unsigned long long c2 = __ballot(r.v == gmax) & 0xFFFFull;
+        int w = __ffsll((long long)c2) - 1;
+        if (__popcll(c2) > 1) {
+            const int rr = r.v == gmax ? r.rank : 0x7FFFFFFF;
+            const int rmin = __builtin_amdgcn_readlane(row_min16_i(rr), 0);
+            w = __ffsll((long long)(__ballot(rr == rmin) & 0xFFFFull)) - 1;
+        }
+        cur.k = __builtin_amdgcn_readlane(r.k, w);
+        cur.x = readlane_f(r.x, w);
+        cur.y = readlane_f(r.y, w);
+        cur.z = readlane_f(r.z, w);
+        if (p == 0) idxs[j] = cur.k;
+    }
+
+#pragma unroll
+    for (int v = 0; v < PPT; ++v) {
+        const int k = order[v * BLOCK + p];
+        if (k != 0xFFFF) temp[k] = tmp[v];
+    }
+}
+
 __global__ void gather_points_kernel(int c, int n, int m, const float *__restrict__ points,
                                      const int *__restrict__ idx, float *__restrict__ out) {
     const int b = blockIdx.z, ci = blockIdx.y;
@@ -304,8 +639,9 @@ static int ref_block_threads(int n, int *logS) {
 
 using namespace pdm;
 
-// Tuning knob (not part of the reference-facing ABI): 0 = 1024 threads x 16 points, 1 = 512 x 32 for
-// 8192 < n <= 16384.  Both give identical indices.
+// Tuning knob (not part of the reference-facing ABI) for 8192 < n <= 16384: 0 = pruned kernel, 1024 threads
+// x 16 points (default, fastest measured), 3 = pruned, 512 x 32; 1 = 512 x 32 and 2 = 1024 x 16 without pruning.
+// All give identical indices.
 static int g_fps_variant = 0;
 extern "C" int pdm_tune_fps_variant(int v) { const int old = g_fps_variant; g_fps_variant = v; return old; }
 
@@ -337,7 +673,10 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     } else if (per <= 8) {
         FPS_LAUNCH(1024, 8);
     } else if (per <= 16) {
-        if (g_fps_variant == 1) FPS_LAUNCH(512, 32); else FPS_LAUNCH(1024, 16);
+        if (g_fps_variant == 1) FPS_LAUNCH(512, 32);
+        else if (g_fps_variant == 2) FPS_LAUNCH(1024, 16);
+        else if (g_fps_variant == 3) hipLaunchKernelGGL((fps_pruned_kernel<512, 32>), dim3(b), dim3(512), 0, as_stream(stream), n, m, points, temp, idx);
+        else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, points, temp, idx);
     } else {
         hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n,
                            m, S, logS, points, temp, idx);

@@ -349,3 +349,40 @@ def test_three_nn_grid_equals_scan_at_full_size(dev, monkeypatch):
     monkeypatch.setattr(ext, "NN_GRID_MIN_M", 1 << 30)
     d2, i2 = pu.three_nn(xyz, known)
     assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+# ------------------------------------------------------------------ pruned FPS (8192 < N <= 16384)
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_fps_large_variants_index_exact(oracle, dev, variant):
+    """All three kernels for 8192 < N <= 16384 (pruned / 512x32 / 1024x16) give the oracle's indices,
+    including clouds with duplicated points, a lattice (many equal distances) and a ragged N."""
+    from pdm_ssd_amd import _native
+    rng = np.random.default_rng(17)
+    base = clouds("lidar", 1, 8192, seed=91)
+    dup = np.concatenate([base, base[:, ::-1]], axis=1)                      # every point twice
+    lattice = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(16), indexing="ij"), -1)
+    lattice = lattice.reshape(1, -1, 3).astype(np.float32)                   # 16384 grid points
+    ragged = clouds("uniform", 2, 10007, seed=92)
+    same = np.full((1, 9000, 3), 1.5, dtype=np.float32)                      # zero extent
+    old = _native.lib().pdm_tune_fps_variant(variant)
+    try:
+        for xyz, m in ((dup, 700), (lattice, 600), (ragged, 500), (same, 40), (clouds("uniform", 2, 16384, seed=93), 2048)):
+            ref, ref_temp = oracle.furthest_point_sample(xyz, m, return_temp=True)
+            x = T(xyz, dev)
+            got = pu.furthest_point_sample(x, m)
+            np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    finally:
+        _native.lib().pdm_tune_fps_variant(old)
+
+
+def test_fps_pruned_leaves_final_min_distances_in_temp(oracle, dev):
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    xyz = clouds("lidar", 2, 12000, seed=94)
+    ref, ref_temp = oracle.furthest_point_sample(xyz, 300, return_temp=True)
+    x = T(xyz, dev)
+    temp = torch.full((2, 12000), 1e10, device=dev)
+    idx = torch.empty((2, 300), dtype=torch.int32, device=dev)
+    ext.farthest_point_sampling_wrapper(2, 12000, 300, x, temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)

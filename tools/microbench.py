@@ -49,7 +49,7 @@ def main():
         levels.append(pu.gather_operation(levels[-1].transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous())
     print(f"clouds={args.clouds} B={B}")
     if "fps" in ops:
-        for variant in (0, 1):
+        for variant in (0, 3, 1):
             _native.lib().pdm_tune_fps_variant(variant)
             for lv, m in enumerate(npts):
                 x = levels[lv]
