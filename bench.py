@@ -316,6 +316,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * B * args.steps / elapsed
 
+    # HBM traffic per launch from the committed PMC passes of this same command (profiles/r01c_pmc_traffic.json;
+    # rocprofv3 cannot run inside this process): corrected bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))["kernels"]
+    except Exception:
+        pass
+
+    def pmc_traffic(prefix):
+        rows = [v for k, v in pmc.items() if k.startswith(prefix) and v["launches"] > 0]
+        if not rows:
+            return None
+        return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
+
     sa_gf, fp_gf = model_flops(backbone, B, N)
     for o in ops:
         if o["op"] == "pdm_sa_mlp_fused":
@@ -336,7 +350,8 @@ def main():
         ach = per_launch_flop / per_launch_s / 1e12
         roofline = {"bound": "mfma", "kernel": "pdm::sa_mlp_fused_kernel (pdm_sa_mlp_fused)", "achieved": round(ach, 2),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": o["calls_per_step"],
+                    "traffic": pmc_traffic("pdm::sa_mlp_fused_kernel"), "traffic_unit": "HBM bytes per launch (PMC)",
+                    "launches_per_step": o["calls_per_step"],
                     "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop)}
     with torch.no_grad():
         refops, gp = reference_op_section(backbone, points, B)
@@ -344,7 +359,8 @@ def main():
     gp_launch_s = gp["ms_per_step"] / 1e3 / gp["calls_per_step"]
     roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_v4_kernel (pdm_group_points, API-exact operator)",
                     "achieved": round(gp_launch_bytes / gp_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gp_launch_bytes / gp_launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(gp_launch_bytes / gp_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic("pdm::group_points_v4_kernel"),
                     "launches_per_step": gp["calls_per_step"], "avg_launch_us": round(gp_launch_s * 1e6, 2),
                     "alg_bytes_per_launch": int(gp_launch_bytes)}
     fps_op = [o for o in ops if o["op"] == "pdm_furthest_point_sampling"]
