@@ -209,6 +209,60 @@ def cpu_baseline(backbone, neck, N, kind, frames=2):
                       f"{dt:.1f} s wall; the reference itself has no CPU path for these operators"}
 
 
+def train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, device):
+    """Training step (BASELINE config 4): the autograd graph over the HIP operators (fused QueryAndGroup forward,
+    atomic scatter backward kernels), torch modules for the MLPs under bf16 autocast, coordinates and indices in
+    fp32; one gradient all-reduce per step (DDP, single bucket) when world > 1.  The loss is a stand-in (mean
+    square of both outputs): the reference's hybrid head is not part of the hot path."""
+    model = torch.nn.ModuleDict({"backbone": backbone, "neck": neck}).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+
+    class Step(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, pts):
+            bd = {'batch_size': B, 'points': pts, 'points_per_sample_checked': True}
+            bd = self.m["neck"](self.m["backbone"](bd))
+            return bd['point_features'].float().square().mean() + bd['spatial_features'].float().square().mean()
+
+    stepper = Step(model)
+    if world > 1:
+        stepper = torch.nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], bucket_cap_mb=64,
+                                                            gradient_as_bucket_view=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = stepper(points)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    dist_utils.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    dist_utils.barrier()
+    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"train frames/sec ({N}-pt clouds, bs={B}/GPU, bf16 autocast)", "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
+            "config": {"workload": f"configs[3]: train step of PointNet2MSG + PDM neck, bs={B}/GPU x {N} pts, stand-in loss, "
+                                   "AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}"},
+            "final_loss": float(loss.detach())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------- main
 
 def main():
@@ -221,6 +275,9 @@ def main():
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 4 instead: bf16-autocast forward+backward+AdamW step of backbone+neck, "
+                         "DistributedDataParallel gradient all-reduce over RCCL when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
@@ -234,6 +291,8 @@ def main():
     B, N = args.batch, args.points
     backbone, neck = build_models(device)
     _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
+    if args.train:
+        return train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, device)
 
     def step_serial():
         bd = {'batch_size': B, 'points': points, 'points_per_sample_checked': True}
