@@ -521,7 +521,9 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     const int p_staged = p > d.K[0] ? p : d.K[0];
     // two 16-position tiles per workgroup share every weight fragment (half the A traffic, twice the MFMA
     // work per pass); keep one when the problem has few tiles or the LDS tiles would not fit 64 KB
-    int NT = 1;  // 2 tiles per group measured no faster (more VGPRs, fewer waves); code path kept generic
+    // two tiles per group share each weight fragment: measured -5 % on the wide SA layers, +8 % on FP
+    // (heavier input provider), so SA only; knob: 1 forces one tile, 2 forces two where instantiated
+    int NT = (W >= 4 && (g_fused_tiles == 2 || (g_fused_tiles == 0 && pool_floats > 0))) ? 2 : 1;
     (void)ntiles;
     if ((NT * 16 * (p + 4 + q + 4) + pool_floats) * 4 > 64 * 1024) NT = 1;
     *tiles_per_wg = NT;
@@ -533,7 +535,7 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     d.pool_floats = pool_floats;
     // position-split groups per workgroup: as many as fit 8 waves and 64 KB of LDS
     const int region_bytes = (NT * 16 * (d.lds_p + d.lds_q) + pool_floats) * 4;
-    int G = g_fused_groups > 0 ? g_fused_groups : 8;
+    int G = NT == 2 ? 1 : (g_fused_groups > 0 ? g_fused_groups : 8);
     while (G > 1 && (G * W > 8 || (long long)G * region_bytes > 64 * 1024 || (long long)G * NT * 4 > ntiles)) G >>= 1;
     *groups = G;
     return 0;
@@ -553,8 +555,12 @@ extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fu
 #define FUSED_LAUNCH1(KERNEL, W, G, blocks, lds_bytes, ...)                                                   \
     do {                                                                                                       \
         constexpr int MAXNB = (W <= 2) ? 2 : 4; /* narrow layers: fewer registers, more waves in flight */     \
-        hipLaunchKernelGGL((KERNEL<W, 1, MAXNB, G>), dim3(blocks), dim3(64 * W * G), lds_bytes,               \
-                           as_stream(stream), __VA_ARGS__);                                                    \
+        if (NT == 2 && W >= 4 && G == 1) /* experiment: two tiles share each weight fragment */                \
+            hipLaunchKernelGGL((KERNEL<(W >= 4 ? W : 4), 2, 2, 1>), dim3(blocks), dim3(64 * W * G), lds_bytes, \
+                               as_stream(stream), __VA_ARGS__);                                                \
+        else                                                                                                   \
+            hipLaunchKernelGGL((KERNEL<W, 1, MAXNB, G>), dim3(blocks), dim3(64 * W * G), lds_bytes,           \
+                               as_stream(stream), __VA_ARGS__);                                                \
     } while (0)
 
 // (W channel-split waves, G position groups), W * G <= 8; NT = 1 (NT = 2 measured no faster)
@@ -598,7 +604,9 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout};
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    const long long niter = ((long long)b * m + G - 1) / G;  // NT = 1: one centre per group per step
+    const int tpc_ = nsample / 16;
+    const long long units_ = tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
+    const long long niter = (units_ + G - 1) / G;
     const long long cap = (long long)256 * g_fused_wg_per_cu;
     const int blocks = (int)(niter < cap ? niter : cap);
     FUSED_DISPATCH(sa_mlp_fused_kernel, W, G, blocks, lds_bytes, d, a, wpack, bias);
@@ -627,7 +635,7 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
     FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout};
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    const long long niter = (ntiles + G - 1) / G;
+    const long long niter = ((ntiles + NT - 1) / NT + G - 1) / G;
     const long long cap = (long long)256 * g_fused_wg_per_cu;
     const int blocks = (int)(niter < cap ? niter : cap);
     FUSED_DISPATCH(fp_mlp_fused_kernel, W, G, blocks, lds_bytes, d, a, wpack, bias);
