@@ -72,6 +72,13 @@ int pdm_gather_points_grad(void *stream, int b, int c, int n, int npoints, const
 int pdm_furthest_point_sampling(void *stream, int b, int n, int m, const float *points,
                                 float *temp, int *idx);
 
+/* Same operator for large clouds (n > 16384): the cloud is split over ceil(n/16384) cooperating workgroups
+ * that keep their points in registers and exchange one record per iteration through `workspace`
+ * (pdm_furthest_point_sampling_ws_bytes(b, n) bytes, 8-byte aligned, contents irrelevant).  Identical idx/temp. */
+size_t pdm_furthest_point_sampling_ws_bytes(int b, int n);
+int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m, const float *points, float *temp,
+                                   int *idx, void *workspace, size_t workspace_bytes);
+
 /* replaces three_nn_wrapper_fast              interpolate.cpp:18-26 -> interpolate_gpu.cu:16-81
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) squared distances, idx (B,n,3). */
 int pdm_three_nn(void *stream, int b, int n, int m, const float *unknown, const float *known,

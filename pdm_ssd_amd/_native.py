@@ -28,6 +28,7 @@ _SIGNATURES = {
     "pdm_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp],
+    "pdm_furthest_point_sampling_ws": [_i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -45,7 +46,7 @@ _SIGNATURES = {
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,
 }
 EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes",
-           "pdm_three_nn_grid_workspace_bytes"] + list(_SIGNATURES)
+           "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -66,6 +67,8 @@ def lib():
         l.pdm_last_error.restype = ctypes.c_char_p
         l.pdm_ball_query_grid_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
+        l.pdm_furthest_point_sampling_ws_bytes.restype = ctypes.c_size_t
+        l.pdm_furthest_point_sampling_ws_bytes.argtypes = [_i, _i]
         l.pdm_three_nn_grid_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_three_nn_grid_workspace_bytes.argtypes = [_i, _i]
         if l.pdm_abi_version() != ABI_VERSION:

@@ -331,10 +331,17 @@ struct __attribute__((aligned(16))) FpsRecR {
     float pad[2];
 };
 
-template <int BLOCK, int PPT>
-__global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const float *__restrict__ xyz_all,
+// MULTI: a cloud of more than BLOCK*PPT points is split over G workgroups (contiguous index ranges, each
+// register-resident as above); every iteration each workgroup publishes its local winner as six 8-byte
+// {payload, iteration} granules (agent-scope relaxed atomics = sc1 stores/loads, the data-tagged hand-off of
+// the CDNA guide: no flag, no fence) and picks the best of the G records.  All G workgroups of a cloud must be
+// resident together: the host launches at most 256 workgroups at a time.  Every spin is bounded.
+template <int BLOCK, int PPT, bool MULTI>
+__global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, int G,
+                                                          const float *__restrict__ xyz_all,
                                                           float *__restrict__ temp_all,
-                                                          int *__restrict__ idx_all) {
+                                                          int *__restrict__ idx_all,
+                                                          unsigned long long *__restrict__ xch_all) {
     constexpr int NW = BLOCK / 64, HPT = 4096 / BLOCK;  // waves, histogram bins per thread
     using vec = float __attribute__((ext_vector_type(PPT)));
     __shared__ FpsRecR rec[2][16];
@@ -342,11 +349,21 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const f
     __shared__ unsigned short order[BLOCK * PPT];  // sorted point indices, then (slot, thread) -> index
     __shared__ float red[6][NW];
     __shared__ int wsum[NW];
-    const int b = blockIdx.x;
-    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
-    float *__restrict__ temp = temp_all + (size_t)b * n;
+    const int b = MULTI ? blockIdx.x / G : blockIdx.x;
+    const int grp = MULTI ? blockIdx.x - b * G : 0;
+    const int per = MULTI ? (n_total + G - 1) / G : n_total;   // points per workgroup (<= BLOCK*PPT)
+    const int k0 = grp * per;                                   // first global index of this workgroup
+    const int n = max(0, min(per, n_total - k0));               // its point count
+    const int rankQ = (n_total + 1023) >> 10;                   // points per reference thread (block size 1024)
+    const float *__restrict__ xyz0 = xyz_all + (size_t)b * n_total * 3;  // the cloud
+    const float *__restrict__ xyz = xyz0 + (size_t)k0 * 3;               // this workgroup's slice
+    float *__restrict__ temp = temp_all + (size_t)b * n_total + k0;
     int *__restrict__ idxs = idx_all + (size_t)b * m;
     const int p = threadIdx.x, lane = p & 63, wave = __builtin_amdgcn_readfirstlane(p >> 6);
+    auto rank_of = [&](int klocal) -> int {  // reference priority of global index k0 + klocal
+        const int kg = k0 + klocal;
+        return (int)(__brev((unsigned)(kg & 1023)) >> 22) * rankQ + (kg >> 10);
+    };
 
     // ---- bounding box of the cloud
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const f
         if (sp < n) {
             const int k = order[sp];
             kk[v] = k;
-            rk[v] = fps_rank1024(k);
+            rk[v] = rank_of(k);
             px[v] = xyz[(size_t)k * 3 + 0];
             py[v] = xyz[(size_t)k * 3 + 1];
             pz[v] = xyz[(size_t)k * 3 + 2];
@@ -514,8 +531,9 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const f
     // ---- iterations
     FpsPick cur;
     cur.k = 0;
-    cur.x = xyz[0]; cur.y = xyz[1]; cur.z = xyz[2];
-    if (p == 0) idxs[0] = 0;
+    cur.x = xyz0[0]; cur.y = xyz0[1]; cur.z = xyz0[2];
+    if (p == 0 && grp == 0) idxs[0] = 0;
+    __shared__ float fin[8];
     // cached wave result (uniform)
     bool have = false;
     float wmax = -1.0f;
@@ -562,13 +580,13 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const f
             int wl = __ffsll((long long)cand) - 1;
             if (__popcll(cand) > 1) {  // equal maxima in several lanes: the reference order decides
                 const int myk = order[bestv * BLOCK + p];
-                const int r = best == wmax ? fps_rank1024(myk) : 0x7FFFFFFF;
+                const int r = best == wmax ? rank_of(myk) : 0x7FFFFFFF;
                 const int rmin = wave_min_i(r);
                 wl = __ffsll((long long)__ballot(r == rmin)) - 1;
             }
             const int slot = __builtin_amdgcn_readlane(bestv, wl);
             mine.k = order[slot * BLOCK + wave * 64 + wl];
-            mrank = fps_rank1024(mine.k);
+            mrank = rank_of(mine.k);
             mine.x = readlane_f(px[slot], wl);
             mine.y = readlane_f(py[slot], wl);
             mine.z = readlane_f(pz[slot], wl);
@@ -591,11 +609,52 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n, int m, const f
             const int rmin = __builtin_amdgcn_readlane(row_min16_i(rr), 0);
             w = __ffsll((long long)(__ballot(rr == rmin) & 0xFFFFull)) - 1;
         }
-        cur.k = __builtin_amdgcn_readlane(r.k, w);
+        cur.k = __builtin_amdgcn_readlane(r.k, w) + k0;  // global index
         cur.x = readlane_f(r.x, w);
         cur.y = readlane_f(r.y, w);
         cur.z = readlane_f(r.z, w);
-        if (p == 0) idxs[j] = cur.k;
+        if (MULTI) {
+            const int crank = __builtin_amdgcn_readlane(r.rank, w);
+            unsigned long long *slot = xch_all + ((size_t)b * 2 + (j & 1)) * (size_t)G * 6;
+            if (wave == 0) {
+                if (lane < 6) {
+                    const unsigned payload = lane == 0 ? __float_as_uint(n > 0 ? gmax : -1.0f)
+                                           : lane == 1 ? (unsigned)cur.k
+                                           : lane == 2 ? __float_as_uint(cur.x)
+                                           : lane == 3 ? __float_as_uint(cur.y)
+                                           : lane == 4 ? __float_as_uint(cur.z) : (unsigned)crank;
+                    __hip_atomic_store(slot + grp * 6 + lane, ((unsigned long long)(unsigned)j << 32) | payload,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                unsigned got = 0;
+                if (lane < 6 * G) {
+                    for (int spin = 0; spin < (1 << 16); ++spin) {  // bounded: a lost peer ends the call, not the GPU
+                        const unsigned long long v = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        got = (unsigned)v;
+                        if ((unsigned)(v >> 32) == (unsigned)j) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                // group q's record sits in lanes 6q .. 6q+5; pick max value, then min rank
+                float bv = -2.0f; int bq = 0, br = 0x7FFFFFFF;
+                for (int q = 0; q < G; ++q) {
+                    const float v = __uint_as_float(__builtin_amdgcn_readlane((int)got, q * 6));
+                    const int rr = __builtin_amdgcn_readlane((int)got, q * 6 + 5);
+                    if (v > bv || (v == bv && rr < br)) { bv = v; bq = q; br = rr; }
+                }
+                if (lane == 0) {
+                    fin[0] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got, bq * 6 + 1));
+                    fin[1] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got, bq * 6 + 2));
+                    fin[2] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got, bq * 6 + 3));
+                    fin[3] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got, bq * 6 + 4));
+                }
+            }
+            __syncthreads();
+            cur.k = (int)__float_as_uint(fin[0]);
+            cur.x = fin[1]; cur.y = fin[2]; cur.z = fin[3];
+            __syncthreads();  // fin is rewritten next iteration
+        }
+        if (p == 0 && grp == 0) idxs[j] = cur.k;
     }
 
 #pragma unroll
@@ -675,13 +734,50 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     } else if (per <= 16) {
         if (g_fps_variant == 1) FPS_LAUNCH(512, 32);
         else if (g_fps_variant == 2) FPS_LAUNCH(1024, 16);
-        else if (g_fps_variant == 3) hipLaunchKernelGGL((fps_pruned_kernel<512, 32>), dim3(b), dim3(512), 0, as_stream(stream), n, m, points, temp, idx);
-        else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, points, temp, idx);
+        else if (g_fps_variant == 3) hipLaunchKernelGGL((fps_pruned_kernel<512, 32, false>), dim3(b), dim3(512), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr);
+        else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n,
                            m, S, logS, points, temp, idx);
     }
     return check_launch("furthest_point_sampling");
+}
+
+// Large clouds (n > 16384): G = ceil(n / 16384) cooperating workgroups per cloud, exchange slots in the
+// caller's workspace.  Same indices as pdm_furthest_point_sampling.
+extern "C" size_t pdm_furthest_point_sampling_ws_bytes(int b, int n) {
+    if (b <= 0 || n <= 16384) return 0;
+    const int G = (n + 16383) / 16384;
+    return (size_t)b * 2 * G * 6 * sizeof(unsigned long long);
+}
+
+extern "C" int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m, const float *points,
+                                              float *temp, int *idx, void *workspace, size_t workspace_bytes) {
+    const int G = (n + 16383) / 16384;
+    if (n <= 16384 || G > 8 || b <= 0 || m <= 0)  // small clouds and clouds beyond 131072 points: single-workgroup kernels
+        return pdm_furthest_point_sampling(stream, b, n, m, points, temp, idx);
+    PDM_REQUIRE(points && temp && idx && workspace, PDM_E_BADARG, "fps_ws: null pointer");
+    PDM_REQUIRE(workspace_bytes >= pdm_furthest_point_sampling_ws_bytes(b, n) &&
+                    (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                PDM_E_BADARG, "fps_ws: workspace of %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
+                pdm_furthest_point_sampling_ws_bytes(b, n));
+    // stale tags from an earlier use of the workspace must not look like iteration numbers
+    hipError_t e = hipMemsetAsync(workspace, 0, pdm_furthest_point_sampling_ws_bytes(b, n), as_stream(stream));
+    if (e != hipSuccess) {
+        set_error("fps_ws: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    // all G workgroups of a cloud must be co-resident (they wait for each other): <= 256 workgroups per launch
+    const int chunk = 256 / G;
+    for (int b0 = 0; b0 < b; b0 += chunk) {
+        const int nb = b - b0 < chunk ? b - b0 : chunk;
+        hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, true>), dim3(nb * G), dim3(1024), 0, as_stream(stream), n, m, G,
+                           points + (size_t)b0 * n * 3, temp + (size_t)b0 * n, idx + (size_t)b0 * m,
+                           reinterpret_cast<unsigned long long *>(workspace) + (size_t)b0 * 2 * G * 6);
+        int rc = check_launch("furthest_point_sampling_ws");
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int pdm_gather_points(void *stream, int b, int c, int n, int npoints,

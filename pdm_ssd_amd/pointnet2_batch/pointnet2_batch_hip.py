@@ -101,6 +101,12 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     _check("points", points, torch.float32); _check("temp", temp, torch.float32); _check("idx", idx, torch.int32)
     _numel_at_least("points", points, b * n * 3); _numel_at_least("temp", temp, b * n)
     _numel_at_least("idx", idx, b * m)
+    if n > 16384 and b > 0 and m > 0:
+        nbytes = _native.lib().pdm_furthest_point_sampling_ws_bytes(b, n)
+        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=points.device)
+        _run("pdm_furthest_point_sampling_ws", points, b, n, m, points.data_ptr(), temp.data_ptr(), idx.data_ptr(),
+             ws.data_ptr(), nbytes)
+        return 1
     _run("pdm_furthest_point_sampling", points, b, n, m, points.data_ptr(), temp.data_ptr(), idx.data_ptr())
     return 1
 

@@ -386,3 +386,32 @@ def test_fps_pruned_leaves_final_min_distances_in_temp(oracle, dev):
     ext.farthest_point_sampling_wrapper(2, 12000, 300, x, temp, idx)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref)
     np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+
+
+# ------------------------------------------------------------------ multi-workgroup FPS (N > 16384)
+
+@pytest.mark.parametrize("N,m", [(20000, 300), (65536, 400), (40001, 257)])
+def test_fps_multi_workgroup_index_exact(oracle, dev, N, m):
+    rng = np.random.default_rng(N)
+    xyz = clouds("lidar", 2, N, seed=101)
+    xyz[1, N // 2:] = xyz[1, :N - N // 2]      # second cloud: duplicates that straddle the workgroup split
+    ref, ref_temp = oracle.furthest_point_sample(xyz, m, return_temp=True)
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    x = T(xyz, dev)
+    temp = torch.full((2, N), 1e10, device=dev)
+    idx = torch.empty((2, m), dtype=torch.int32, device=dev)
+    ext.farthest_point_sampling_wrapper(2, N, m, x, temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(temp.cpu().numpy(), ref_temp)
+
+
+def test_fps_multi_workgroup_equals_stream_kernel(dev):
+    """The API-exact entry point (no workspace) takes the single-workgroup streaming kernel; same answer."""
+    from pdm_ssd_amd import _native
+    xyz = T(clouds("uniform", 1, 30000, seed=103), dev)
+    a = pu.furthest_point_sample(xyz, 200)
+    temp = torch.full((1, 30000), 1e10, device=dev)
+    idx = torch.empty((1, 200), dtype=torch.int32, device=dev)
+    _native.call("pdm_furthest_point_sampling", torch.cuda.current_stream().cuda_stream, 1, 30000, 200,
+                 xyz.data_ptr(), temp.data_ptr(), idx.data_ptr())
+    assert torch.equal(a, idx)
