@@ -73,7 +73,7 @@ def algorithmic_bytes(name, a):
     if name == "pdm_gather_points":
         b, c, n, m = a[:4]
         return b * (4 * m + 4 * c * n + 4 * c * m)
-    if name == "pdm_furthest_point_sampling":
+    if name in ("pdm_furthest_point_sampling", "pdm_furthest_point_sampling_ws"):
         b, n, m = a[:3]
         return b * (12 * n + 4 * m)
     if name in ("pdm_three_nn", "pdm_three_nn_grid"):
@@ -422,11 +422,12 @@ def main():
                     "traffic": pmc_traffic("pdm::group_points_v4_kernel"),
                     "launches_per_step": gp["calls_per_step"], "avg_launch_us": round(gp_launch_s * 1e6, 2),
                     "alg_bytes_per_launch": int(gp_launch_bytes)}
-    fps_op = [o for o in ops if o["op"] == "pdm_furthest_point_sampling"]
-    if fps_op:
-        iters = B * 0 + sum(m.npoint - 1 for m in backbone.SA_modules)
-        fps_op[0]["serial_iterations_per_step"] = iters
-        fps_op[0]["us_per_iteration"] = round(fps_op[0]["ms_per_step"] * 1e3 / iters, 3)
+    fps_ops = [o for o in ops if o["op"].startswith("pdm_furthest_point_sampling")]
+    if fps_ops:
+        iters = sum(m.npoint - 1 for m in backbone.SA_modules)
+        fps_ms = sum(o["ms_per_step"] for o in fps_ops)
+        fps_ops[0]["fps_chain"] = {"serial_iterations_per_step": iters, "ms_per_step": round(fps_ms, 4),
+                                   "us_per_iteration": round(fps_ms * 1e3 / iters, 3)}
 
     cpu = None
     if not args.no_cpu_baseline:
