@@ -167,69 +167,114 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
     const float radius2 = radius * radius;  // ball_query_gpu.cu:29
     const float absr = fabsf(radius);
 
-    const int j = blockIdx.x * BQG_QWAVES + wave;
-    if (j >= m) return;  // whole wave; no block-level barrier below
-    const float *c3 = new_xyz + ((size_t)b * m + j) * 3;
-    const float cx = c3[0], cy = c3[1], cz = c3[2];
-    const float rx = search_halfwidth(cx, absr), ry = search_halfwidth(cy, absr), rz = search_halfwidth(cz, absr);
-    const int x0 = cell_of(cx - rx, minx, inv_h, gx), x1 = cell_of(cx + rx, minx, inv_h, gx);
-    const int y0 = cell_of(cy - ry, miny, inv_h, gy), y1 = cell_of(cy + ry, miny, inv_h, gy);
-    const int z0 = cell_of(cz - rz, minz, inv_h, gz), z1 = cell_of(cz + rz, minz, inv_h, gz);
+    __shared__ int s_pre[BQG_QWAVES][65];
+    __shared__ int s_beg[BQG_QWAVES][64];
+    // a wave walks centres j, j + stride, ...: the bitmap is cleared once per wave and left clean by every centre
+    for (int j = blockIdx.x * BQG_QWAVES + wave; j < m; j += gridDim.x * BQG_QWAVES) {
+        const float *c3 = new_xyz + ((size_t)b * m + j) * 3;
+        const float cx = c3[0], cy = c3[1], cz = c3[2];
+        const float rx = search_halfwidth(cx, absr), ry = search_halfwidth(cy, absr), rz = search_halfwidth(cz, absr);
+        const int x0 = cell_of(cx - rx, minx, inv_h, gx), x1 = cell_of(cx + rx, minx, inv_h, gx);
+        const int y0 = cell_of(cy - ry, miny, inv_h, gy), y1 = cell_of(cy + ry, miny, inv_h, gy);
+        const int z0 = cell_of(cz - rz, minz, inv_h, gz), z1 = cell_of(cz + rz, minz, inv_h, gz);
+        int *out = idx + ((size_t)b * m + j) * nsample;
 
-    int hits = 0;  // wave-uniform
-    for (int z = z0; z <= z1; ++z) {
-        for (int y = y0; y <= y1; ++y) {
-            const int base = (z * gy + y) * gx;
-            const int s = cell_start[base + x0], e = cell_start[base + x1 + 1];
-            for (int p0 = s; p0 < e; p0 += 64) {  // wave-uniform trip count
-                const int p = p0 + lane;
+        // The (z, y) rows of the search box are x-contiguous runs of the sorted array.  All run bounds are
+        // fetched at once (lane r = row r) and the candidates of all runs are numbered consecutively.
+        const int ny = y1 - y0 + 1;
+        const int nrows = ny * (z1 - z0 + 1);
+        int hits = 0;          // wave-uniform
+        bool used_bitmap = false;
+        for (int r0 = 0; r0 < nrows; r0 += 64) {  // one pass unless the box spans more than 64 rows
+            const int r = r0 + lane;
+            int beg = 0, cntr = 0;
+            if (r < nrows) {
+                const int base = ((z0 + r / ny) * gy + (y0 + r % ny)) * gx;
+                beg = cell_start[base + x0];
+                cntr = cell_start[base + x1 + 1] - beg;
+            }
+            int incl = cntr;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (total == 0) continue;  // wave-uniform
+            s_pre[wave][lane + 1] = incl;
+            s_beg[wave][lane] = beg;
+            if (lane == 0) s_pre[wave][0] = 0;
+            __builtin_amdgcn_wave_barrier();
+            const int rows_here = min(64, nrows - r0);
+            const bool single = nrows <= 64 && total <= 64;  // every candidate of this centre sits in one lane
+            for (int t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count
+                const int t = t0 + lane;
                 bool hit = false;
-                int k = 0;
-                if (p < e) {
-                    const float4 q = sorted[p];
+                int k = 0x7FFFFFFF;
+                if (t < total) {
+                    int row = 0;
+                    while (row + 1 < rows_here && t >= s_pre[wave][row + 1]) ++row;
+                    const float4 q = sorted[s_beg[wave][row] + (t - s_pre[wave][row])];
                     const float d2 = sqdist(cx - q.x, cy - q.y, cz - q.z);
                     hit = d2 < radius2;
-                    k = __float_as_int(q.w);
+                    if (hit) k = __float_as_int(q.w);
                 }
-                if (hit) atomicOr(&bm[k >> 5], 1u << (k & 31));
-                hits += __popcll(__ballot(hit));
+                const unsigned long long hm = __ballot(hit);
+                if (single) {
+                    // fast path, registers only: a hit's output slot is the number of hits with a smaller index
+                    hits = __popcll(hm);
+                    if (hits > 0) {
+                        int pos = 0, kmin = 0x7FFFFFFF;
+                        for (unsigned long long mrest = hm; mrest != 0ull; mrest &= mrest - 1ull) {
+                            const int other = __builtin_amdgcn_readlane(k, __ffsll((long long)mrest) - 1);
+                            pos += other < k ? 1 : 0;
+                            kmin = min(kmin, other);
+                        }
+                        if (hit && pos < nsample) out[pos] = k;
+                        for (int l = hits + lane; l < nsample; l += 64) out[l] = kmin;  // ball_query_gpu.cu:41-45
+                    }
+                } else {
+                    if (hit) atomicOr(&bm[k >> 5], 1u << (k & 31));
+                    hits += __popcll(hm);
+                    used_bitmap = true;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-    }
-    if (hits == 0) return;  // row stays as the caller zero-filled it (pointnet2_utils.py:218)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // LDS atomics of this wave are done before it reads them back
+        if (!used_bitmap || hits == 0) continue;  // empty ball: row stays as the caller zero-filled it (pointnet2_utils.py:218)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // LDS atomics of this wave are done before it reads them back
 
-    // lane owns bitmap words [lane*wpl, (lane+1)*wpl) = indices [lane*wpl*32, ...): ascending with lane
-    unsigned int *mine = bm + lane * wpl;
-    int cnt = 0;
-    for (int w = 0; w < wpl; ++w) cnt += __popc(mine[w]);
-    int incl = cnt;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    int pos = incl - cnt;  // hits in lower lanes
-    int *out = idx + ((size_t)b * m + j) * nsample;
-    int first_local = -1;
-    if (cnt > 0) {
-        for (int w = 0; w < wpl; ++w) {
-            unsigned int bits = mine[w];
-            if (bits == 0u) continue;
-            mine[w] = 0u;  // leave the bitmap clean for the next launch-resident centre
-            if (first_local < 0) first_local = (lane * wpl + w) * 32 + (__ffs(bits) - 1);
-            while (bits != 0u && pos < nsample) {
-                const int bit = __ffs(bits) - 1;
-                bits &= bits - 1u;
-                out[pos++] = (lane * wpl + w) * 32 + bit;
+        // general path: lane owns bitmap words [lane*wpl, (lane+1)*wpl) = indices ascending with lane
+        unsigned int *mine = bm + lane * wpl;
+        int cnt = 0;
+        for (int w = 0; w < wpl; ++w) cnt += __popc(mine[w]);
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        int pos = incl - cnt;  // hits in lower lanes
+        int first_local = -1;
+        if (cnt > 0) {
+            for (int w = 0; w < wpl; ++w) {
+                unsigned int bits = mine[w];
+                if (bits == 0u) continue;
+                mine[w] = 0u;  // leave the bitmap clean for the next centre
+                if (first_local < 0) first_local = (lane * wpl + w) * 32 + (__ffs(bits) - 1);
+                while (bits != 0u && pos < nsample) {
+                    const int bit = __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    out[pos++] = (lane * wpl + w) * 32 + bit;
+                }
             }
         }
+        // slots beyond the hit count hold the first hit (ball_query_gpu.cu:41-45)
+        const unsigned long long have = __ballot(cnt > 0);
+        const int fl = __ffsll((long long)have) - 1;
+        const int first = __shfl(first_local, fl, 64);
+        for (int l = hits + lane; l < nsample; l += 64) out[l] = first;
+        __builtin_amdgcn_wave_barrier();
     }
-    // slots beyond the hit count hold the first hit (ball_query_gpu.cu:41-45)
-    const unsigned long long have = __ballot(cnt > 0);
-    const int fl = __ffsll((long long)have) - 1;
-    const int first = __shfl(first_local, fl, 64);
-    for (int l = hits + lane; l < nsample; l += 64) out[l] = first;
 }
 
 int launch_grid_build(hipStream_t stream, int b, int n, float radius, int max_cells, const float *xyz,
@@ -266,7 +311,9 @@ extern "C" int pdm_ball_query_grid(void *stream, int b, int n, int m, float radi
     const GridWs ws = grid_carve(workspace, b, n);
     int rc = launch_grid_build(as_stream(stream), b, n, radius, BQG_CAP, xyz, ws);
     if (rc) return rc;
-    dim3 grid(divup(m, BQG_QWAVES), b);
+    const int per_sample = divup(m, BQG_QWAVES);
+    const int cap = (256 * 16 + b - 1) / b;  // about 16 four-wave workgroups per CU in total; waves loop beyond that
+    dim3 grid(per_sample < cap ? per_sample : cap, b);
     hipLaunchKernelGGL(bq_grid_query_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius,
                        nsample, wpl, new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
     return check_launch("ball_query_grid(query)");
