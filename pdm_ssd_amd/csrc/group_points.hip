@@ -118,6 +118,80 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_scalar_kernel(
     }
 }
 
+// LDS-staged forms.  With real (non-repeating) ball-query indices the direct kernel above is bound by the
+// vector L1's line rate: a wave gather of 64 random 4-byte elements touches up to 64 cache lines (measured
+// 1.9 TB/s at C=96, N=4096 with random indices vs 4.8 TB/s with the padded indices of sparse clouds).  Here a
+// workgroup first copies its source rows into LDS with coalesced 16-byte loads (a (b,c) row is N floats) and
+// gathers from there: LDS serves 64 random dwords in a few cycles.  The backward pass accumulates each row in
+// LDS (ds_add_f32) and writes it once: no global atomics.
+constexpr int GPL_THREADS = 256;
+
+__global__ __launch_bounds__(GPL_THREADS) void group_points_lds_kernel(
+    int c, int n, long long L, int rows_per_wg, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out) {
+    extern __shared__ float rows[];  // rows_per_wg x n
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * rows_per_wg;
+    const int nr = min(rows_per_wg, c - c0);
+    const float *__restrict__ src = points + ((size_t)b * c + c0) * n;
+    const long long tot = (long long)nr * n;
+    if ((tot & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        for (long long i = (long long)threadIdx.x * 4; i < tot; i += GPL_THREADS * 4)
+            *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+    } else {
+        for (long long i = threadIdx.x; i < tot; i += GPL_THREADS) rows[i] = src[i];
+    }
+    __syncthreads();
+    const int *__restrict__ ib = idx + (size_t)b * L;
+    float *__restrict__ ob = out + ((size_t)b * c + c0) * L;
+    if ((L & 3) == 0 && (reinterpret_cast<uintptr_t>(ib) & 15) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15) == 0) {
+        for (long long q = threadIdx.x; q < L / 4; q += GPL_THREADS) {
+            const int4 id = *reinterpret_cast<const int4 *>(ib + q * 4);
+            for (int r = 0; r < nr; ++r) {
+                const float *row = rows + (size_t)r * n;
+                float4 v;
+                v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
+                *reinterpret_cast<float4 *>(ob + (size_t)r * L + q * 4) = v;
+            }
+        }
+    } else {
+        for (long long l = threadIdx.x; l < L; l += GPL_THREADS) {
+            const int id = ib[l];
+            for (int r = 0; r < nr; ++r) ob[(size_t)r * L + l] = rows[(size_t)r * n + id];
+        }
+    }
+}
+
+__global__ __launch_bounds__(GPL_THREADS) void group_points_grad_lds_kernel(
+    int c, int n, long long L, int rows_per_wg, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points) {
+    extern __shared__ float rows[];  // rows_per_wg x n accumulators
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * rows_per_wg;
+    const int nr = min(rows_per_wg, c - c0);
+    const long long tot = (long long)nr * n;
+    for (long long i = threadIdx.x; i < tot; i += GPL_THREADS) rows[i] = 0.0f;
+    __syncthreads();
+    const int *__restrict__ ib = idx + (size_t)b * L;
+    const float *__restrict__ gb = grad_out + ((size_t)b * c + c0) * L;
+    for (long long l = threadIdx.x; l < L; l += GPL_THREADS) {
+        const int id = ib[l];
+        for (int r = 0; r < nr; ++r) atomicAdd(&rows[(size_t)r * n + id], gb[(size_t)r * L + l]);
+    }
+    __syncthreads();
+    float *__restrict__ dst = grad_points + ((size_t)b * c + c0) * n;
+    for (long long i = threadIdx.x; i < tot; i += GPL_THREADS) dst[i] += rows[i];  // caller-zeroed, accumulated
+}
+
+// rows of n floats per workgroup: up to `budget` bytes of LDS (several workgroups per CU overlap one's staging
+// with another's streaming), at most 8 (index registers reused across them); 0 = a row does not fit 64 KB
+static inline int lds_rows_per_wg(int n, int c, size_t budget) {
+    if (n <= 0 || (size_t)n * sizeof(float) > 64 * 1024) return 0;
+    int r = (int)(budget / ((size_t)n * sizeof(float)));
+    r = r < 1 ? 1 : r > 8 ? 8 : r;
+    return r > c ? c : r;
+}
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace pdm
@@ -132,6 +206,14 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
     if (b == 0 || c == 0 || L == 0) return 0;
     PDM_REQUIRE(points && idx && out, PDM_E_BADARG, "group_points: null pointer");
     PDM_REQUIRE(b <= 65535 && divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_points: b=%d c=%d exceed grid", b, c);
+    const int rpw = lds_rows_per_wg(n, c, 32 * 1024);
+    // LDS staging pays when a row is re-used by many outputs and there are enough (b, c) rows to fill the chip
+    if (rpw > 0 && L >= 4 * n && (long long)b * divup(c, rpw) >= 512) {
+        dim3 grid(divup(c, rpw), b);
+        hipLaunchKernelGGL(group_points_lds_kernel, grid, dim3(GPL_THREADS), (size_t)rpw * n * sizeof(float),
+                           as_stream(stream), c, n, L, rpw, points, idx, out);
+        return check_launch("group_points");
+    }
     if (L % 4 == 0 && aligned16(idx) && aligned16(out)) {
         dim3 grid(divup(L / 4, GP_THREADS), divup(c, GP_CG), b);
         hipLaunchKernelGGL(group_points_v4_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n,
@@ -152,6 +234,13 @@ extern "C" int pdm_group_points_grad(void *stream, int b, int c, int n, int npoi
     if (b == 0 || c == 0 || L == 0) return 0;
     PDM_REQUIRE(grad_out && idx && grad_points, PDM_E_BADARG, "group_points_grad: null pointer");
     PDM_REQUIRE(b <= 65535 && divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_points_grad: exceeds grid");
+    const int rpw = lds_rows_per_wg(n, c, 32 * 1024);
+    if (rpw > 0 && L >= n && (long long)b * divup(c, rpw) >= 256) {
+        dim3 grid_l(divup(c, rpw), b);
+        hipLaunchKernelGGL(group_points_grad_lds_kernel, grid_l, dim3(GPL_THREADS), (size_t)rpw * n * sizeof(float),
+                           as_stream(stream), c, n, L, rpw, grad_out, idx, grad_points);
+        return check_launch("group_points_grad");
+    }
     dim3 grid(divup(L, GP_THREADS), divup(c, GP_CG), b);
     hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n, L,
                        grad_out, idx, grad_points);
