@@ -253,7 +253,7 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
         const f4 bi = *reinterpret_cast<const f4 *>(bias + 16 * (mb + i) + 4 * g);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = bi;
-#if defined(FUSED_DIAG) && FUSED_DIAG == 1
+#if defined(FUSED_DIAG) && (FUSED_DIAG == 1 || FUSED_DIAG == 4)
         wb[i] = w;  // timing-only: every pass re-reads the same L1-resident weight fragments
 #endif
         an[i] = wb[i][0];
@@ -266,12 +266,12 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
 #pragma unroll
         for (int i = 0; i < NB; ++i) a[i] = an[i];
         if (kb + 1 < nkb) {
-#if defined(FUSED_DIAG) && FUSED_DIAG == 1
+#if defined(FUSED_DIAG) && (FUSED_DIAG == 1 || FUSED_DIAG == 4)
             const size_t o = 0;
 #else
             const size_t o = (size_t)(kb + 1) * 64;
 #endif
-#if !(defined(FUSED_DIAG) && FUSED_DIAG == 2)
+#if !(defined(FUSED_DIAG) && (FUSED_DIAG == 2 || FUSED_DIAG == 4))
 #pragma unroll
             for (int t = 0; t < NT; ++t) bn[t] = in(t, kb + 1);
 #endif

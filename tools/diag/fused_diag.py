@@ -1,6 +1,6 @@
 """Timing-only diagnostic builds of the fused MLP kernels (results wrong by construction):
 diag1 = weights always the same L1-resident fragments; diag2 = no LDS/global B refetch in the K loop;
-diag3 = no MFMA (VALU stand-in).  Runs the bench model's backbone with the product library swapped."""
+diag3 = no MFMA (VALU stand-in); diag4 = diag1 + diag2 (matrix work with no operand traffic in the K loop).  Runs the bench model's backbone with the product library swapped."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -25,7 +25,7 @@ def measure():
             return {o["op"]: o["ms_per_step"] for o in t.summary(3)}
 
 print("full ", {k: v for k, v in measure().items() if "fused" in k})
-for d in (1, 2, 3):
+for d in (1, 2, 3, 4):
     lib = ctypes.CDLL(os.path.join(here, f"libfused_diag{d}.so"))
     def call(name, stream, *args, _lib=lib):
         if "mlp_fused" in name:
