@@ -162,6 +162,16 @@ int pdm_scatter_bev(void *stream, int B, int P, int C, int degree, const float *
 int pdm_bev_normalize(void *stream, int B, int C, int W, int H, int D, int layout, float eps,
                       float *grid, const float *wsum);
 
+/* Gather form of pdm_scatter_bev (+ pdm_bev_normalize when normalize != 0) for layout 1: every cell of
+ * grid (B,H,W,C*D) and wsum (B,H,W,D) is WRITTEN (no zero-fill by the caller), without atomics and in a fixed
+ * summation order (ascending point index), so the result is bitwise reproducible.  workspace >=
+ * pdm_gather_bev_workspace_bytes(...) bytes. */
+size_t pdm_gather_bev_workspace_bytes(int B, int P, int W, int H, int kx, int ky);
+int pdm_gather_bev(void *stream, int B, int P, int C, int degree, const float *xyz, const float *feat,
+                   const float *sh, const float *inv2s2, float ox, float oy, float oz, float cx, float cy,
+                   float cz, float icx, float icy, float icz, int W, int H, int D, int kx, int ky, int kz,
+                   int normalize, float eps, float *grid, float *wsum, void *workspace, size_t workspace_bytes);
+
 /* backward of pdm_scatter_bev w.r.t. feat, sh, inv2s2 (outputs fully written, no zero-fill needed);
  * dwsum may be NULL. */
 int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const float *xyz,

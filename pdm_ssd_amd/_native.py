@@ -42,11 +42,13 @@ _SIGNATURES = {
     "pdm_tune_fused_groups": None,
     "pdm_tune_fused_wg_per_cu": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
+    "pdm_gather_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 6 + [_i, _f, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_bev_normalize": [_i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "pdm_scatter_bev_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp] * 5,
 }
 EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes",
-           "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes"] + list(_SIGNATURES)
+           "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes",
+           "pdm_gather_bev_workspace_bytes"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -69,6 +71,8 @@ def lib():
         l.pdm_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
         l.pdm_furthest_point_sampling_ws_bytes.restype = ctypes.c_size_t
         l.pdm_furthest_point_sampling_ws_bytes.argtypes = [_i, _i]
+        l.pdm_gather_bev_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_gather_bev_workspace_bytes.argtypes = [_i] * 6
         l.pdm_three_nn_grid_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_three_nn_grid_workspace_bytes.argtypes = [_i, _i]
         if l.pdm_abi_version() != ABI_VERSION:

@@ -60,6 +60,15 @@ class PDMNeck(nn.Module):
         sh = co[..., :self.nsh].contiguous()
         sigma = F.softplus(co[..., self.nsh]) + self.sigma_min
         inv2s2 = (0.5 / (sigma * sigma)).contiguous()
+        if not torch.is_grad_enabled() and self.layout == 1 and pdm_ops.gather_supported(self.feature_dim, self.grid.D) \
+                and getattr(self, 'use_gather', True):
+            # inference: deterministic gather form, normalisation fused, the grid is written exactly once
+            grid, wsum = pdm_ops.pdm_gather(xyz, feat, sh, inv2s2, self.grid, self.dilation, self.degree,
+                                            normalize=self.normalize)
+            batch_dict['spatial_features'] = grid.permute(0, 3, 1, 2)
+            batch_dict['spatial_features_stride'] = self.stride
+            batch_dict['pdm_weight_sum'] = wsum
+            return batch_dict
         grid, wsum = pdm_ops.pdm_scatter(xyz.contiguous(), feat, sh, inv2s2, self.grid, self.dilation,
                                          self.degree, self.layout)
         if self.normalize:

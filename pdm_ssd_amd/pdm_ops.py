@@ -99,3 +99,31 @@ def bev_normalize_(grid, wsum, C, grid_spec, layout=1, eps=1e-6):
     _native.call("pdm_bev_normalize", _stream(grid), B, C, g.W, g.H, g.D, layout, float(eps), grid.data_ptr(),
                  wsum.data_ptr())
     return grid
+
+
+def pdm_gather(xyz, feat, sh, inv2s2, grid_spec, kernel, degree, normalize=True, eps=1e-6):
+    """Inference form of pdm_scatter (+ normalise): no autograd, no atomics, bitwise reproducible.
+    Returns (grid (B,H,W,C*D) channels-last storage, wsum (B,H,W,D)); every cell is written."""
+    B, P, _ = xyz.shape
+    C = feat.shape[2]
+    nsh = (degree + 1) ** 2
+    xyz, feat, sh, inv2s2 = (t.float().contiguous() for t in (xyz, feat, sh, inv2s2))
+    _chk("xyz", xyz, (B, P, 3)); _chk("feat", feat, (B, P, C)); _chk("sh", sh, (B, P, nsh)); _chk("inv2s2", inv2s2, (B, P))
+    g = grid_spec
+    grid = torch.empty((B, g.H, g.W, C * g.D), dtype=torch.float32, device=xyz.device)
+    wsum = torch.empty((B, g.H, g.W, g.D), dtype=torch.float32, device=xyz.device)
+    nbytes = _native.lib().pdm_gather_bev_workspace_bytes(B, P, g.W, g.H, kernel[0], kernel[1])
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=xyz.device)
+    _native.call("pdm_gather_bev", _stream(xyz), B, P, C, degree, xyz.data_ptr(), feat.data_ptr(), sh.data_ptr(),
+                 inv2s2.data_ptr(), *g.floats(), g.W, g.H, g.D, *kernel, 1 if normalize else 0, float(eps),
+                 grid.data_ptr(), wsum.data_ptr(), ws.data_ptr(), nbytes)
+    return grid, wsum
+
+
+def gather_supported(C, D):
+    """D == 1, C <= 256: register accumulators.  Otherwise the LDS accumulator tile (64*D cells x C channels)
+    must fit 64 KB."""
+    if D == 1 and C <= 256:
+        return True
+    ncell = 64 * D
+    return (ncell * C + ncell + ncell * 32 + 32 * C + 32 * 20) * 4 + 32 * 12 <= 64 * 1024

@@ -60,6 +60,85 @@ def test_scatter_matches_oracle(oracle, dev, layout, degree, cell, kernel):
     np.testing.assert_allclose(got_n, ref_n, rtol=2e-3, atol=2e-3 * np.abs(ref_n).max())
 
 
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+@pytest.mark.parametrize("cell,kernel,C", [((0.8, 0.8, 4.0), (7, 7, 1), 128), ((0.8, 0.8, 4.0), (7, 7, 1), 70),
+                                           ((1.6, 1.6, 2.0), (3, 5, 3), 70), ((0.4, 0.4, 4.0), (1, 1, 1), 33),
+                                           ((3.2, 1.6, 4.0), (17, 9, 1), 64)])
+def test_gather_matches_oracle(oracle, dev, degree, cell, kernel, C):
+    """Gather form (inference): same sums as the scatter spec, every cell written, wsum included."""
+    B, P = 2, 300
+    assert pdm_ops.gather_supported(C, int(round(4.0 / cell[2])))
+    xyz, feat, sh, inv2s2 = make_inputs(B, P, C, degree, seed=degree * 7 + C)
+    g = pdm_ops.BevGrid(RANGE, cell)
+    origin, cellf, inv_cell, dims = oracle.pdm_grid_params(RANGE, cell)
+    ref_grid, ref_wsum = oracle.pdm_scatter(xyz, feat, sh, inv2s2, origin, cellf, inv_cell, dims, kernel, degree, 1)
+    args = (T(xyz, dev), T(feat, dev), T(sh, dev), T(inv2s2, dev), g, kernel, degree)
+    grid, wsum = pdm_ops.pdm_gather(*args, normalize=False)
+    scale = np.abs(ref_grid).max()
+    np.testing.assert_allclose(grid.cpu().numpy(), ref_grid, rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(wsum.cpu().numpy(), ref_wsum, rtol=1e-4, atol=1e-4 * np.abs(ref_wsum).max())
+    assert (grid.cpu().numpy()[ref_grid == 0] == 0).all()
+    ref_n = oracle.pdm_normalize(ref_grid, ref_wsum, C, dims, 1)
+    got_n, wsum_n = pdm_ops.pdm_gather(*args, normalize=True)
+    np.testing.assert_allclose(got_n.cpu().numpy(), ref_n, rtol=2e-3, atol=2e-3 * np.abs(ref_n).max())
+    assert torch.equal(wsum_n, wsum)
+    # fixed summation order: bitwise reproducible, also into a dirty output buffer of another launch
+    again, _ = pdm_ops.pdm_gather(*args, normalize=True)
+    assert torch.equal(again, got_n)
+
+
+def test_gather_dense_tile_and_edge_sizes(oracle, dev):
+    """Many points in one tile (several 32-point chunks, long sorted list), P = 1, P = 0 and B = 0."""
+    rng = np.random.default_rng(5)
+    B, P, C, degree, kernel, cell = 2, 700, 48, 2, (5, 5, 1), (0.8, 0.8, 4.0)
+    xyz, feat, sh, inv2s2 = make_inputs(B, P, C, degree, seed=11, outliers=False)
+    xyz[0, :, 0] = rng.uniform(10.0, 13.0, P); xyz[0, :, 1] = rng.uniform(-2.0, 1.0, P)   # sample 0: 4 x 4 cells
+    g = pdm_ops.BevGrid(RANGE, cell)
+    origin, cellf, inv_cell, dims = oracle.pdm_grid_params(RANGE, cell)
+    ref_grid, ref_wsum = oracle.pdm_scatter(xyz, feat, sh, inv2s2, origin, cellf, inv_cell, dims, kernel, degree, 1)
+    grid, wsum = pdm_ops.pdm_gather(T(xyz, dev), T(feat, dev), T(sh, dev), T(inv2s2, dev), g, kernel, degree, normalize=False)
+    np.testing.assert_allclose(grid.cpu().numpy(), ref_grid, rtol=1e-4, atol=1e-4 * np.abs(ref_grid).max())
+    np.testing.assert_allclose(wsum.cpu().numpy(), ref_wsum, rtol=1e-4, atol=1e-4 * np.abs(ref_wsum).max())
+    for p in (1, 0):
+        a = [T(v[:, :p], dev) for v in (xyz, feat, sh, inv2s2)]
+        rg, rw = oracle.pdm_scatter(xyz[:, :p], feat[:, :p], sh[:, :p], inv2s2[:, :p], origin, cellf, inv_cell, dims, kernel, degree, 1)
+        gg, ww = pdm_ops.pdm_gather(*a, g, kernel, degree, normalize=False)
+        np.testing.assert_allclose(gg.cpu().numpy(), rg, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ww.cpu().numpy(), rw, rtol=1e-4, atol=1e-6)
+    a = [T(v[:0], dev) for v in (xyz, feat, sh, inv2s2)]
+    gg, ww = pdm_ops.pdm_gather(*a, g, kernel, degree)
+    assert gg.shape[0] == 0 and ww.shape[0] == 0
+
+
+def test_gather_rejects_what_it_cannot_hold(dev):
+    g = pdm_ops.BevGrid(RANGE, (0.8, 0.8, 0.5))   # D = 8, C = 128: accumulator tile exceeds LDS
+    assert not pdm_ops.gather_supported(128, 8)
+    xyz, feat, sh, inv2s2 = make_inputs(1, 16, 128, 1, seed=0)
+    with pytest.raises(RuntimeError, match="LDS"):
+        pdm_ops.pdm_gather(T(xyz, dev), T(feat, dev), T(sh, dev), T(inv2s2, dev), g, (3, 3, 3), 1)
+
+
+def test_neck_eval_gather_equals_scatter_path(dev):
+    """PDMNeck inference (gather form) against its own scatter + normalise path on the same weights."""
+    from pdm_ssd_amd.pdm_neck import PDMNeck
+    cfg = {'SOURCE_LAYER': 1, 'FEATURE_DIM': 128, 'DILATION': [7, 7, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 8,
+           'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 40}
+    torch.manual_seed(0)
+    neck = PDMNeck(cfg, grid_size=[1408, 1600, 40], voxel_size=[0.05, 0.05, 0.1], point_cloud_range=RANGE).to(dev).eval()
+    with torch.no_grad():
+        neck.coef.weight.normal_(0.0, 0.05)
+    xyz, feat, _, _ = make_inputs(3, 1024, 40, 2, seed=9)
+    bd = {'sa_xyz': [None, T(xyz, dev)], 'sa_features': [None, T(feat, dev).transpose(1, 2).contiguous()]}
+    with torch.no_grad():
+        a = neck(dict(bd))
+        neck.use_gather = False
+        b = neck(dict(bd))
+    assert a['spatial_features'].shape == b['spatial_features'].shape == (3, 128, 200, 176)
+    sa, sb = a['spatial_features'], b['spatial_features']
+    assert torch.allclose(sa, sb, rtol=2e-3, atol=2e-3 * float(sb.abs().max()))
+    assert torch.allclose(a['pdm_weight_sum'], b['pdm_weight_sum'], rtol=1e-4, atol=1e-5)
+
+
 def test_scatter_linearity_and_zero_features(dev):
     """Size-independent property: the scatter is linear in the features."""
     B, P, C = 3, 512, 128
