@@ -146,6 +146,29 @@ int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, int c_skip,
                      int nlayers, const int *dims, const float *wpack, const float *bias,
                      float *out_pm, int out_stride, int cout);
 
+/* Per-row MLP on fp32 MFMA: in_pm (rows, cin) -> out_pm (rows, out_stride), same dims/wpack/bias packing.
+ * relu_last = 0 leaves the last layer linear.  Serves 1x1 convolutions over point-major rows and the
+ * pre-projections below. */
+int pdm_rows_mlp_fused(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims,
+                       const float *wpack, const float *bias, int relu_last, float *out_pm, int out_stride,
+                       int cout);
+
+/* The same SA scale / FP module with the wide part of the FIRST layer hoisted out of the per-pair (per-fine-
+ * point) loop — algebraically identical, fp32 rounding order differs (tests: <= 1e-4 of the oracle):
+ *   SA:  W1 [f_nb ; x_nb - c] = z[nb] + W1[:, xyz] (x_nb - c),   z = W1[:, features] f  over the n source points;
+ *   FP:  W1 [sum_k w_k f_k ; s] = sum_k w_k z[idx_k] + W1[:, skip] s,   z = W1[:, known] f  over the m known points.
+ * z_pm rows hold the layer's padded C1 floats at [z_coff, z_coff + C1pad) of z_stride (pdm_rows_mlp_fused with
+ * relu_last = 0 and zero bias); dims[0] is the padded width of what stays in the kernel (16 for xyz; the
+ * padded skip width, or 16 with zero weights when c_skip == 0). */
+int pdm_sa_mlp_fused_pre(void *stream, int b, int n, int m, int nsample, const float *xyz,
+                         const float *new_xyz, const float *z_pm, int z_stride, int z_coff, const int *idx,
+                         int nlayers, const int *dims, const float *wpack, const float *bias, float *out_pm,
+                         int out_stride, int out_coff, int cout);
+int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
+                         const float *skip_pm, const int *idx, const float *weight, int nlayers,
+                         const int *dims, const float *wpack, const float *bias, float *out_pm,
+                         int out_stride, int cout);
+
 /* ---- PDM neck (build-defined spec, DESIGN.md "PDM spec"; no reference source exists) ------- */
 
 /* Multi-centre scatter-add of dilated, SH x Gaussian weighted point features into a BEV grid.

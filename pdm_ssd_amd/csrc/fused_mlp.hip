@@ -34,6 +34,7 @@ struct MlpDesc {
     int boff[FM_MAXL];
     int stage_in;        // 1: layer-1 input is gathered once into LDS; 0: re-gathered per output block pair
     int pool_floats;     // SA: width of the last layer (max-pool combine buffer), FP: 0
+    int relu_last;       // 0: the last layer stores W x + b without the ReLU (pre-projection rows)
     int lds_p, lds_q;    // LDS tile widths (floats per position, incl. +4 pad) of the two ping-pong buffers
 };
 
@@ -45,6 +46,8 @@ struct SaArgs {
     const int *idx;        // (B,M,ns)
     float *out;            // (B,M,out_stride) point-major
     int out_stride, out_coff, cout;
+    const float *z;        // (B,N,z_stride) pre-projected layer-1 partial sums of the source points, or null
+    int z_stride, z_coff;
 };
 
 struct FpArgs {
@@ -55,6 +58,8 @@ struct FpArgs {
     const float *weight;  // (B,n,3)
     float *out;           // (B,n,out_stride) point-major
     int out_stride, cout;
+    const float *z;       // (B,m,z_stride) pre-projected layer-1 partial sums of the known points, or null
+    int z_stride;
 };
 
 __device__ __forceinline__ f4 mfma4(f4 acc, f4 a, f4 b) {
@@ -102,6 +107,14 @@ struct SaIn {
     float rx, ry, rz;
     int cin, g;
     bool vec;           // cin % 4 == 0 and 16-byte aligned rows
+    const float *zrow;  // pre-projected layer-1 row of this lane's neighbour (or null)
+    using Pre = f4;
+    __device__ __forceinline__ f4 pre_load(int mb) const {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (zrow) v = *reinterpret_cast<const f4 *>(zrow + 16 * mb + 4 * g);
+        return v;
+    }
+    __device__ __forceinline__ f4 pre_apply(const f4 &z, f4 acc) const { return acc + z; }
     __device__ __forceinline__ float elem(int c) const {
         if (c < cin) return frow[c];
         const int e = c - cin;
@@ -123,8 +136,28 @@ struct FpIn {
     float w0, w1, w2;
     int ck, cs, g;
     bool vec_k, vec_s, live;
+    const float *z0, *z1, *z2;  // pre-projected layer-1 rows of the three neighbours (or null)
+    struct Pre { f4 a, b, c; };
     __device__ __forceinline__ float interp(float a, float b, float c) const {
         return __fmaf_rn(w2, c, __fmaf_rn(w1, b, __fmul_rn(w0, a)));
+    }
+    __device__ __forceinline__ Pre pre_load(int mb) const {
+        Pre p;
+        p.a = p.b = p.c = f4{0.f, 0.f, 0.f, 0.f};
+        if (z0 && live) {
+            const int c0 = 16 * mb + 4 * g;
+            p.a = *reinterpret_cast<const f4 *>(z0 + c0);
+            p.b = *reinterpret_cast<const f4 *>(z1 + c0);
+            p.c = *reinterpret_cast<const f4 *>(z2 + c0);
+        }
+        return p;
+    }
+    // interpolation is linear, so W (sum_k w_k f_k) = sum_k w_k (W f_k): the known-feature part of layer 1
+    // arrives already multiplied by the weights (m rows instead of n)
+    __device__ __forceinline__ f4 pre_apply(const Pre &p, f4 acc) const {
+        acc.x += interp(p.a.x, p.b.x, p.c.x); acc.y += interp(p.a.y, p.b.y, p.c.y);
+        acc.z += interp(p.a.z, p.b.z, p.c.z); acc.w += interp(p.a.w, p.b.w, p.c.w);
+        return acc;
     }
     __device__ __forceinline__ float elem(int c) const {
         if (c < ck) return interp(r0[c], r1[c], r2[c]);
@@ -211,6 +244,7 @@ struct Tiles {
 };
 template <int NT>
 struct LdsTilesIn {
+    struct Pre {};
     const float *row;  // &H[pos][4g] of tile 0; tile t is 16 positions further
     int tile_stride;   // floats between tiles = 16 * width
     __device__ __forceinline__ f4 operator()(int t, int kb) const {
@@ -227,8 +261,21 @@ struct LdsTilesOut {
 };
 template <class T, int NT>
 struct TilesIn {
+    using Pre = typename T::Pre;
     const Tiles<T, NT> *p;
     __device__ __forceinline__ f4 operator()(int t, int kb) const { return p->t[t](kb); }
+    __device__ __forceinline__ Pre pre_load(int t, int mb) const { return p->t[t].pre_load(mb); }
+    __device__ __forceinline__ f4 pre_apply(int t, const Pre &z, f4 acc) const { return p->t[t].pre_apply(z, acc); }
+};
+// layer-1 input staged in LDS, pre-projection still taken from the gather provider
+template <class T, int NT>
+struct StagedPreIn {
+    using Pre = typename T::Pre;
+    LdsTilesIn<NT> li;
+    const Tiles<T, NT> *p;
+    __device__ __forceinline__ f4 operator()(int t, int kb) const { return li(t, kb); }
+    __device__ __forceinline__ Pre pre_load(int t, int mb) const { return p->t[t].pre_load(mb); }
+    __device__ __forceinline__ f4 pre_apply(int t, const Pre &z, f4 acc) const { return p->t[t].pre_apply(z, acc); }
 };
 template <class T, int NT>
 struct TilesOut {
@@ -241,12 +288,20 @@ struct TilesOut {
 // round-robin over the NB*NT independent accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40
 // cycles, the pipe issues one per 32); the next K block's fragments are requested before the current
 // block's MFMAs.
-template <int NB, int NT, class In, class Out>
+template <int NB, int NT, bool PRE, class In, class Out>
 __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__ w, size_t bstride,
-                                         const float *__restrict__ bias, int g, const In &in,
+                                         const float *__restrict__ bias, int g, bool relu, const In &in,
                                          const Out &out) {
     const f4 *__restrict__ wb[NB];
     f4 acc[NB][NT], a[NB], an[NB], b[NT], bn[NT];
+    // pre-projected part of the first layer: requested first, consumed after the K loop
+    typename In::Pre z[PRE ? NB : 1][PRE ? NT : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) z[i][t] = in.pre_load(t, mb + i);
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         wb[i] = w + (size_t)(mb + i) * bstride;
@@ -309,14 +364,18 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) out(t, mb + i, relu4(acc[i][t]));
+        for (int t = 0; t < NT; ++t) {
+            f4 v = acc[i][t];
+            if constexpr (PRE) v = in.pre_apply(t, z[i][t], v);
+            out(t, mb + i, relu ? relu4(v) : v);
+        }
 }
 
 // One layer for the W waves of a workgroup: the nmb output blocks are dealt to the waves in contiguous
 // shares; a wave walks its share in passes of up to 4 blocks.  `wave` must be wave-uniform (SGPR).
-template <int W, int NT, int MAXNB, class In, class Out>
+template <int W, int NT, int MAXNB, bool PRE, class In, class Out>
 __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restrict__ wp,
-                                          const float *__restrict__ bias, int lane, int wave,
+                                          const float *__restrict__ bias, int lane, int wave, bool relu,
                                           const In &in, const Out &out) {
     const int g = lane >> 4;
     const int share = (nmb + W - 1) / W;                  // blocks per wave
@@ -329,10 +388,10 @@ __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restr
     const size_t bstride = (size_t)nkb * 64;              // f4 elements between consecutive blocks
     for (int mb = mb_begin; mb < mb_end; mb += bpp) {
         const int nb = min(bpp, mb_end - mb);             // wave-uniform
-        if (MAXNB >= 4 && nb == 4) mlp_pass<4, NT>(nkb, mb, w, bstride, bias, g, in, out);
-        else if (MAXNB >= 3 && nb == 3) mlp_pass<3, NT>(nkb, mb, w, bstride, bias, g, in, out);
-        else if (MAXNB >= 2 && nb == 2) mlp_pass<2, NT>(nkb, mb, w, bstride, bias, g, in, out);
-        else mlp_pass<1, NT>(nkb, mb, w, bstride, bias, g, in, out);
+        if (MAXNB >= 4 && nb == 4) mlp_pass<4, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        else if (MAXNB >= 3 && nb == 3) mlp_pass<3, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        else if (MAXNB >= 2 && nb == 2) mlp_pass<2, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        else mlp_pass<1, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
     }
 }
 
@@ -346,35 +405,42 @@ __device__ __forceinline__ void wg_sync() {
 // (NT*16 positions x lds_p / lds_q floats): layer 1 writes Q, layer 2 writes P, layer 3 writes Q ...; a
 // staged input lives in P.  The layer sequence is unrolled so every descriptor field is read with a
 // constant index (a runtime index into the by-value descriptor would push it to scratch).
-template <int W, int NT, int MAXNB, int PSW, int L, class In, class Out>
+template <int W, int NT, int MAXNB, int PSW, int L, bool PRE, class T, class Out>
 __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restrict__ wpack,
                                           const float *__restrict__ bias, float *P, float *Q, int lane,
-                                          int wave, const In &in, const Out &out) {
+                                          int wave, const TilesIn<T, NT> &in, const Out &out) {
     const int pos = lane & 15, g = lane >> 4;
     const int nkb = d.K[L - 1] >> 4, nmb = d.K[L] >> 4;
     const float *wl = wpack + d.woff[L - 1];
     const float *bl = bias + d.boff[L - 1];
     const bool last = L == d.nlayers;
+    const bool relu = !last || d.relu_last;
     float *ob = (L & 1) ? Q : P;
     const int ow = (L & 1) ? d.lds_q : d.lds_p;
     const LdsTilesOut<NT> lo{ob + pos * ow + 4 * g, 16 * ow};
     if (L == 1 && !d.stage_in) {
-        if (last) mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, in, out);
-        else mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, in, lo);
+        if (last) mlp_layer<W, NT, MAXNB, PRE>(nkb, nmb, wl, bl, lane, wave, relu, in, out);
+        else mlp_layer<W, NT, MAXNB, PRE>(nkb, nmb, wl, bl, lane, wave, relu, in, lo);
     } else {
         float *ib = (L & 1) ? P : Q;  // layer 1 (staged) and layer 3 read P, layer 2 reads Q
         const int iw = (L & 1) ? d.lds_p : d.lds_q;
         const LdsTilesIn<NT> li{ib + pos * iw + 4 * g, 16 * iw};
-        if (last) mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, li, out);
-        else mlp_layer<W, NT, MAXNB>(nkb, nmb, wl, bl, lane, wave, li, lo);
+        if (L == 1 && PRE) {
+            const StagedPreIn<T, NT> si{li, in.p};
+            if (last) mlp_layer<W, NT, MAXNB, true>(nkb, nmb, wl, bl, lane, wave, relu, si, out);
+            else mlp_layer<W, NT, MAXNB, true>(nkb, nmb, wl, bl, lane, wave, relu, si, lo);
+        } else {
+            if (last) mlp_layer<W, NT, MAXNB, false>(nkb, nmb, wl, bl, lane, wave, relu, li, out);
+            else mlp_layer<W, NT, MAXNB, false>(nkb, nmb, wl, bl, lane, wave, relu, li, lo);
+        }
     }
     wg_sync<W * PSW>();
 }
 
-template <int W, int NT, int MAXNB, int PSW, class In, class Out>
+template <int W, int NT, int MAXNB, int PSW, class T, class Out>
 __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restrict__ wpack,
                                         const float *__restrict__ bias, float *P, float *Q, int lane,
-                                        int wave, const In &in, const Out &out) {
+                                        int wave, bool pre, const TilesIn<T, NT> &in, const Out &out) {
     if (d.stage_in) {
         // gather the input tiles once, K blocks dealt round-robin to the waves: P[tile*16 + pos][K0]
         float *row = P + (lane & 15) * d.lds_p + 4 * (lane >> 4);
@@ -384,10 +450,11 @@ __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restric
             for (int t = 0; t < NT; ++t) *reinterpret_cast<f4 *>(row + t * 16 * d.lds_p + 16 * kb) = in(t, kb);
         wg_sync<W * PSW>();
     }
-    run_layer<W, NT, MAXNB, PSW, 1>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 2) run_layer<W, NT, MAXNB, PSW, 2>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 3) run_layer<W, NT, MAXNB, PSW, 3>(d, wpack, bias, P, Q, lane, wave, in, out);
-    if (d.nlayers >= 4) run_layer<W, NT, MAXNB, PSW, 4>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (pre) run_layer<W, NT, MAXNB, PSW, 1, true>(d, wpack, bias, P, Q, lane, wave, in, out);  // wave-uniform
+    else run_layer<W, NT, MAXNB, PSW, 1, false>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 2) run_layer<W, NT, MAXNB, PSW, 2, false>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 3) run_layer<W, NT, MAXNB, PSW, 3, false>(d, wpack, bias, P, Q, lane, wave, in, out);
+    if (d.nlayers >= 4) run_layer<W, NT, MAXNB, PSW, 4, false>(d, wpack, bias, P, Q, lane, wave, in, out);
 }
 
 // Workgroup = PSW position groups x W channel-split waves.  The W waves of a group share one LDS tile
@@ -433,12 +500,13 @@ __global__ __launch_bounds__(64 * W * PSW) void sa_mlp_fused_kernel(MlpDesc d, S
                 in.t[t].rx = p3[0] - c3[0]; in.t[t].ry = p3[1] - c3[1]; in.t[t].rz = p3[2] - c3[2];  // pointnet2_utils.py:252
                 in.t[t].cin = a.cin; in.t[t].g = g;
                 in.t[t].vec = (a.cin & 3) == 0 && a.cin > 0;
+                in.t[t].zrow = a.z ? a.z + ((size_t)b * a.n + nb) * a.z_stride + a.z_coff : nullptr;
                 out.t[t].pool = pool;
                 out.t[t].orow = live ? a.out + ctr * a.out_stride + a.out_coff : nullptr;
                 out.t[t].cout = a.cout; out.t[t].lane = lane; out.t[t].g = g;
                 out.t[t].first_tile = tic == 0; out.t[t].last_tile = tic == tpc - 1;
             }
-            run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn, NT>{&in}, TilesOut<PoolOut, NT>{&out});
+            run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, a.z != nullptr, TilesIn<SaIn, NT>{&in}, TilesOut<PoolOut, NT>{&out});
         }
     }
 }
@@ -468,12 +536,19 @@ __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, F
             FpIn &f = in.t[t];
             f.live = tile < ntiles && p < a.n;
             const size_t q = (size_t)b * a.n + (f.live ? p : 0);
-            const int *id = a.idx + q * 3;
-            const float *w = a.weight + q * 3;
-            f.r0 = a.known + ((size_t)b * a.m + id[0]) * a.c_known;
-            f.r1 = a.known + ((size_t)b * a.m + id[1]) * a.c_known;
-            f.r2 = a.known + ((size_t)b * a.m + id[2]) * a.c_known;
-            f.w0 = w[0]; f.w1 = w[1]; f.w2 = w[2];
+            f.r0 = f.r1 = f.r2 = f.z0 = f.z1 = f.z2 = nullptr;
+            f.w0 = f.w1 = f.w2 = 0.0f;
+            if (a.idx) {  // null for plain rows (pdm_rows_mlp_fused)
+                const int *id = a.idx + q * 3;
+                const float *w = a.weight + q * 3;
+                const size_t k0 = (size_t)b * a.m + id[0], k1 = (size_t)b * a.m + id[1], k2 = (size_t)b * a.m + id[2];
+                f.w0 = w[0]; f.w1 = w[1]; f.w2 = w[2];
+                if (a.z) {
+                    f.z0 = a.z + k0 * a.z_stride; f.z1 = a.z + k1 * a.z_stride; f.z2 = a.z + k2 * a.z_stride;
+                } else {
+                    f.r0 = a.known + k0 * a.c_known; f.r1 = a.known + k1 * a.c_known; f.r2 = a.known + k2 * a.c_known;
+                }
+            }
             f.srow = a.c_skip > 0 ? a.skip + q * a.c_skip : nullptr;
             f.ck = a.c_known; f.cs = a.c_skip; f.g = g;
             f.vec_k = (a.c_known & 3) == 0;
@@ -481,7 +556,7 @@ __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, F
             out.t[t].orow = f.live ? a.out + q * a.out_stride : nullptr;
             out.t[t].cout = a.cout; out.t[t].g = g;
         }
-        run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, TilesIn<FpIn, NT>{&in}, TilesOut<RowOut, NT>{&out});
+        run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, a.z != nullptr, TilesIn<FpIn, NT>{&in}, TilesOut<RowOut, NT>{&out});
     }
 }
 
@@ -495,6 +570,7 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     PDM_REQUIRE(nlayers >= 1 && nlayers <= FM_MAXL, PDM_E_BADARG, "%s: nlayers=%d not in [1,%d]", who, nlayers, FM_MAXL);
     PDM_REQUIRE(dims, PDM_E_BADARG, "%s: null dims", who);
     d.nlayers = nlayers;
+    d.relu_last = 1;
     int wo = 0, bo = 0;
     for (int l = 0; l <= nlayers; ++l) {
         PDM_REQUIRE(dims[l] > 0 && dims[l] % 16 == 0, PDM_E_BADARG, "%s: padded width %d of level %d is not a positive multiple of 16", who, dims[l], l);
@@ -579,11 +655,10 @@ extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fu
         else FUSED_LAUNCH1(KERNEL, 8, 1, blocks, lds_bytes, __VA_ARGS__);                                      \
     } while (0)
 
-extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample,
-                                const float *xyz, const float *new_xyz, const float *feat_pm,
-                                const int *idx, int nlayers, const int *dims, const float *wpack,
-                                const float *bias, float *out_pm, int out_stride, int out_coff,
-                                int cout) {
+static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
+                           const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride,
+                           int z_coff, const int *idx, int nlayers, const int *dims, const float *wpack,
+                           const float *bias, float *out_pm, int out_stride, int out_coff, int cout) {
     PDM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && cin >= 0 && nsample > 0, PDM_E_BADARG, "sa_mlp_fused: bad size");
     PDM_REQUIRE(nsample % 16 == 0, PDM_E_BADARG, "sa_mlp_fused: nsample=%d must be a multiple of 16", nsample);
     if (b == 0 || m == 0) return 0;
@@ -595,13 +670,19 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3,
                        dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, sa_tiles, &W, &NT, &G);
     if (rc) return rc;
+    if (z_pm) {
+        d.stage_in = 0;  // layer-1 input is the lane's own xyz offset: nothing to stage
+        PDM_REQUIRE(z_stride % 4 == 0 && z_coff % 4 == 0 && z_coff >= 0 && z_coff + d.K[1] <= z_stride &&
+                        (reinterpret_cast<uintptr_t>(z_pm) & 15) == 0,
+                    PDM_E_BADARG, "sa_mlp_fused_pre: z rows need %d floats at offset %d of stride %d, 16-byte aligned", d.K[1], z_coff, z_stride);
+    }
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && out_coff >= 0 && out_coff + cout <= out_stride, PDM_E_BADARG,
                 "sa_mlp_fused: cout=%d coff=%d stride=%d", cout, out_coff, out_stride);
     PDM_REQUIRE(out_stride % 4 == 0 && out_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
                     (cin % 4 != 0 || (reinterpret_cast<uintptr_t>(feat_pm) & 15) == 0),
                 PDM_E_BADARG, "sa_mlp_fused: out/wpack/bias/feat must be 16-byte aligned, out_stride and out_coff multiples of 4");
-    SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout};
+    SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout, z_pm, z_stride, z_coff};
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const int tpc_ = nsample / 16;
@@ -613,26 +694,55 @@ extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int 
     return check_launch("sa_mlp_fused");
 }
 
-extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, int c_skip,
-                                const float *known_pm, const float *skip_pm, const int *idx,
-                                const float *weight, int nlayers, const int *dims, const float *wpack,
-                                const float *bias, float *out_pm, int out_stride, int cout) {
-    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 1 && c_known >= 1 && c_skip >= 0, PDM_E_BADARG, "fp_mlp_fused: bad size");
+extern "C" int pdm_sa_mlp_fused(void *stream, int b, int n, int m, int cin, int nsample,
+                                const float *xyz, const float *new_xyz, const float *feat_pm,
+                                const int *idx, int nlayers, const int *dims, const float *wpack,
+                                const float *bias, float *out_pm, int out_stride, int out_coff,
+                                int cout) {
+    return sa_fused_launch(stream, b, n, m, cin, nsample, xyz, new_xyz, feat_pm, nullptr, 0, 0, idx, nlayers, dims,
+                           wpack, bias, out_pm, out_stride, out_coff, cout);
+}
+
+// Same SA scale with the FEATURE part of layer 1 applied beforehand to the n source points
+// (z = W1[:, features] f, pdm_rows_mlp_fused with relu_last = 0): layer 1 = relu(z[nb] + W1[:, xyz] (x_nb - c) + b).
+// The contraction runs once per source point instead of once per (centre, neighbour) pair.
+extern "C" int pdm_sa_mlp_fused_pre(void *stream, int b, int n, int m, int nsample, const float *xyz,
+                                    const float *new_xyz, const float *z_pm, int z_stride, int z_coff,
+                                    const int *idx, int nlayers, const int *dims, const float *wpack,
+                                    const float *bias, float *out_pm, int out_stride, int out_coff, int cout) {
+    PDM_REQUIRE(z_pm || b == 0 || m == 0, PDM_E_BADARG, "sa_mlp_fused_pre: null z");
+    return sa_fused_launch(stream, b, n, m, 0, nsample, xyz, new_xyz, nullptr, z_pm, z_stride, z_coff, idx, nlayers,
+                           dims, wpack, bias, out_pm, out_stride, out_coff, cout);
+}
+
+// mode 0: FP module (known rows interpolated in the kernel); 1: FP module with pre-projected known rows z;
+// 2: plain rows (no interpolation: c_known = 0, the rows are `skip`)
+static int fp_fused_launch(void *stream, int mode, int relu_last, int b, int n, int m, int c_known, int c_skip,
+                           const float *known_pm, const float *z_pm, int z_stride, const float *skip_pm,
+                           const int *idx, const float *weight, int nlayers, const int *dims,
+                           const float *wpack, const float *bias, float *out_pm, int out_stride, int cout) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 1 && c_known >= 0 && c_skip >= 0 && c_known + c_skip >= (mode == 1 ? 0 : 1),
+                PDM_E_BADARG, "fp_mlp_fused: bad size");
     if (b == 0 || n == 0) return 0;
-    PDM_REQUIRE(known_pm && idx && weight && wpack && bias && out_pm && (c_skip == 0 || skip_pm), PDM_E_BADARG,
-                "fp_mlp_fused: null pointer");
+    PDM_REQUIRE(wpack && bias && out_pm && (c_skip == 0 || skip_pm) && (mode == 2 || (idx && weight)) &&
+                    (mode != 0 || known_pm) && (mode != 1 || z_pm),
+                PDM_E_BADARG, "fp_mlp_fused: null pointer");
     MlpDesc d;
     int W = 1, NT = 1, G = 1;
     const long long ntiles = (long long)b * ((n + 15) / 16);
     int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, ntiles, &W, &NT, &G);
     if (rc) return rc;
+    d.relu_last = relu_last ? 1 : 0;
+    if (mode == 1)
+        PDM_REQUIRE(z_stride % 4 == 0 && z_stride >= d.K[1] && (reinterpret_cast<uintptr_t>(z_pm) & 15) == 0, PDM_E_BADARG,
+                    "fp_mlp_fused_pre: z rows need %d floats, stride %d, 16-byte aligned", d.K[1], z_stride);
     PDM_REQUIRE(cout > 0 && cout <= d.K[nlayers] && cout <= out_stride, PDM_E_BADARG, "fp_mlp_fused: cout=%d stride=%d", cout, out_stride);
     PDM_REQUIRE(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_pm) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
                     (c_known % 4 != 0 || (reinterpret_cast<uintptr_t>(known_pm) & 15) == 0) &&
                     (c_skip % 4 != 0 || c_skip == 0 || (reinterpret_cast<uintptr_t>(skip_pm) & 15) == 0),
                 PDM_E_BADARG, "fp_mlp_fused: buffers must be 16-byte aligned and out_stride a multiple of 4");
-    FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout};
+    FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout, mode == 1 ? z_pm : nullptr, z_stride};
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const long long niter = ((ntiles + NT - 1) / NT + G - 1) / G;
@@ -640,4 +750,35 @@ extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, 
     const int blocks = (int)(niter < cap ? niter : cap);
     FUSED_DISPATCH(fp_mlp_fused_kernel, W, G, blocks, lds_bytes, d, a, wpack, bias);
     return check_launch("fp_mlp_fused");
+}
+
+extern "C" int pdm_fp_mlp_fused(void *stream, int b, int n, int m, int c_known, int c_skip,
+                                const float *known_pm, const float *skip_pm, const int *idx,
+                                const float *weight, int nlayers, const int *dims, const float *wpack,
+                                const float *bias, float *out_pm, int out_stride, int cout) {
+    PDM_REQUIRE(c_known >= 1, PDM_E_BADARG, "fp_mlp_fused: c_known=%d", c_known);
+    return fp_fused_launch(stream, 0, 1, b, n, m, c_known, c_skip, known_pm, nullptr, 0, skip_pm, idx, weight, nlayers,
+                           dims, wpack, bias, out_pm, out_stride, cout);
+}
+
+// Same FP module with the KNOWN-feature part of layer 1 applied beforehand to the m known points
+// (z = W1[:, known] f, pdm_rows_mlp_fused with relu_last = 0).  Interpolation is linear, so
+// layer 1 = relu(sum_k w_k z[idx_k] + W1[:, skip] s + b): the wide contraction runs over m rows instead of n.
+// dims[0] = padded skip width (16 with all-zero weights when c_skip == 0).
+extern "C" int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const float *z_pm,
+                                    int z_stride, const float *skip_pm, const int *idx, const float *weight,
+                                    int nlayers, const int *dims, const float *wpack, const float *bias,
+                                    float *out_pm, int out_stride, int cout) {
+    return fp_fused_launch(stream, 1, 1, b, n, m, 0, c_skip, nullptr, z_pm, z_stride, skip_pm, idx, weight, nlayers, dims,
+                           wpack, bias, out_pm, out_stride, cout);
+}
+
+// Per-row MLP on fp32 MFMA: out[r] = act(W_L ... relu(W_1 in[r] + b_1) ... + b_L), rows (R, cin) contiguous.
+// relu_last = 0 leaves the last layer linear (the pre-projections above, 1x1 convolutions without activation).
+extern "C" int pdm_rows_mlp_fused(void *stream, int rows, int cin, const float *in_pm, int nlayers,
+                                  const int *dims, const float *wpack, const float *bias, int relu_last,
+                                  float *out_pm, int out_stride, int cout) {
+    PDM_REQUIRE(rows >= 0 && cin >= 1, PDM_E_BADARG, "rows_mlp_fused: rows=%d cin=%d", rows, cin);
+    return fp_fused_launch(stream, 2, relu_last, 1, rows, 1, 0, cin, nullptr, nullptr, 0, in_pm, nullptr, nullptr, nlayers,
+                           dims, wpack, bias, out_pm, out_stride, cout);
 }

@@ -14,6 +14,15 @@ import torch.nn as nn
 
 from . import _native
 
+# bench.py installs a dict here to tally the FLOPs each entry point executes (2 * real cin * cout per position and
+# layer, padding excluded); None = no accounting
+FLOP_COUNTER = None
+
+
+def _count(name, positions, pk):
+    if FLOP_COUNTER is not None:
+        FLOP_COUNTER[name] = FLOP_COUNTER.get(name, 0.0) + float(positions) * pk.flops_per_position
+
 
 def _pad16(c):
     return (c + 15) // 16 * 16
@@ -64,13 +73,18 @@ def pack_layer(w, shift):
 
 
 class PackedMLP:
-    def __init__(self, layers, device, in_perm=None):
-        """layers: list of (conv, bn).  in_perm: optional input-channel permutation of the first layer."""
+    def __init__(self, layers, device, in_perm=None, min_in=0):
+        """layers: list of (conv, bn).  in_perm: optional input-channel selection / permutation of the first
+        layer (a subset keeps only those columns; an empty one leaves `min_in` all-zero columns)."""
         ws, bs, dims = [], [], []
+        self.flops_per_position = 0
         for li, (conv, bn) in enumerate(layers):
             w, shift = fold_conv_bn(conv, bn)
             if li == 0 and in_perm is not None:
                 w = w[:, in_perm]
+            self.flops_per_position += 2 * w.shape[0] * w.shape[1]
+            if li == 0 and w.shape[1] < min_in:
+                w = torch.cat([w, torch.zeros(w.shape[0], min_in - w.shape[1], dtype=w.dtype)], dim=1)
             pw, pb, kp, cp = pack_layer(w.numpy().astype(np.float32), shift.numpy().astype(np.float32))
             if li == 0:
                 dims.append(kp)
@@ -82,10 +96,42 @@ class PackedMLP:
         self.nlayers = len(layers)
         self.dims = dims
         self.cout = layers[-1][0].out_channels
-        self.cin = layers[0][0].in_channels
+        self.cin = layers[0][0].in_channels if in_perm is None else len(in_perm)
         self.dims_c = (ctypes.c_int * len(dims))(*dims)
         self.wpack = torch.from_numpy(np.concatenate(ws)).to(device)
         self.bias = torch.from_numpy(np.concatenate(bs)).to(device)
+
+    @property
+    def dims_ptr(self):
+        return ctypes.cast(self.dims_c, ctypes.c_void_p)
+
+
+class PackedPre:
+    """First-layer column blocks of several MLPs stacked into one linear map: z = [W_a f | W_b f | ...] (no bias,
+    no activation), each block padded to a multiple of 16 outputs.  offsets[i] = column of block i in a z row."""
+
+    def __init__(self, first_layers, cols, device):
+        blocks, self.offsets, o = [], [], 0
+        self.flops_per_position = 0
+        for conv, bn in first_layers:
+            w, _ = fold_conv_bn(conv, bn)          # the shift stays with the consuming kernel
+            w = w[:, cols].numpy().astype(np.float32)
+            self.flops_per_position += 2 * w.shape[0] * w.shape[1]
+            wp = np.zeros((_pad16(w.shape[0]), w.shape[1]), dtype=np.float32)
+            wp[:w.shape[0]] = w
+            blocks.append(wp)
+            self.offsets.append(o)
+            o += wp.shape[0]
+        self.width = o
+        self.cin = len(cols)
+        pw, pb, kp, cp = pack_layer(np.concatenate(blocks, axis=0), np.zeros(o, dtype=np.float32))
+        assert cp == o
+        self.dims = [kp, cp]
+        self.dims_c = (ctypes.c_int * 2)(kp, cp)
+        self.wpack = torch.from_numpy(pw).to(device)
+        self.bias = torch.from_numpy(pb).to(device)
+        self.nlayers = 1
+        self.cout = o
 
     @property
     def dims_ptr(self):
@@ -112,6 +158,24 @@ def cached_pack(owner, slot, seq, device, in_perm=None):
     return packed
 
 
+def cached_pre_packs(owner, slot, seqs, device, pre_cols, keep_cols, min_in=0):
+    """(PackedPre over the first layers of `seqs` restricted to `pre_cols`, [PackedMLP of each seq with only
+    `keep_cols` left in its first layer]); cached on `owner`; None when a seq is not a [conv, bn, relu]* chain."""
+    cache = owner.__dict__.setdefault('_pdm_fused_cache', {})
+    key = (tuple(_state_key(seq) for seq in seqs), str(device), tuple(pre_cols), tuple(keep_cols))
+    hit = cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    layer_lists = [split_shared_mlp(seq) for seq in seqs]
+    if any(l is None for l in layer_lists):
+        cache[slot] = (key, None)
+        return None
+    pre = PackedPre([l[0] for l in layer_lists], list(pre_cols), device)
+    packs = [PackedMLP(l, device, list(keep_cols), min_in) for l in layer_lists]
+    cache[slot] = (key, (pre, packs))
+    return pre, packs
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -123,6 +187,7 @@ def sa_scale_forward(pk, xyz, new_xyz, feat_pm, idx, out_pm, out_coff):
     M, ns = idx.shape[1], idx.shape[2]
     cin = 0 if feat_pm is None else feat_pm.shape[2]
     assert pk.cin == cin + 3
+    _count("pdm_sa_mlp_fused", B * M * ns, pk)
     _native.call("pdm_sa_mlp_fused", _stream(xyz), B, N, M, cin, ns, xyz.data_ptr(), new_xyz.data_ptr(),
                  0 if feat_pm is None else feat_pm.data_ptr(), idx.data_ptr(), pk.nlayers, pk.dims_ptr,
                  pk.wpack.data_ptr(), pk.bias.data_ptr(), out_pm.data_ptr(), out_pm.shape[2], out_coff, pk.cout)
@@ -134,6 +199,41 @@ def fp_forward(pk, known_pm, skip_pm, idx, weight, out_pm):
     n = idx.shape[1]
     cs = 0 if skip_pm is None else skip_pm.shape[2]
     assert pk.cin == ck + cs
+    _count("pdm_fp_mlp_fused", B * n, pk)
     _native.call("pdm_fp_mlp_fused", _stream(known_pm), B, n, m, ck, cs, known_pm.data_ptr(),
+                 0 if skip_pm is None else skip_pm.data_ptr(), idx.data_ptr(), weight.data_ptr(), pk.nlayers,
+                 pk.dims_ptr, pk.wpack.data_ptr(), pk.bias.data_ptr(), out_pm.data_ptr(), out_pm.shape[2], pk.cout)
+
+
+def rows_forward(pk, in_pm, out_pm, relu_last=True):
+    """Per-row MLP: in_pm (..., cin) contiguous rows -> out_pm (..., stride), pk.cout columns written."""
+    cin = in_pm.shape[-1]
+    rows = in_pm.numel() // cin
+    assert pk.cin == cin and in_pm.is_contiguous() and out_pm.is_contiguous()
+    _count("pdm_rows_mlp_fused", rows, pk)
+    _native.call("pdm_rows_mlp_fused", _stream(in_pm), rows, cin, in_pm.data_ptr(), pk.nlayers, pk.dims_ptr,
+                 pk.wpack.data_ptr(), pk.bias.data_ptr(), 1 if relu_last else 0, out_pm.data_ptr(),
+                 out_pm.shape[-1], pk.cout)
+
+
+def sa_scale_forward_pre(pk, xyz, new_xyz, z, z_coff, idx, out_pm, out_coff):
+    """SA scale whose first layer's feature part was applied to the source points: z (B,N,width)."""
+    B, N, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    assert pk.cin == 3 and z.shape[0] == B and z.shape[1] == N
+    _count("pdm_sa_mlp_fused_pre", B * M * ns, pk)
+    _native.call("pdm_sa_mlp_fused_pre", _stream(xyz), B, N, M, ns, xyz.data_ptr(), new_xyz.data_ptr(), z.data_ptr(),
+                 z.shape[2], z_coff, idx.data_ptr(), pk.nlayers, pk.dims_ptr, pk.wpack.data_ptr(), pk.bias.data_ptr(),
+                 out_pm.data_ptr(), out_pm.shape[2], out_coff, pk.cout)
+
+
+def fp_forward_pre(pk, z, skip_pm, idx, weight, out_pm):
+    """FP module whose first layer's known-feature part was applied to the known points: z (B,m,width)."""
+    B, m, _ = z.shape
+    n = idx.shape[1]
+    cs = 0 if skip_pm is None else skip_pm.shape[2]
+    assert pk.cin == cs
+    _count("pdm_fp_mlp_fused_pre", B * n, pk)
+    _native.call("pdm_fp_mlp_fused_pre", _stream(z), B, n, m, cs, z.data_ptr(), z.shape[2],
                  0 if skip_pm is None else skip_pm.data_ptr(), idx.data_ptr(), weight.data_ptr(), pk.nlayers,
                  pk.dims_ptr, pk.wpack.data_ptr(), pk.bias.data_ptr(), out_pm.data_ptr(), out_pm.shape[2], pk.cout)

@@ -14,6 +14,8 @@ import torch.nn.functional as F
 from . import pointnet2_utils
 from .. import fused
 
+PRE_MIN_CIN = 16   # hoist the first layer's feature block when it is at least one 16-deep K block wide
+
 
 def _shared_mlp(spec: List[int]) -> nn.Sequential:
     """Conv2d(1x1, no bias) -> BatchNorm2d -> ReLU per stage (ref :91-97, :132-139)."""
@@ -71,9 +73,22 @@ class _PointnetSAModuleBase(nn.Module):
         ctot = sum(pk.cout for pk in packs)
         out_pm = torch.empty((B, M, ctot), dtype=torch.float32, device=xyz.device)
         coff = 0
-        for grouper, pk in zip(self.groupers, packs):
+        cin = 0 if feat_pm is None else feat_pm.shape[2]
+        pre = None
+        if cin >= PRE_MIN_CIN and getattr(self, 'use_pre', True):
+            # hoist W1[:, features] out of the (centre, neighbour) loop: one projection of the N source points
+            # serves every scale (reference channel order [xyz(3), features(cin)], pointnet2_utils.py:254)
+            pre = fused.cached_pre_packs(self, 'pre', list(self.mlps), xyz.device, range(3, 3 + cin), range(3))
+        if pre is not None:
+            prepack, packs = pre
+            z = torch.empty((B, xyz.shape[1], prepack.width), dtype=torch.float32, device=xyz.device)
+            fused.rows_forward(prepack, feat_pm, z, relu_last=False)
+        for i, (grouper, pk) in enumerate(zip(self.groupers, packs)):
             idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-            fused.sa_scale_forward(pk, xyz, new_xyz, feat_pm, idx, out_pm, coff)
+            if pre is not None:
+                fused.sa_scale_forward_pre(pk, xyz, new_xyz, z, prepack.offsets[i], idx, out_pm, coff)
+            else:
+                fused.sa_scale_forward(pk, xyz, new_xyz, feat_pm, idx, out_pm, coff)
             coff += pk.cout
         return new_xyz, out_pm.transpose(1, 2)  # logical (B, C, M) over point-major storage
 
@@ -163,7 +178,21 @@ class PointnetFPModule(nn.Module):
                     skip_pm = None if unknow_feats is None else unknow_feats.float().transpose(1, 2).contiguous()
                     out_pm = torch.empty((unknown.shape[0], unknown.shape[1], pk.cout), dtype=torch.float32,
                                          device=known_feats.device)
-                    fused.fp_forward(pk, known_pm, skip_pm, idx, weight.contiguous(), out_pm)
+                    ck = known_feats.shape[1]
+                    pre = None
+                    if getattr(self, 'use_pre', True) and ck >= PRE_MIN_CIN:
+                        # interpolation is linear: apply W1[:, known] to the m known points, interpolate after
+                        # (channel order of ref :165 is [interpolated(ck), skip(cs)])
+                        pre = fused.cached_pre_packs(self, 'pre', [self.mlp], known_feats.device, range(ck),
+                                                     range(ck, ck + cs), min_in=1)
+                    if pre is not None:
+                        prepack, (pk1,) = pre
+                        z = torch.empty((known_pm.shape[0], known_pm.shape[1], prepack.width), dtype=torch.float32,
+                                        device=known_feats.device)
+                        fused.rows_forward(prepack, known_pm, z, relu_last=False)
+                        fused.fp_forward_pre(pk1, z, skip_pm, idx, weight.contiguous(), out_pm)
+                    else:
+                        fused.fp_forward(pk, known_pm, skip_pm, idx, weight.contiguous(), out_pm)
                     return out_pm.transpose(1, 2)
             interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:

@@ -49,7 +49,12 @@ def test_sa_fused_matches_cpu_graph(dev, cin, mlps, nsamples):
     assert nf.stride(1) == 1, "fused output must be a view of point-major storage"
     np.testing.assert_array_equal(nx.cpu().numpy(), ref_xyz)
     np.testing.assert_allclose(nf.cpu().numpy(), ref_feat, rtol=1e-4, atol=1e-4)
-    # same module, fused path switched off, agrees too
+    assert ('pre' in sa_g._pdm_fused_cache) == (cin >= pm.PRE_MIN_CIN)
+    # first-layer hoisting switched off (features gathered and contracted per pair), then the whole fused path off
+    sa_g.use_pre = False
+    with torch.no_grad():
+        _, nf1 = sa_g(torch.from_numpy(xyz).to(dev), None if feat is None else torch.from_numpy(feat).to(dev))
+    np.testing.assert_allclose(nf1.cpu().numpy(), ref_feat, rtol=1e-4, atol=1e-4)
     sa_g.use_fused = False
     with torch.no_grad():
         _, nf2 = sa_g(torch.from_numpy(xyz).to(dev), None if feat is None else torch.from_numpy(feat).to(dev))
@@ -79,6 +84,40 @@ def test_fp_fused_matches_cpu_graph(dev, ck, cs, mlp, n, m):
                    None if uf is None else torch.from_numpy(uf).to(dev), torch.from_numpy(kf).to(dev))
     assert got.stride(1) == 1 and fp_g._pdm_fused_cache[0][1] is not None
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    assert fp_g._pdm_fused_cache['pre'][1] is not None      # known-feature block applied on the m known points
+    fp_g.use_pre = False                                     # interpolate-then-contract form of the same module
+    with torch.no_grad():
+        got1 = fp_g(torch.from_numpy(unknown).to(dev), torch.from_numpy(known).to(dev),
+                    None if uf is None else torch.from_numpy(uf).to(dev), torch.from_numpy(kf).to(dev))
+    np.testing.assert_allclose(got1.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,cin,widths,relu_last", [(1000, 96, [128], False), (37, 515, [256, 64], True),
+                                                        (4096, 1, [16], False), (0, 8, [16], True)])
+def test_rows_mlp_matches_torch(dev, rows, cin, widths, relu_last):
+    """pdm_rows_mlp_fused against torch fp64 Conv1d/BN/ReLU on CPU (1e-4, fp32 accumulation order differs)."""
+    torch.manual_seed(rows + cin)
+    chans = [cin] + widths
+    seq = torch.nn.Sequential(*[m for i in range(len(widths)) for m in
+                                (torch.nn.Conv1d(chans[i], chans[i + 1], 1, bias=False),
+                                 torch.nn.BatchNorm1d(chans[i + 1]), torch.nn.ReLU())]).eval()
+    randomize_bn(seq, 2)
+    x = torch.randn(max(rows, 1), cin)
+    with torch.no_grad():
+        y = x.double().t().unsqueeze(0)
+        mods = list(seq.double())
+        for i, m in enumerate(mods):
+            if i == len(mods) - 1 and not relu_last:
+                break
+            y = m(y)
+        ref = y[0].t().float()[:rows]
+    x = x[:rows].contiguous()
+    seq.float()
+    pk = fused.PackedMLP(fused.split_shared_mlp(seq), dev)
+    out = torch.full((rows, pk.dims[-1] + 4), 7.0, device=dev)
+    fused.rows_forward(pk, x.to(dev), out, relu_last=relu_last)
+    torch.testing.assert_close(out[:, :widths[-1]].cpu(), ref, rtol=1e-4, atol=1e-4)
+    assert (out[:, widths[-1]:] == 7.0).all()           # only cout columns are written
 
 
 def test_pack_cache_follows_weight_updates(dev):
