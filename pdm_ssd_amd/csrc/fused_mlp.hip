@@ -102,19 +102,15 @@ struct LdsIn {
 };
 
 // SA: virtual row = [gathered feature row (cin), xyz[nb] - centre (3), zeros]
-struct SaIn {
+template <bool PRE>
+struct SaIn;
+template <>
+struct SaIn<false> {
     const float *frow;  // feature row of this lane's neighbour (or null)
     float rx, ry, rz;
     int cin, g;
     bool vec;           // cin % 4 == 0 and 16-byte aligned rows
-    const float *zrow;  // pre-projected layer-1 row of this lane's neighbour (or null)
-    using Pre = f4;
-    __device__ __forceinline__ f4 pre_load(int mb) const {
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (zrow) v = *reinterpret_cast<const f4 *>(zrow + 16 * mb + 4 * g);
-        return v;
-    }
-    __device__ __forceinline__ f4 pre_apply(const f4 &z, f4 acc) const { return acc + z; }
+    struct Pre {};
     __device__ __forceinline__ float elem(int c) const {
         if (c < cin) return frow[c];
         const int e = c - cin;
@@ -128,36 +124,34 @@ struct SaIn {
         return v;
     }
 };
+// hoisted form: virtual row = [xyz[nb] - centre (3), zeros]; the feature block of layer 1 arrives as z[nb]
+template <>
+struct SaIn<true> {
+    const float *zrow;  // &z[b][nb][z_coff + 4g]
+    float rx, ry, rz;   // zero on lanes with g != 0
+    using Pre = f4;
+    __device__ __forceinline__ f4 pre_load(int mb) const { return *reinterpret_cast<const f4 *>(zrow + 16 * mb); }
+    __device__ __forceinline__ f4 pre_apply(const f4 &z, f4 acc) const { return acc + z; }
+    __device__ __forceinline__ f4 operator()(int kb) const {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kb == 0) { v.x = rx; v.y = ry; v.z = rz; }
+        return v;
+    }
+};
 
 // FP: virtual row = [w0*known[i0] + w1*known[i1] + w2*known[i2] (c_known), skip row (c_skip), zeros];
 // the interpolation keeps the oracle's rounding sequence fma(w2,p2, fma(w1,p1, rn(w0*p0))).
-struct FpIn {
+template <bool PRE>
+struct FpIn;
+template <>
+struct FpIn<false> {
     const float *r0, *r1, *r2, *srow;
     float w0, w1, w2;
     int ck, cs, g;
     bool vec_k, vec_s, live;
-    const float *z0, *z1, *z2;  // pre-projected layer-1 rows of the three neighbours (or null)
-    struct Pre { f4 a, b, c; };
+    struct Pre {};
     __device__ __forceinline__ float interp(float a, float b, float c) const {
         return __fmaf_rn(w2, c, __fmaf_rn(w1, b, __fmul_rn(w0, a)));
-    }
-    __device__ __forceinline__ Pre pre_load(int mb) const {
-        Pre p;
-        p.a = p.b = p.c = f4{0.f, 0.f, 0.f, 0.f};
-        if (z0 && live) {
-            const int c0 = 16 * mb + 4 * g;
-            p.a = *reinterpret_cast<const f4 *>(z0 + c0);
-            p.b = *reinterpret_cast<const f4 *>(z1 + c0);
-            p.c = *reinterpret_cast<const f4 *>(z2 + c0);
-        }
-        return p;
-    }
-    // interpolation is linear, so W (sum_k w_k f_k) = sum_k w_k (W f_k): the known-feature part of layer 1
-    // arrives already multiplied by the weights (m rows instead of n)
-    __device__ __forceinline__ f4 pre_apply(const Pre &p, f4 acc) const {
-        acc.x += interp(p.a.x, p.b.x, p.c.x); acc.y += interp(p.a.y, p.b.y, p.c.y);
-        acc.z += interp(p.a.z, p.b.z, p.c.z); acc.w += interp(p.a.w, p.b.w, p.c.w);
-        return acc;
     }
     __device__ __forceinline__ float elem(int c) const {
         if (c < ck) return interp(r0[c], r1[c], r2[c]);
@@ -178,6 +172,45 @@ struct FpIn {
         }
         if (vec_s && c0 >= ck && c0 + 4 <= ck + cs) return *reinterpret_cast<const f4 *>(srow + (c0 - ck));
         v.x = elem(c0); v.y = elem(c0 + 1); v.z = elem(c0 + 2); v.w = elem(c0 + 3);
+        return v;
+    }
+};
+// hoisted form: virtual row = [skip row (c_skip), zeros]; the known-feature block of layer 1 arrives as
+// z rows of the three neighbours.  Interpolation is linear, so W (sum_k w_k f_k) = sum_k w_k (W f_k).
+template <>
+struct FpIn<true> {
+    const float *zbase;   // &z[b][0][4g]
+    const float *srow;
+    int o0, o1, o2;       // float offsets of the three neighbours' z rows
+    float w0, w1, w2;
+    int cs, g;
+    bool vec_s, live;
+    struct Pre { f4 a, b, c; };
+    __device__ __forceinline__ float interp(float a, float b, float c) const {
+        return __fmaf_rn(w2, c, __fmaf_rn(w1, b, __fmul_rn(w0, a)));
+    }
+    __device__ __forceinline__ Pre pre_load(int mb) const {
+        Pre p;
+        p.a = p.b = p.c = f4{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            p.a = *reinterpret_cast<const f4 *>(zbase + o0 + 16 * mb);
+            p.b = *reinterpret_cast<const f4 *>(zbase + o1 + 16 * mb);
+            p.c = *reinterpret_cast<const f4 *>(zbase + o2 + 16 * mb);
+        }
+        return p;
+    }
+    __device__ __forceinline__ f4 pre_apply(const Pre &p, f4 acc) const {
+        acc.x += interp(p.a.x, p.b.x, p.c.x); acc.y += interp(p.a.y, p.b.y, p.c.y);
+        acc.z += interp(p.a.z, p.b.z, p.c.z); acc.w += interp(p.a.w, p.b.w, p.c.w);
+        return acc;
+    }
+    __device__ __forceinline__ f4 operator()(int kb) const {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!live) return v;
+        const int c0 = 16 * kb + 4 * g;
+        if (vec_s && c0 + 4 <= cs) return *reinterpret_cast<const f4 *>(srow + c0);
+        v.x = c0 < cs ? srow[c0] : 0.f; v.y = c0 + 1 < cs ? srow[c0 + 1] : 0.f;
+        v.z = c0 + 2 < cs ? srow[c0 + 2] : 0.f; v.w = c0 + 3 < cs ? srow[c0 + 3] : 0.f;
         return v;
     }
 };
@@ -425,7 +458,7 @@ __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restr
         float *ib = (L & 1) ? P : Q;  // layer 1 (staged) and layer 3 read P, layer 2 reads Q
         const int iw = (L & 1) ? d.lds_p : d.lds_q;
         const LdsTilesIn<NT> li{ib + pos * iw + 4 * g, 16 * iw};
-        if (L == 1 && PRE) {
+        if constexpr (L == 1 && PRE) {
             const StagedPreIn<T, NT> si{li, in.p};
             if (last) mlp_layer<W, NT, MAXNB, true>(nkb, nmb, wl, bl, lane, wave, relu, si, out);
             else mlp_layer<W, NT, MAXNB, true>(nkb, nmb, wl, bl, lane, wave, relu, si, lo);
@@ -437,10 +470,10 @@ __device__ __forceinline__ void run_layer(const MlpDesc &d, const float *__restr
     wg_sync<W * PSW>();
 }
 
-template <int W, int NT, int MAXNB, int PSW, class T, class Out>
+template <int W, int NT, int MAXNB, int PSW, bool PRE, class T, class Out>
 __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restrict__ wpack,
                                         const float *__restrict__ bias, float *P, float *Q, int lane,
-                                        int wave, bool pre, const TilesIn<T, NT> &in, const Out &out) {
+                                        int wave, const TilesIn<T, NT> &in, const Out &out) {
     if (d.stage_in) {
         // gather the input tiles once, K blocks dealt round-robin to the waves: P[tile*16 + pos][K0]
         float *row = P + (lane & 15) * d.lds_p + 4 * (lane >> 4);
@@ -450,8 +483,7 @@ __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restric
             for (int t = 0; t < NT; ++t) *reinterpret_cast<f4 *>(row + t * 16 * d.lds_p + 16 * kb) = in(t, kb);
         wg_sync<W * PSW>();
     }
-    if (pre) run_layer<W, NT, MAXNB, PSW, 1, true>(d, wpack, bias, P, Q, lane, wave, in, out);  // wave-uniform
-    else run_layer<W, NT, MAXNB, PSW, 1, false>(d, wpack, bias, P, Q, lane, wave, in, out);
+    run_layer<W, NT, MAXNB, PSW, 1, PRE>(d, wpack, bias, P, Q, lane, wave, in, out);
     if (d.nlayers >= 2) run_layer<W, NT, MAXNB, PSW, 2, false>(d, wpack, bias, P, Q, lane, wave, in, out);
     if (d.nlayers >= 3) run_layer<W, NT, MAXNB, PSW, 3, false>(d, wpack, bias, P, Q, lane, wave, in, out);
     if (d.nlayers >= 4) run_layer<W, NT, MAXNB, PSW, 4, false>(d, wpack, bias, P, Q, lane, wave, in, out);
@@ -461,7 +493,7 @@ __device__ __forceinline__ void run_mlp(const MlpDesc &d, const float *__restric
 // set and split each layer's output blocks; the PSW groups work on different tiles but walk the same
 // (layer, block, K) sequence, so the weight fragments one group pulls from L2 are L1 hits for the others
 // (the workgroup-wide barrier after every layer keeps them together).
-template <int W, int NT, int MAXNB, int PSW>
+template <int W, int NT, int MAXNB, int PSW, bool PRE>
 __global__ __launch_bounds__(64 * W * PSW) void sa_mlp_fused_kernel(MlpDesc d, SaArgs a,
                                                                     const float *__restrict__ wpack,
                                                                     const float *__restrict__ bias) {
@@ -483,7 +515,7 @@ __global__ __launch_bounds__(64 * W * PSW) void sa_mlp_fused_kernel(MlpDesc d, S
     for (long long base = (long long)blockIdx.x * PSW; base < nunits; base += (long long)gridDim.x * PSW) {
         const long long unit = base + grp;  // groups past the end run dead tiles so barriers still match
         for (int sub = 0; sub < nsub; ++sub) {
-            Tiles<SaIn, NT> in;
+            Tiles<SaIn<PRE>, NT> in;
             Tiles<PoolOut, NT> out;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -496,22 +528,27 @@ __global__ __launch_bounds__(64 * W * PSW) void sa_mlp_fused_kernel(MlpDesc d, S
                 const float *c3 = a.new_xyz + ctr * 3;
                 const int nb = a.idx[ctr * a.ns + tl * 16 + pos];
                 const float *p3 = a.xyz + ((size_t)b * a.n + nb) * 3;
-                in.t[t].frow = a.cin > 0 ? a.feat + ((size_t)b * a.n + nb) * a.cin : nullptr;
-                in.t[t].rx = p3[0] - c3[0]; in.t[t].ry = p3[1] - c3[1]; in.t[t].rz = p3[2] - c3[2];  // pointnet2_utils.py:252
-                in.t[t].cin = a.cin; in.t[t].g = g;
-                in.t[t].vec = (a.cin & 3) == 0 && a.cin > 0;
-                in.t[t].zrow = a.z ? a.z + ((size_t)b * a.n + nb) * a.z_stride + a.z_coff : nullptr;
+                const float rx = p3[0] - c3[0], ry = p3[1] - c3[1], rz = p3[2] - c3[2];  // pointnet2_utils.py:252
+                if constexpr (PRE) {
+                    in.t[t].zrow = a.z + ((size_t)b * a.n + nb) * a.z_stride + a.z_coff + 4 * g;
+                    in.t[t].rx = g == 0 ? rx : 0.f; in.t[t].ry = g == 0 ? ry : 0.f; in.t[t].rz = g == 0 ? rz : 0.f;
+                } else {
+                    in.t[t].frow = a.cin > 0 ? a.feat + ((size_t)b * a.n + nb) * a.cin : nullptr;
+                    in.t[t].rx = rx; in.t[t].ry = ry; in.t[t].rz = rz;
+                    in.t[t].cin = a.cin; in.t[t].g = g;
+                    in.t[t].vec = (a.cin & 3) == 0 && a.cin > 0;
+                }
                 out.t[t].pool = pool;
                 out.t[t].orow = live ? a.out + ctr * a.out_stride + a.out_coff : nullptr;
                 out.t[t].cout = a.cout; out.t[t].lane = lane; out.t[t].g = g;
                 out.t[t].first_tile = tic == 0; out.t[t].last_tile = tic == tpc - 1;
             }
-            run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, a.z != nullptr, TilesIn<SaIn, NT>{&in}, TilesOut<PoolOut, NT>{&out});
+            run_mlp<W, NT, MAXNB, PSW, PRE>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn<PRE>, NT>{&in}, TilesOut<PoolOut, NT>{&out});
         }
     }
 }
 
-template <int W, int NT, int MAXNB, int PSW>
+template <int W, int NT, int MAXNB, int PSW, bool PRE>
 __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
                                                                     const float *__restrict__ wpack,
                                                                     const float *__restrict__ bias) {
@@ -526,37 +563,44 @@ __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, F
     const long long niter = (ntiles + NT - 1) / NT;
     for (long long base = (long long)blockIdx.x * PSW; base < niter; base += (long long)gridDim.x * PSW) {
         const long long it = base + grp;
-        Tiles<FpIn, NT> in;
+        Tiles<FpIn<PRE>, NT> in;
         Tiles<RowOut, NT> out;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const long long tile = it < niter ? it * NT + t : ntiles;
             const int b = tile < ntiles ? (int)(tile / tps) : 0;
             const int p = (int)(tile - (long long)b * tps) * 16 + pos;
-            FpIn &f = in.t[t];
+            FpIn<PRE> &f = in.t[t];
             f.live = tile < ntiles && p < a.n;
             const size_t q = (size_t)b * a.n + (f.live ? p : 0);
-            f.r0 = f.r1 = f.r2 = f.z0 = f.z1 = f.z2 = nullptr;
             f.w0 = f.w1 = f.w2 = 0.0f;
-            if (a.idx) {  // null for plain rows (pdm_rows_mlp_fused)
+            f.srow = a.c_skip > 0 ? a.skip + q * a.c_skip : nullptr;
+            f.cs = a.c_skip; f.g = g;
+            if constexpr (PRE) {
                 const int *id = a.idx + q * 3;
                 const float *w = a.weight + q * 3;
-                const size_t k0 = (size_t)b * a.m + id[0], k1 = (size_t)b * a.m + id[1], k2 = (size_t)b * a.m + id[2];
+                f.zbase = a.z + (size_t)b * a.m * a.z_stride + 4 * g;
+                f.o0 = id[0] * a.z_stride; f.o1 = id[1] * a.z_stride; f.o2 = id[2] * a.z_stride;
                 f.w0 = w[0]; f.w1 = w[1]; f.w2 = w[2];
-                if (a.z) {
-                    f.z0 = a.z + k0 * a.z_stride; f.z1 = a.z + k1 * a.z_stride; f.z2 = a.z + k2 * a.z_stride;
-                } else {
-                    f.r0 = a.known + k0 * a.c_known; f.r1 = a.known + k1 * a.c_known; f.r2 = a.known + k2 * a.c_known;
+                f.vec_s = (a.c_skip & 3) == 0 && a.c_skip > 0;
+            } else {
+                f.r0 = f.r1 = f.r2 = nullptr;
+                if (a.idx) {  // null for plain rows (pdm_rows_mlp_fused)
+                    const int *id = a.idx + q * 3;
+                    const float *w = a.weight + q * 3;
+                    f.r0 = a.known + ((size_t)b * a.m + id[0]) * a.c_known;
+                    f.r1 = a.known + ((size_t)b * a.m + id[1]) * a.c_known;
+                    f.r2 = a.known + ((size_t)b * a.m + id[2]) * a.c_known;
+                    f.w0 = w[0]; f.w1 = w[1]; f.w2 = w[2];
                 }
+                f.ck = a.c_known;
+                f.vec_k = (a.c_known & 3) == 0;
+                f.vec_s = (a.c_skip & 3) == 0 && (a.c_known & 3) == 0 && a.c_skip > 0;
             }
-            f.srow = a.c_skip > 0 ? a.skip + q * a.c_skip : nullptr;
-            f.ck = a.c_known; f.cs = a.c_skip; f.g = g;
-            f.vec_k = (a.c_known & 3) == 0;
-            f.vec_s = (a.c_skip & 3) == 0 && (a.c_known & 3) == 0 && a.c_skip > 0;
             out.t[t].orow = f.live ? a.out + q * a.out_stride : nullptr;
             out.t[t].cout = a.cout; out.t[t].g = g;
         }
-        run_mlp<W, NT, MAXNB, PSW>(d, wpack, bias, P, Q, lane, wave, a.z != nullptr, TilesIn<FpIn, NT>{&in}, TilesOut<RowOut, NT>{&out});
+        run_mlp<W, NT, MAXNB, PSW, PRE>(d, wpack, bias, P, Q, lane, wave, TilesIn<FpIn<PRE>, NT>{&in}, TilesOut<RowOut, NT>{&out});
     }
 }
 
@@ -628,15 +672,20 @@ extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_
 extern "C" int pdm_tune_fused_groups(int n) { const int old = g_fused_groups; g_fused_groups = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0; return old; }
 extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = t; return old; }  // kept for ABI stability; no effect
 
-#define FUSED_LAUNCH1(KERNEL, W, G, blocks, lds_bytes, ...)                                                   \
+#define FUSED_LAUNCH2(KERNEL, W, G, PRE, blocks, lds_bytes, ...)                                              \
     do {                                                                                                       \
         constexpr int MAXNB = (W <= 2) ? 2 : 4; /* narrow layers: fewer registers, more waves in flight */     \
-        if (NT == 2 && W >= 4 && G == 1) /* experiment: two tiles share each weight fragment */                \
-            hipLaunchKernelGGL((KERNEL<(W >= 4 ? W : 4), 2, 2, 1>), dim3(blocks), dim3(64 * W * G), lds_bytes, \
-                               as_stream(stream), __VA_ARGS__);                                                \
+        if (NT == 2 && W >= 4 && G == 1) /* two tiles share each weight fragment */                            \
+            hipLaunchKernelGGL((KERNEL<(W >= 4 ? W : 4), 2, 2, 1, PRE>), dim3(blocks), dim3(64 * W * G),       \
+                               lds_bytes, as_stream(stream), __VA_ARGS__);                                     \
         else                                                                                                   \
-            hipLaunchKernelGGL((KERNEL<W, 1, MAXNB, G>), dim3(blocks), dim3(64 * W * G), lds_bytes,           \
+            hipLaunchKernelGGL((KERNEL<W, 1, MAXNB, G, PRE>), dim3(blocks), dim3(64 * W * G), lds_bytes,       \
                                as_stream(stream), __VA_ARGS__);                                                \
+    } while (0)
+#define FUSED_LAUNCH1(KERNEL, W, G, blocks, lds_bytes, ...)                                                   \
+    do {                                                                                                       \
+        if (pre_form) FUSED_LAUNCH2(KERNEL, W, G, true, blocks, lds_bytes, __VA_ARGS__);                       \
+        else FUSED_LAUNCH2(KERNEL, W, G, false, blocks, lds_bytes, __VA_ARGS__);                               \
     } while (0)
 
 // (W channel-split waves, G position groups), W * G <= 8; NT = 1 (NT = 2 measured no faster)
@@ -683,6 +732,7 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
                     (cin % 4 != 0 || (reinterpret_cast<uintptr_t>(feat_pm) & 15) == 0),
                 PDM_E_BADARG, "sa_mlp_fused: out/wpack/bias/feat must be 16-byte aligned, out_stride and out_coff multiples of 4");
     SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout, z_pm, z_stride, z_coff};
+    const bool pre_form = z_pm != nullptr;
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const int tpc_ = nsample / 16;
@@ -743,6 +793,8 @@ static int fp_fused_launch(void *stream, int mode, int relu_last, int b, int n, 
                     (c_skip % 4 != 0 || c_skip == 0 || (reinterpret_cast<uintptr_t>(skip_pm) & 15) == 0),
                 PDM_E_BADARG, "fp_mlp_fused: buffers must be 16-byte aligned and out_stride a multiple of 4");
     FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout, mode == 1 ? z_pm : nullptr, z_stride};
+    const bool pre_form = mode == 1;
+    PDM_REQUIRE(!pre_form || (long long)m * z_stride < (1ll << 31), PDM_E_TOOLARGE, "fp_mlp_fused_pre: m * z_stride overflows 32-bit row offsets");
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const long long niter = ((ntiles + NT - 1) / NT + G - 1) / G;
