@@ -21,6 +21,9 @@
 // one contiguous row.  Max-pool over nsample = DPP row-max over the 16 lanes that share g.
 #include "common.h"
 
+#include <mutex>
+#include <set>
+
 namespace pdm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -70,8 +73,11 @@ __device__ __forceinline__ f4 mfma4(f4 acc, f4 a, f4 b) {
     return acc;
 }
 
-__device__ __forceinline__ f4 relu4(f4 v) {
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+// max(v, floor) as one v_med3_f32 (fmaxf() costs a canonicalising v_max v,v,v on top; inline asm would hide the
+// MFMA -> VALU read hazard from the compiler).  floor = 0 for ReLU, -inf for a linear last layer.
+__device__ __forceinline__ float max1(float v, float floor) { return __builtin_amdgcn_fmed3f(v, floor, __builtin_inff()); }
+__device__ __forceinline__ f4 floor4(f4 v, float floor) {
+    v.x = max1(v.x, floor); v.y = max1(v.y, floor); v.z = max1(v.z, floor); v.w = max1(v.w, floor);
     return v;
 }
 
@@ -90,6 +96,25 @@ __device__ __forceinline__ float row16_max_nonneg(float f) {
         "s_nop 1"
         : "+v"(v));
     return __builtin_bit_cast(float, v);
+}
+
+// the same for four values at once: the four chains are interleaved so each DPP read of a just-written VGPR
+// is three instructions behind its producer (the 2-wait-state hazard is covered without s_nops)
+__device__ __forceinline__ f4 row16_max_nonneg4(f4 f) {
+    // (copies first: __builtin_bit_cast applied to an ext-vector element lvalue reads element 0 for every lane)
+    const float fx = f.x, fy = f.y, fz = f.z, fw = f.w;
+    int a = __float_as_int(fx), b = __float_as_int(fy), c = __float_as_int(fz), d = __float_as_int(fw);
+#define PDM_DPP4(CTRL)                                                        \
+    "v_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_max_i32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_max_i32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t" PDM_DPP4("quad_perm:[1,0,3,2]") PDM_DPP4("quad_perm:[2,3,0,1]")
+                 PDM_DPP4("row_half_mirror") PDM_DPP4("row_mirror") "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef PDM_DPP4
+    f.x = __int_as_float(a); f.y = __int_as_float(b); f.z = __int_as_float(c); f.w = __int_as_float(d);
+    return f;
 }
 
 // ---- B-operand providers: float4 of channels [16kb + 4g, +4) of this lane's position ------------
@@ -231,8 +256,7 @@ struct PoolOut {
     int cout, lane, g;
     bool first_tile, last_tile;
     __device__ __forceinline__ void operator()(int mb, f4 v) const {
-        v.x = row16_max_nonneg(v.x); v.y = row16_max_nonneg(v.y);
-        v.z = row16_max_nonneg(v.z); v.w = row16_max_nonneg(v.w);
+        v = row16_max_nonneg4(v);
         if ((lane & 15) != 0 || !orow) return;
         float *p = pool + 16 * mb + 4 * g;
         if (!first_tile) {
@@ -327,6 +351,7 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
                                          const Out &out) {
     const f4 *__restrict__ wb[NB];
     f4 acc[NB][NT], a[NB], an[NB], b[NT], bn[NT];
+    const float floor = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(relu ? 0 : (int)0xff800000u));
     // pre-projected part of the first layer: requested first, consumed after the K loop
     typename In::Pre z[PRE ? NB : 1][PRE ? NT : 1];
     if constexpr (PRE) {
@@ -400,7 +425,7 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
         for (int t = 0; t < NT; ++t) {
             f4 v = acc[i][t];
             if constexpr (PRE) v = in.pre_apply(t, z[i][t], v);
-            out(t, mb + i, relu ? relu4(v) : v);
+            out(t, mb + i, floor4(v, floor));
         }
 }
 
@@ -607,6 +632,7 @@ __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, F
 static int g_fused_waves = 0;
 static int g_fused_tiles = 0;
 static int g_fused_groups = 0;      // 0 = auto
+static int g_fused_lds_cap = 152 * 1024;  // two-tile form allowed up to this much LDS per workgroup (CU has 160 KB)
 static int g_fused_wg_per_cu = 32;  // grid cap = 256 CUs x this many workgroups (grid-stride loop beyond)
 
 static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max, int pool_floats,
@@ -645,7 +671,7 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     // (heavier input provider), so SA only; knob: 1 forces one tile, 2 forces two where instantiated
     int NT = (W >= 4 && (g_fused_tiles == 2 || (g_fused_tiles == 0 && pool_floats > 0))) ? 2 : 1;
     (void)ntiles;
-    if ((NT * 16 * (p + 4 + q + 4) + pool_floats) * 4 > 64 * 1024) NT = 1;
+    if ((NT * 16 * (p + 4 + q + 4) + pool_floats) * 4 > g_fused_lds_cap) NT = 1;
     *tiles_per_wg = NT;
     const int budget = (W == 1 ? 20 : W == 2 ? 40 : W == 4 ? 52 : 64) * 1024;
     d.stage_in = (NT * 16 * (p_staged + 4 + q + 4) + pool_floats) * 4 <= budget ? 1 : 0;
@@ -668,6 +694,16 @@ using namespace pdm;
 // Tuning knob (not part of the reference-facing ABI): force the waves-per-workgroup choice (0 = auto).
 extern "C" int pdm_tune_fused_waves(int w) { const int old = g_fused_waves; g_fused_waves = (w == 1 || w == 2 || w == 4 || w == 8) ? w : 0; return old; }
 
+// more than 64 KB of dynamic LDS has to be granted per kernel function (once)
+static void allow_lds(const void *fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::set<const void *> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(fn)) return;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) done.insert(fn);
+}
+extern "C" int pdm_tune_fused_lds_cap(int bytes) { const int old = g_fused_lds_cap; if (bytes >= 16 * 1024 && bytes <= 160 * 1024) g_fused_lds_cap = bytes; return old; }
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
 extern "C" int pdm_tune_fused_groups(int n) { const int old = g_fused_groups; g_fused_groups = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0; return old; }
 extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = t; return old; }  // kept for ABI stability; no effect
@@ -675,12 +711,15 @@ extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fu
 #define FUSED_LAUNCH2(KERNEL, W, G, PRE, blocks, lds_bytes, ...)                                              \
     do {                                                                                                       \
         constexpr int MAXNB = (W <= 2) ? 2 : 4; /* narrow layers: fewer registers, more waves in flight */     \
-        if (NT == 2 && W >= 4 && G == 1) /* two tiles share each weight fragment */                            \
+        if (NT == 2 && W >= 4 && G == 1) { /* two tiles share each weight fragment */                          \
+            allow_lds(reinterpret_cast<const void *>(&KERNEL<(W >= 4 ? W : 4), 2, 2, 1, PRE>), lds_bytes);     \
             hipLaunchKernelGGL((KERNEL<(W >= 4 ? W : 4), 2, 2, 1, PRE>), dim3(blocks), dim3(64 * W * G),       \
                                lds_bytes, as_stream(stream), __VA_ARGS__);                                     \
-        else                                                                                                   \
+        } else {                                                                                               \
+            allow_lds(reinterpret_cast<const void *>(&KERNEL<W, 1, MAXNB, G, PRE>), lds_bytes);                \
             hipLaunchKernelGGL((KERNEL<W, 1, MAXNB, G, PRE>), dim3(blocks), dim3(64 * W * G), lds_bytes,       \
                                as_stream(stream), __VA_ARGS__);                                                \
+        }                                                                                                      \
     } while (0)
 #define FUSED_LAUNCH1(KERNEL, W, G, blocks, lds_bytes, ...)                                                   \
     do {                                                                                                       \
@@ -734,7 +773,7 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
     SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout, z_pm, z_stride, z_coff};
     const bool pre_form = z_pm != nullptr;
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
-    PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const int tpc_ = nsample / 16;
     const long long units_ = tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
     const long long niter = (units_ + G - 1) / G;
@@ -796,7 +835,7 @@ static int fp_fused_launch(void *stream, int mode, int relu_last, int b, int n, 
     const bool pre_form = mode == 1;
     PDM_REQUIRE(!pre_form || (long long)m * z_stride < (1ll << 31), PDM_E_TOOLARGE, "fp_mlp_fused_pre: m * z_stride overflows 32-bit row offsets");
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
-    PDM_REQUIRE(lds_bytes <= 64 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const long long niter = ((ntiles + NT - 1) / NT + G - 1) / G;
     const long long cap = (long long)256 * g_fused_wg_per_cu;
     const int blocks = (int)(niter < cap ? niter : cap);
