@@ -119,6 +119,11 @@ size_t pdm_three_nn_grid_workspace_bytes(int b, int m);
 int pdm_three_nn_grid(void *stream, int b, int n, int m, const float *unknown, const float *known,
                       float *dist2, int *idx, void *workspace, size_t workspace_bytes);
 
+/* The reference's python glue between three_nn and three_interpolate in one launch: dist = sqrt(dist2)
+ * (pointnet2_utils.py:98; optional, NULL to skip), weight = (1/(dist+1e-8)) / sum_k (1/(dist_k+1e-8))
+ * (pointnet2_modules.py:154-156), same correctly-rounded fp32 operations in the same order.  rows = B*n. */
+int pdm_three_nn_weights(void *stream, long long rows, const float *dist2, float *dist, float *weight);
+
 /* The gather half of the above for a given idx (B,M,nsample): grouped xyz minus centre, grouped
  * features, concatenated on the channel axis -> out (B, 3+C, M, nsample)
  * (pointnet2_utils.py:250-257: two grouping_operation calls, the in-place subtract and torch.cat). */

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "pdm_group_concat": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
+    "pdm_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused_pre": [_i] * 4 + [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i],

@@ -111,9 +111,33 @@ __global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_kernel(
     }
 }
 
+// dist2 (rows,3) -> weight (rows,3): the reference's python glue after three_nn, in one pass and with the same
+// correctly-rounded operations in the same order (pointnet2_utils.py:98 sqrt; pointnet2_modules.py:154-156).
+__global__ __launch_bounds__(256) void three_nn_weights_kernel(long long rows, const float *__restrict__ dist2,
+                                                              float *__restrict__ dist, float *__restrict__ weight) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float d0 = __fsqrt_rn(dist2[r * 3 + 0]), d1 = __fsqrt_rn(dist2[r * 3 + 1]), d2 = __fsqrt_rn(dist2[r * 3 + 2]);
+    const float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f)), r1 = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f)),
+                r2 = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+    const float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+    weight[r * 3 + 0] = __fdiv_rn(r0, norm); weight[r * 3 + 1] = __fdiv_rn(r1, norm); weight[r * 3 + 2] = __fdiv_rn(r2, norm);
+    if (dist) { dist[r * 3 + 0] = d0; dist[r * 3 + 1] = d1; dist[r * 3 + 2] = d2; }
+}
+
 }  // namespace pdm
 
 using namespace pdm;
+
+extern "C" int pdm_three_nn_weights(void *stream, long long rows, const float *dist2, float *dist, float *weight) {
+    PDM_REQUIRE(rows >= 0, PDM_E_BADARG, "three_nn_weights: negative size");
+    if (rows == 0) return 0;
+    PDM_REQUIRE(dist2 && weight, PDM_E_BADARG, "three_nn_weights: null pointer");
+    PDM_REQUIRE(rows <= 0x7fffffffll * 256, PDM_E_TOOLARGE, "three_nn_weights: too many rows");
+    hipLaunchKernelGGL(three_nn_weights_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), rows,
+                       dist2, dist, weight);
+    return check_launch("three_nn_weights");
+}
 
 extern "C" int pdm_three_nn(void *stream, int b, int n, int m, const float *unknown,
                             const float *known, float *dist2, int *idx) {

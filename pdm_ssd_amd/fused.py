@@ -158,6 +158,19 @@ def cached_pack(owner, slot, seq, device, in_perm=None):
     return packed
 
 
+def cached_layers(owner, slot, key_module, layers_fn, device):
+    """PackedMLP of layers_fn() (a list of (conv, bn|None)), cached on `owner` under `slot` and rebuilt when any
+    tensor of `key_module` changed."""
+    cache = owner.__dict__.setdefault('_pdm_fused_cache', {})
+    key = (_state_key(key_module), str(device))
+    hit = cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = PackedMLP(layers_fn(), device)
+    cache[slot] = (key, packed)
+    return packed
+
+
 def cached_pre_packs(owner, slot, seqs, device, pre_cols, keep_cols, min_in=0):
     """(PackedPre over the first layers of `seqs` restricted to `pre_cols`, [PackedMLP of each seq with only
     `keep_cols` left in its first layer]); cached on `owner`; None when a seq is not a [conv, bn, relu]* chain."""

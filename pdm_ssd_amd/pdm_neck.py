@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import pdm_ops
+from . import fused, pdm_ops
 
 
 def _get(cfg, key, default=None):
@@ -55,8 +55,19 @@ class PDMNeck(nn.Module):
     def forward(self, batch_dict):
         xyz = batch_dict['sa_xyz'][self.source_layer]            # (B, P, 3)
         src = batch_dict['sa_features'][self.source_layer]       # (B, Cin, P)
-        feat = self.proj(src).transpose(1, 2).contiguous()       # (B, P, C)
-        co = self.coef(src).transpose(1, 2)                      # (B, P, nsh+1)
+        infer = not self.training and not torch.is_grad_enabled() and src.is_cuda and src.dtype == torch.float32
+        if infer and self.feature_dim % 4 == 0 and getattr(self, 'use_fused', True):
+            # the two 1x1 convolutions as per-row MLPs on the point-major rows (BN folded; no transposes)
+            src_pm = src.transpose(1, 2).contiguous()            # free when src is a view of (B, P, Cin) storage
+            pk = fused.cached_pack(self, 'proj', self.proj, src.device)
+            pc = fused.cached_layers(self, 'coef', self.coef, lambda: [(self.coef, None)], src.device)
+            feat = torch.empty((src_pm.shape[0], src_pm.shape[1], self.feature_dim), dtype=torch.float32, device=src.device)
+            fused.rows_forward(pk, src_pm, feat, relu_last=True)
+            co = torch.empty((src_pm.shape[0], src_pm.shape[1], pc.dims[-1]), dtype=torch.float32, device=src.device)
+            fused.rows_forward(pc, src_pm, co, relu_last=False)
+        else:
+            feat = self.proj(src).transpose(1, 2).contiguous()   # (B, P, C)
+            co = self.coef(src).transpose(1, 2)                  # (B, P, nsh+1)
         sh = co[..., :self.nsh].contiguous()
         sigma = F.softplus(co[..., self.nsh]) + self.sigma_min
         inv2s2 = (0.5 / (sigma * sigma)).contiguous()

@@ -125,6 +125,15 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     _run("pdm_three_nn", unknown, b, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(), idx.data_ptr())
 
 
+def three_nn_weights_wrapper(rows, dist2, dist, weight):
+    """Not in the reference extension (its python glue does this with five torch ops)."""
+    _check("dist2", dist2, torch.float32); _check("weight", weight, torch.float32)
+    _numel_at_least("dist2", dist2, rows * 3); _numel_at_least("weight", weight, rows * 3)
+    if dist is not None:
+        _check("dist", dist, torch.float32); _numel_at_least("dist", dist, rows * 3)
+    _run("pdm_three_nn_weights", dist2, rows, dist2.data_ptr(), 0 if dist is None else dist.data_ptr(), weight.data_ptr())
+
+
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     _check("points", points, torch.float32); _check("idx", idx, torch.int32)
     _check("weight", weight, torch.float32); _check("out", out, torch.float32)

@@ -166,11 +166,15 @@ class PointnetFPModule(nn.Module):
         result is a (B,C,n) VIEW of point-major (B,n,C) storage.
         """
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown.contiguous(), known.contiguous())
-            dist_recip = 1.0 / (dist + 1e-8)  # ref :154
-            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            if not (self.training or torch.is_grad_enabled()) and getattr(self, 'use_fused', True) \
-                    and known_feats.is_cuda and known_feats.dtype == torch.float32:
+            fused_ok = not (self.training or torch.is_grad_enabled()) and getattr(self, 'use_fused', True) \
+                and known_feats.is_cuda and known_feats.dtype == torch.float32
+            if fused_ok:
+                idx, weight = pointnet2_utils.three_nn_weights(unknown, known)   # ref :153-156 in two launches
+            else:
+                dist, idx = pointnet2_utils.three_nn(unknown.contiguous(), known.contiguous())
+                dist_recip = 1.0 / (dist + 1e-8)  # ref :154
+                weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            if fused_ok:
                 pk = fused.cached_pack(self, 0, self.mlp, known_feats.device)
                 cs = 0 if unknow_feats is None else unknow_feats.shape[1]
                 if pk is not None and pk.cin == known_feats.shape[1] + cs and pk.cout % 4 == 0:

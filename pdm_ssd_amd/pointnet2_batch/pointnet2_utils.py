@@ -107,6 +107,19 @@ class ThreeNN(Function):
 three_nn = ThreeNN.apply
 
 
+def three_nn_weights(unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(idx (B,n,3) int32, weight (B,n,3)) = three_nn followed by the inverse-distance weighting of
+    ref pointnet2_modules.py:154-156 (dist_recip = 1/(dist+1e-8), normalised), in two launches; no gradient."""
+    unknown, known = unknown.float().contiguous(), known.float().contiguous()
+    B, N, _ = unknown.size()
+    dist2 = _new(unknown, (B, N, 3), torch.float32)
+    idx = _new(unknown, (B, N, 3), torch.int32)
+    pointnet2.three_nn_wrapper(B, N, known.size(1), unknown, known, dist2, idx)
+    weight = torch.empty_like(dist2)
+    pointnet2.three_nn_weights_wrapper(B * N, dist2, None, weight)
+    return idx, weight
+
+
 class ThreeInterpolate(Function):
     """ref pointnet2_utils.py:108-150 — features (B,C,M), idx/weight (B,n,3) -> (B,C,n)."""
 

@@ -415,3 +415,20 @@ def test_fps_multi_workgroup_equals_stream_kernel(dev):
     _native.call("pdm_furthest_point_sampling", torch.cuda.current_stream().cuda_stream, 1, 30000, 200,
                  xyz.data_ptr(), temp.data_ptr(), idx.data_ptr())
     assert torch.equal(a, idx)
+
+
+def test_three_nn_weights_matches_reference_glue(dev):
+    """pdm_three_nn_weights == the reference's python glue (sqrt, 1/(d+1e-8), normalise), same fp32 operations."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    torch.manual_seed(0)
+    unknown = (torch.rand(3, 1000, 3, device=dev) * 20).contiguous()
+    known = unknown[:, ::7].contiguous()                       # some unknown points coincide with a known one (d = 0)
+    dist, idx = pu.three_nn(unknown, known)
+    dist_recip = 1.0 / (dist + 1e-8)
+    ref = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+    idx2, w = pu.three_nn_weights(unknown, known)
+    assert torch.equal(idx, idx2)
+    torch.testing.assert_close(w, ref, rtol=1e-6, atol=1e-7)
+    assert torch.isfinite(w).all() and torch.allclose(w.sum(-1), torch.ones_like(w[..., 0]), atol=1e-6)
+    e_idx, e_w = pu.three_nn_weights(unknown[:, :0].contiguous(), known)
+    assert e_idx.shape == (3, 0, 3) and e_w.shape == (3, 0, 3)

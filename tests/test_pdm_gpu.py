@@ -131,7 +131,9 @@ def test_neck_eval_gather_equals_scatter_path(dev):
     bd = {'sa_xyz': [None, T(xyz, dev)], 'sa_features': [None, T(feat, dev).transpose(1, 2).contiguous()]}
     with torch.no_grad():
         a = neck(dict(bd))
+        assert neck._pdm_fused_cache['proj'][1] is not None and neck._pdm_fused_cache['coef'][1] is not None
         neck.use_gather = False
+        neck.use_fused = False     # torch Conv1d/BatchNorm1d for the projection and coefficient heads
         b = neck(dict(bd))
     assert a['spatial_features'].shape == b['spatial_features'].shape == (3, 128, 200, 176)
     sa, sb = a['spatial_features'], b['spatial_features']
