@@ -345,7 +345,7 @@ struct TilesOut {
 // round-robin over the NB*NT independent accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40
 // cycles, the pipe issues one per 32); the next K block's fragments are requested before the current
 // block's MFMAs.
-template <int NB, int NT, bool PRE, class In, class Out>
+template <int NB, int NT, bool PRE, bool PP, class In, class Out>
 __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__ w, size_t bstride,
                                          const float *__restrict__ bias, int g, bool relu, const In &in,
                                          const Out &out) {
@@ -360,6 +360,7 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
 #pragma unroll
             for (int t = 0; t < NT; ++t) z[i][t] = in.pre_load(t, mb + i);
     }
+    if constexpr (!PP) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         wb[i] = w + (size_t)(mb + i) * bstride;
@@ -419,6 +420,56 @@ __device__ __forceinline__ void mlp_pass(int nkb, int mb, const f4 *__restrict__
             for (int t = 0; t < NT; ++t)
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[t].w, acc[i][t], 0, 0, 0);
     }
+    } else {
+    // K loop unrolled by two over two fixed fragment sets (no register rotation): the set a k-block has just
+    // consumed is refilled for k-block + 2 right behind its MFMAs, so every fragment load has the MFMAs of two
+    // k-blocks (8 * NB * NT of them) to land in.
+    f4 a1[NB], b1[NT];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        wb[i] = w + (size_t)(mb + i) * bstride;
+        const f4 bi = *reinterpret_cast<const f4 *>(bias + 16 * (mb + i) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = bi;
+        a[i] = wb[i][0];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = in(t, 0);
+    if (nkb > 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b1[t] = in(t, 1);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) a1[i] = wb[i][64];
+    }
+#define PDM_MFMA_BLOCK(A, B)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int t = 0; t < NT; ++t)          \
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i].x, B[t].x, acc[i][t], 0, 0, 0);              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int t = 0; t < NT; ++t)          \
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i].y, B[t].y, acc[i][t], 0, 0, 0);              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int t = 0; t < NT; ++t)          \
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i].z, B[t].z, acc[i][t], 0, 0, 0);              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int t = 0; t < NT; ++t)          \
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i].w, B[t].w, acc[i][t], 0, 0, 0);
+    int kb = 0;
+    for (; kb + 2 <= nkb; kb += 2) {
+        PDM_MFMA_BLOCK(a, b)
+        if (kb + 2 < nkb) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[t] = in(t, kb + 2);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) a[i] = wb[i][(size_t)(kb + 2) * 64];
+        }
+        PDM_MFMA_BLOCK(a1, b1)
+        if (kb + 3 < nkb) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b1[t] = in(t, kb + 3);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) a1[i] = wb[i][(size_t)(kb + 3) * 64];
+        }
+    }
+    if (kb < nkb) { PDM_MFMA_BLOCK(a, b) }
+#undef PDM_MFMA_BLOCK
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -444,12 +495,17 @@ __device__ __forceinline__ void mlp_layer(int nkb, int nmb, const float *__restr
     const int bpp = (share + passes - 1) / passes;        // blocks per pass, 1..MAXNB
     const f4 *__restrict__ w = reinterpret_cast<const f4 *>(wp) + lane;
     const size_t bstride = (size_t)nkb * 64;              // f4 elements between consecutive blocks
+#if defined(FUSED_DIAG)
+    constexpr bool PP = false;
+#else
+    constexpr bool PP = W >= 4;  // wide layers: two-set K loop (measured: SA3 -10 %, SA4 -3 %; narrow layers +3 %)
+#endif
     for (int mb = mb_begin; mb < mb_end; mb += bpp) {
         const int nb = min(bpp, mb_end - mb);             // wave-uniform
-        if (MAXNB >= 4 && nb == 4) mlp_pass<4, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
-        else if (MAXNB >= 3 && nb == 3) mlp_pass<3, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
-        else if (MAXNB >= 2 && nb == 2) mlp_pass<2, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
-        else mlp_pass<1, NT, PRE>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        if (MAXNB >= 4 && nb == 4) mlp_pass<4, NT, PRE, PP>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        else if (MAXNB >= 3 && nb == 3) mlp_pass<3, NT, PRE, PP>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        else if (MAXNB >= 2 && nb == 2) mlp_pass<2, NT, PRE, PP>(nkb, mb, w, bstride, bias, g, relu, in, out);
+        else mlp_pass<1, NT, PRE, PP>(nkb, mb, w, bstride, bias, g, relu, in, out);
     }
 }
 
@@ -636,7 +692,7 @@ static int g_fused_lds_cap = 152 * 1024;  // two-tile form allowed up to this mu
 static int g_fused_wg_per_cu = 32;  // grid cap = 256 CUs x this many workgroups (grid-stride loop beyond)
 
 static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, int k0_real_max, int pool_floats,
-                     long long ntiles, int *waves, int *tiles_per_wg, int *groups) {
+                     long long ntiles, int *waves, int *tiles_per_wg, int *groups, bool two_tiles) {
     PDM_REQUIRE(nlayers >= 1 && nlayers <= FM_MAXL, PDM_E_BADARG, "%s: nlayers=%d not in [1,%d]", who, nlayers, FM_MAXL);
     PDM_REQUIRE(dims, PDM_E_BADARG, "%s: null dims", who);
     d.nlayers = nlayers;
@@ -667,9 +723,10 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     const int p_staged = p > d.K[0] ? p : d.K[0];
     // two 16-position tiles per workgroup share every weight fragment (half the A traffic, twice the MFMA
     // work per pass); keep one when the problem has few tiles or the LDS tiles would not fit 64 KB
-    // two tiles per group share each weight fragment: measured -5 % on the wide SA layers, +8 % on FP
-    // (heavier input provider), so SA only; knob: 1 forces one tile, 2 forces two where instantiated
-    int NT = (W >= 4 && (g_fused_tiles == 2 || (g_fused_tiles == 0 && pool_floats > 0))) ? 2 : 1;
+    // two tiles per group share each weight fragment: measured -5 % on the wide SA layers, -7..-18 % on the
+    // hoisted FP form, +8 % on the unhoisted FP form (heavier input provider) and up to 2x slower on plain rows
+    // (few tiles); knob: 1 forces one tile, 2 forces two where instantiated
+    int NT = (W >= 4 && (g_fused_tiles == 2 || (g_fused_tiles == 0 && two_tiles))) ? 2 : 1;
     (void)ntiles;
     if ((NT * 16 * (p + 4 + q + 4) + pool_floats) * 4 > g_fused_lds_cap) NT = 1;
     *tiles_per_wg = NT;
@@ -756,7 +813,7 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
     int W = 1, NT = 1, G = 1;
     const long long sa_tiles = (long long)b * m * (nsample / 16);
     int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3,
-                       dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, sa_tiles, &W, &NT, &G);
+                       dims ? dims[nlayers > 0 && nlayers <= FM_MAXL ? nlayers : 0] : 0, sa_tiles, &W, &NT, &G, true);
     if (rc) return rc;
     if (z_pm) {
         d.stage_in = 0;  // layer-1 input is the lane's own xyz offset: nothing to stage
@@ -819,7 +876,7 @@ static int fp_fused_launch(void *stream, int mode, int relu_last, int b, int n, 
     MlpDesc d;
     int W = 1, NT = 1, G = 1;
     const long long ntiles = (long long)b * ((n + 15) / 16);
-    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, ntiles, &W, &NT, &G);
+    int rc = fill_desc("fp_mlp_fused", d, nlayers, dims, c_known + c_skip, 0, ntiles, &W, &NT, &G, mode == 1);
     if (rc) return rc;
     d.relu_last = relu_last ? 1 : 0;
     if (mode == 1)

@@ -27,7 +27,7 @@ def measure(reps=3):
         out.append((recs[i][0], sum(recs[i + k * per][1] for k in range(reps)) / reps))
     return out
 
-settings = [dict(kv.split("=") for kv in arg.split(",")) for arg in sys.argv[1:]] or [{}]
+settings = [dict(kv.split("=") for kv in arg.split(",") if kv != "default") for arg in sys.argv[1:]] or [{}]
 cols = []
 for st in settings:
     for k, v in st.items():
