@@ -738,7 +738,9 @@ static int fill_desc(const char *who, MlpDesc &d, int nlayers, const int *dims, 
     d.pool_floats = pool_floats;
     // position-split groups per workgroup: as many as fit 8 waves and 64 KB of LDS
     const int region_bytes = (NT * 16 * (d.lds_p + d.lds_q) + pool_floats) * 4;
-    int G = NT == 2 ? 1 : (g_fused_groups > 0 ? g_fused_groups : 8);
+    // measured per launch (tools/diag/fused_calls.py): small workgroups win — W = 1: 1 group, W = 2: 2 groups
+    // (FP1 -18 %, first rows call -15 % against 4), wide layers indifferent
+    int G = NT == 2 ? 1 : (g_fused_groups > 0 ? g_fused_groups : W == 2 ? 2 : 1);
     while (G > 1 && (G * W > 8 || (long long)G * region_bytes > 64 * 1024 || (long long)G * NT * 4 > ntiles)) G >>= 1;
     *groups = G;
     return 0;
