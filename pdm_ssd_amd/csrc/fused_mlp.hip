@@ -685,6 +685,176 @@ __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, F
     }
 }
 
+
+// Register-resident form for small SA scales (input <= 16 channels, three layers of at most 64 outputs — SA1 of
+// PointNet2MSG): one wave = one pair of 16-position tiles, ALL weight fragments live in VGPRs for the whole kernel
+// (B1 + B2*B1 + B3*B2 float4 per lane), and because a wave owns every output block of its tiles the bias+ReLU'd
+// accumulator of block mb IS the next layer's B fragment of k-block mb: no LDS, no barriers, no weight traffic
+// after the first instruction — per tile only the index/neighbour gather, the MFMA chain and the DPP max-pool.
+template <int B1, int B2, int B3, bool SAME>   // SAME: nsample >= 32, the two tiles of a step share their centre
+__global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *__restrict__ wpack,
+                                                         const float *__restrict__ bias) {
+    constexpr int NT = 2;
+    const int lane = threadIdx.x & 63, pos = lane & 15, g = lane >> 4;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const f4 *__restrict__ w1 = reinterpret_cast<const f4 *>(wpack) + lane;
+    const f4 *__restrict__ w2 = w1 + 64 * B1;            // layer 1: B1 blocks x 1 k-block x 64 lanes
+    const f4 *__restrict__ w3 = w2 + 64 * B2 * B1;
+    f4 A1[B1], A2[B2][B1], A3[B3][B2];
+#pragma unroll
+    for (int mb = 0; mb < B1; ++mb) A1[mb] = w1[64 * mb];
+#pragma unroll
+    for (int mb = 0; mb < B2; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < B1; ++kb) A2[mb][kb] = w2[64 * (mb * B1 + kb)];
+#pragma unroll
+    for (int mb = 0; mb < B3; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < B2; ++kb) A3[mb][kb] = w3[64 * (mb * B2 + kb)];
+    const float *__restrict__ bias1 = bias + 4 * g, *__restrict__ bias2 = bias1 + 16 * B1, *__restrict__ bias3 = bias2 + 16 * B2;
+    const int tpc = a.ns >> 4;
+    const long long ncentres = (long long)a.b * a.m;
+    const int cpu_ = tpc >= NT ? 1 : NT / tpc;          // centres per unit
+    const int nsub = tpc >= NT ? (tpc + NT - 1) / NT : 1;
+    const long long nunits = (ncentres + cpu_ - 1) / cpu_;
+#define PDM_CHAIN(ACC, A, B)                                                          \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, ACC, 0, 0, 0);           \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, ACC, 0, 0, 0);           \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, ACC, 0, 0, 0);           \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, ACC, 0, 0, 0);
+    // Flattened (unit, sub-step) sequence of this wave; the neighbour indices of the next step are requested
+    // before the current step's MFMA chain (deeper prefetching costs registers, i.e. waves per SIMD: measured slower).
+    const long long my_units = wave_id < nunits ? (nunits - wave_id + nwaves - 1) / nwaves : 0;
+    const long long nsteps = my_units * nsub;
+    struct Where { long long ctr; int tic; bool live; };
+    auto where = [&](long long k, int t) {
+        const long long unit = wave_id + (k / nsub) * nwaves;
+        const int sub = (int)(k % nsub);
+        const long long ctr_raw = tpc >= NT ? unit : unit * cpu_ + t / tpc;
+        const int tic = tpc >= NT ? sub * NT + t : t % tpc;
+        Where r;
+        r.live = k < nsteps && ctr_raw < ncentres && tic < tpc;
+        r.ctr = r.live ? ctr_raw : 0;
+        r.tic = r.live ? tic : 0;
+        return r;
+    };
+    int nb_next[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const Where wq = where(0, t);
+        nb_next[t] = a.idx[wq.ctr * a.ns + wq.tic * 16 + pos];
+    }
+    f4 best[SAME ? 1 : NT][B3];
+    for (long long k = 0; k < nsteps; ++k) {
+        const int sub = (int)(k % nsub);
+        if (sub == 0) {
+#pragma unroll
+            for (int t = 0; t < (SAME ? 1 : NT); ++t)
+#pragma unroll
+                for (int mb = 0; mb < B3; ++mb) best[t][mb] = f4{0.f, 0.f, 0.f, 0.f};   // outputs are >= 0 after the ReLU
+        }
+        f4 in[NT];
+        bool live[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const Where wq = where(k, t);
+            live[t] = wq.live;
+            const int nb = nb_next[t];
+            const int b = (int)(wq.ctr / a.m);
+            const float *c3 = a.new_xyz + wq.ctr * 3;
+            const size_t src = (size_t)b * a.n + nb;
+            const float *p3 = a.xyz + src * 3;
+            const float rel[3] = {p3[0] - c3[0], p3[1] - c3[1], p3[2] - c3[2]};   // pointnet2_utils.py:252
+            float v[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int c = 4 * g + s_, e = c - a.cin;
+                v[s_] = c < a.cin ? a.feat[src * a.cin + c] : e == 0 ? rel[0] : e == 1 ? rel[1] : e == 2 ? rel[2] : 0.0f;
+            }
+            in[t] = f4{v[0], v[1], v[2], v[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const Where wq = where(k + 1, t);
+            nb_next[t] = a.idx[wq.ctr * a.ns + wq.tic * 16 + pos];
+        }
+        {
+            f4 h1[NT][B1], h2[NT][B2];
+#pragma unroll
+            for (int mb = 0; mb < B1; ++mb) {
+                const f4 bi = *reinterpret_cast<const f4 *>(bias1 + 16 * mb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f4 acc = bi;
+                    PDM_CHAIN(acc, A1[mb], in[t])
+                    h1[t][mb] = floor4(acc, 0.0f);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) {
+                const f4 bi = *reinterpret_cast<const f4 *>(bias2 + 16 * mb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f4 acc = bi;
+#pragma unroll
+                    for (int kb = 0; kb < B1; ++kb) { PDM_CHAIN(acc, A2[mb][kb], h1[t][kb]) }
+                    h2[t][mb] = floor4(acc, 0.0f);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < B3; ++mb) {
+                const f4 bi = *reinterpret_cast<const f4 *>(bias3 + 16 * mb);
+                f4 v[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f4 acc = bi;
+#pragma unroll
+                    for (int kb = 0; kb < B2; ++kb) { PDM_CHAIN(acc, A3[mb][kb], h2[t][kb]) }
+                    v[t] = floor4(acc, 0.0f);
+                    if (!live[t]) v[t] = f4{0.f, 0.f, 0.f, 0.f};   // wave-uniform
+                }
+                if constexpr (SAME) {   // both tiles belong to one centre: pool them together
+                    f4 u = v[0];
+                    u.x = fmaxf(u.x, v[1].x); u.y = fmaxf(u.y, v[1].y); u.z = fmaxf(u.z, v[1].z); u.w = fmaxf(u.w, v[1].w);
+                    u = row16_max_nonneg4(u);
+                    best[0][mb].x = fmaxf(best[0][mb].x, u.x); best[0][mb].y = fmaxf(best[0][mb].y, u.y);
+                    best[0][mb].z = fmaxf(best[0][mb].z, u.z); best[0][mb].w = fmaxf(best[0][mb].w, u.w);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const f4 u = row16_max_nonneg4(v[t]);
+                        best[t][mb].x = fmaxf(best[t][mb].x, u.x); best[t][mb].y = fmaxf(best[t][mb].y, u.y);
+                        best[t][mb].z = fmaxf(best[t][mb].z, u.z); best[t][mb].w = fmaxf(best[t][mb].w, u.w);
+                    }
+                }
+            }
+        }
+        if (sub != nsub - 1) continue;
+        // lane pos == 0 of every DPP row holds the row maxima of channels 16mb + 4g .. +3
+        const long long unit = wave_id + (k / nsub) * nwaves;
+#pragma unroll
+        for (int t = 0; t < (SAME ? 1 : NT); ++t) {
+            const long long ctr = SAME ? unit : unit * cpu_ + t / tpc;
+            if (ctr >= ncentres || pos != 0) continue;
+            float *orow = a.out + ctr * a.out_stride + a.out_coff;
+#pragma unroll
+            for (int mb = 0; mb < B3; ++mb) {
+                const f4 v = best[t][mb];
+                const int c0 = 16 * mb + 4 * g;
+                if (c0 + 4 <= a.cout) {
+                    *reinterpret_cast<f4 *>(orow + c0) = v;
+                } else {
+                    if (c0 < a.cout) orow[c0] = v.x;
+                    if (c0 + 1 < a.cout) orow[c0 + 1] = v.y;
+                    if (c0 + 2 < a.cout) orow[c0 + 2] = v.z;
+                }
+            }
+        }
+    }
+#undef PDM_CHAIN
+}
+
+static int g_fused_reg = 1;         // 0 switches the register-resident SA form off (A/B measurements)
 static int g_fused_waves = 0;
 static int g_fused_tiles = 0;
 static int g_fused_groups = 0;      // 0 = auto
@@ -763,6 +933,7 @@ static void allow_lds(const void *fn, size_t bytes) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) done.insert(fn);
 }
 extern "C" int pdm_tune_fused_lds_cap(int bytes) { const int old = g_fused_lds_cap; if (bytes >= 16 * 1024 && bytes <= 160 * 1024) g_fused_lds_cap = bytes; return old; }
+extern "C" int pdm_tune_fused_reg(int on) { const int old = g_fused_reg; g_fused_reg = on != 0; return old; }
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
 extern "C" int pdm_tune_fused_groups(int n) { const int old = g_fused_groups; g_fused_groups = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0; return old; }
 extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = t; return old; }  // kept for ABI stability; no effect
@@ -833,6 +1004,25 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
     const bool pre_form = z_pm != nullptr;
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
+    if (g_fused_reg && !pre_form && nlayers == 3 && d.K[0] == 16 && nsample / 16 >= 1) {
+        // small scales: the whole MLP stays in registers (weights, activations), one wave per tile pair
+        const int b1 = d.K[1] >> 4, b2 = d.K[2] >> 4, b3 = d.K[3] >> 4;
+        const long long centres = (long long)b * m;
+        const long long units = nsample >= 32 ? centres : (centres + 1) / 2;
+        const long long want = (units + 3) / 4, capr = 256 * 8;
+        const int blocks_r = (int)(want < capr ? want : capr);
+#define PDM_REG_LAUNCH(X, Y, Z)                                                                                          \
+    if (b1 == X && b2 == Y && b3 == Z) {                                                                                \
+        if (nsample >= 32)                                                                                              \
+            hipLaunchKernelGGL((sa_reg_mlp_kernel<X, Y, Z, true>), dim3(blocks_r), dim3(256), 0, as_stream(stream), a, wpack, bias);  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((sa_reg_mlp_kernel<X, Y, Z, false>), dim3(blocks_r), dim3(256), 0, as_stream(stream), a, wpack, bias); \
+        return check_launch("sa_mlp_fused(reg)");                                                                       \
+    }
+        PDM_REG_LAUNCH(1, 1, 2)
+        PDM_REG_LAUNCH(2, 2, 4)
+#undef PDM_REG_LAUNCH
+    }
     const int tpc_ = nsample / 16;
     const long long units_ = tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
     const long long niter = (units_ + G - 1) / G;
