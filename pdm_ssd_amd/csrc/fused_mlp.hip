@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
                                                          const float *__restrict__ bias) {
     constexpr int NT = 2;
     const int lane = threadIdx.x & 63, pos = lane & 15, g = lane >> 4;
-    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const f4 *__restrict__ w1 = reinterpret_cast<const f4 *>(wpack) + lane;
     const f4 *__restrict__ w2 = w1 + 64 * B1;            // layer 1: B1 blocks x 1 k-block x 64 lanes
     const f4 *__restrict__ w3 = w2 + 64 * B2 * B1;
@@ -713,27 +713,24 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
         for (int kb = 0; kb < B2; ++kb) A3[mb][kb] = w3[64 * (mb * B2 + kb)];
     const float *__restrict__ bias1 = bias + 4 * g, *__restrict__ bias2 = bias1 + 16 * B1, *__restrict__ bias3 = bias2 + 16 * B2;
     const int tpc = a.ns >> 4;
-    const long long ncentres = (long long)a.b * a.m;
-    const int cpu_ = tpc >= NT ? 1 : NT / tpc;          // centres per unit
-    const int nsub = tpc >= NT ? (tpc + NT - 1) / NT : 1;
-    const long long nunits = (ncentres + cpu_ - 1) / cpu_;
+    const int ncentres = a.b * a.m;
+    const int cpu_ = SAME ? 1 : NT / tpc;               // centres per unit
+    const int nsub = SAME ? (tpc + NT - 1) / NT : 1;
+    const int nunits = (ncentres + cpu_ - 1) / cpu_;
 #define PDM_CHAIN(ACC, A, B)                                                          \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, ACC, 0, 0, 0);           \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, ACC, 0, 0, 0);           \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, ACC, 0, 0, 0);           \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, ACC, 0, 0, 0);
-    // Flattened (unit, sub-step) sequence of this wave; the neighbour indices of the next step are requested
-    // before the current step's MFMA chain (deeper prefetching costs registers, i.e. waves per SIMD: measured slower).
-    const long long my_units = wave_id < nunits ? (nunits - wave_id + nwaves - 1) / nwaves : 0;
-    const long long nsteps = my_units * nsub;
-    struct Where { long long ctr; int tic; bool live; };
-    auto where = [&](long long k, int t) {
-        const long long unit = wave_id + (k / nsub) * nwaves;
-        const int sub = (int)(k % nsub);
-        const long long ctr_raw = tpc >= NT ? unit : unit * cpu_ + t / tpc;
-        const int tic = tpc >= NT ? sub * NT + t : t % tpc;
+    // (unit, sub-step) sequence of this wave in 32-bit arithmetic (the host checks b*m*nsample < 2^31); the
+    // neighbour indices of the next step are requested before the current step's MFMA chain (deeper prefetching
+    // costs registers, i.e. waves per SIMD: measured slower).
+    struct Where { int ctr, tic; bool live; };
+    auto where = [&](int unit, int sub, int t) {
+        const int ctr_raw = SAME ? unit : unit * cpu_ + t / tpc;
+        const int tic = SAME ? sub * NT + t : t % tpc;
         Where r;
-        r.live = k < nsteps && ctr_raw < ncentres && tic < tpc;
+        r.live = unit < nunits && ctr_raw < ncentres && tic < tpc;
         r.ctr = r.live ? ctr_raw : 0;
         r.tic = r.live ? tic : 0;
         return r;
@@ -741,12 +738,12 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
     int nb_next[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const Where wq = where(0, t);
+        const Where wq = where(wave_id, 0, t);
         nb_next[t] = a.idx[wq.ctr * a.ns + wq.tic * 16 + pos];
     }
     f4 best[SAME ? 1 : NT][B3];
-    for (long long k = 0; k < nsteps; ++k) {
-        const int sub = (int)(k % nsub);
+    for (int unit = wave_id; unit < nunits; unit += nwaves)
+    for (int sub = 0; sub < nsub; ++sub) {
         if (sub == 0) {
 #pragma unroll
             for (int t = 0; t < (SAME ? 1 : NT); ++t)
@@ -757,11 +754,11 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
         bool live[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const Where wq = where(k, t);
+            const Where wq = where(unit, sub, t);
             live[t] = wq.live;
             const int nb = nb_next[t];
-            const int b = (int)(wq.ctr / a.m);
-            const float *c3 = a.new_xyz + wq.ctr * 3;
+            const int b = (unsigned)wq.ctr / (unsigned)a.m;
+            const float *c3 = a.new_xyz + (size_t)wq.ctr * 3;
             const size_t src = (size_t)b * a.n + nb;
             const float *p3 = a.xyz + src * 3;
             const float rel[3] = {p3[0] - c3[0], p3[1] - c3[1], p3[2] - c3[2]};   // pointnet2_utils.py:252
@@ -773,10 +770,14 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
             }
             in[t] = f4{v[0], v[1], v[2], v[3]};
         }
+        {
+            const bool wrap = sub + 1 == nsub;
+            const int nunit = wrap ? unit + nwaves : unit, nsub_ = wrap ? 0 : sub + 1;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const Where wq = where(k + 1, t);
-            nb_next[t] = a.idx[wq.ctr * a.ns + wq.tic * 16 + pos];
+            for (int t = 0; t < NT; ++t) {
+                const Where wq = where(nunit, nsub_, t);
+                nb_next[t] = a.idx[wq.ctr * a.ns + wq.tic * 16 + pos];
+            }
         }
         {
             f4 h1[NT][B1], h2[NT][B2];
@@ -831,12 +832,11 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
         }
         if (sub != nsub - 1) continue;
         // lane pos == 0 of every DPP row holds the row maxima of channels 16mb + 4g .. +3
-        const long long unit = wave_id + (k / nsub) * nwaves;
 #pragma unroll
         for (int t = 0; t < (SAME ? 1 : NT); ++t) {
-            const long long ctr = SAME ? unit : unit * cpu_ + t / tpc;
+            const int ctr = SAME ? unit : unit * cpu_ + t / tpc;
             if (ctr >= ncentres || pos != 0) continue;
-            float *orow = a.out + ctr * a.out_stride + a.out_coff;
+            float *orow = a.out + (size_t)ctr * a.out_stride + a.out_coff;
 #pragma unroll
             for (int mb = 0; mb < B3; ++mb) {
                 const f4 v = best[t][mb];
@@ -1004,7 +1004,8 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
     const bool pre_form = z_pm != nullptr;
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    if (g_fused_reg && !pre_form && nlayers == 3 && d.K[0] == 16 && nsample / 16 >= 1) {
+    if (g_fused_reg && !pre_form && nlayers == 3 && d.K[0] == 16 && (long long)b * m * nsample < (1ll << 31) &&
+        (long long)b * n * (cin > 3 ? cin : 3) < (1ll << 31)) {
         // small scales: the whole MLP stays in registers (weights, activations), one wave per tile pair
         const int b1 = d.K[1] >> 4, b2 = d.K[2] >> 4, b3 = d.K[3] >> 4;
         const long long centres = (long long)b * m;
