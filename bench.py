@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
+    ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
+                    help="batches whose sampling chain is in flight beside the feature path (pdm_ssd_amd/pipeline.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")
     ap.add_argument("--train", action="store_true",
@@ -300,11 +302,11 @@ def main():
         bd = neck(bd)
         return bd['spatial_features'], bd['point_features']
 
-    pipe = PipelinedHotPath(backbone, neck)
+    pipe = PipelinedHotPath(backbone, neck, depth=args.pipeline_depth)
 
     def step_pipelined():
-        # features of this batch || FPS chain of the next batch (same synthetic cloud every step)
-        bd = pipe.step(points, points, B, extra={'points_per_sample_checked': True})
+        # features of this batch || sampling of the following batch(es) (same synthetic cloud every step)
+        bd = pipe.step(points, points, B, extra={'points_per_sample_checked': True}, points_next2=points)
         return bd['spatial_features'], bd['point_features']
 
     step = step_serial if args.serial else step_pipelined
@@ -452,8 +454,12 @@ def main():
         "config": {"workload": f"configs[2]: PointNet2MSG backbone + PDM neck forward, bs={B}/GPU x {N} pts, "
                                f"{args.clouds} KITTI-range clouds, fp32 inference, inputs resident in HBM",
                    "launch": mode, "parallelism": f"dp{world}",
-                   "overlap": "none" if args.serial else "FPS chain of batch i+1 on a side stream under the "
-                              "feature half of batch i (pdm_ssd_amd/pipeline.py)",
+                   "overlap": "none" if args.serial else
+                              ("FPS chain of batch i+1 on a side stream under the feature half of batch i "
+                               "(pdm_ssd_amd/pipeline.py)" if args.pipeline_depth == 1 else
+                               "sampling two batches deep: level-1 FPS of batch i+2 and levels 2-4 of batch i+1 on side "
+                               "streams under the feature half of batch i; every step does one full batch of every "
+                               "kind of work (pdm_ssd_amd/pipeline.py)"),
                    "ms_per_step_eager_serial": round(serial_ms, 4)},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,

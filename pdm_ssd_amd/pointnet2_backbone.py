@@ -66,8 +66,13 @@ class PointNet2MSG(nn.Module):
         [new_xyz_1 .. new_xyz_L].  It depends on no feature, so a caller may run it ahead of time (e.g. on
         a side stream for the NEXT batch, see pdm_ssd_amd/pipeline.py) and hand the result to forward()
         as batch_dict['sampled_xyz']."""
+        return self.sample_levels(xyz, 0, len(self.SA_modules))
+
+    @torch.no_grad()
+    def sample_levels(self, xyz, first, last):
+        """Levels [first, last) of the sampling chain, starting from `xyz` = the input of level `first`."""
         out = []
-        for sa in self.SA_modules:
+        for sa in list(self.SA_modules)[first:last]:
             xyz = sa.sample(xyz)
             out.append(xyz)
         return out

@@ -119,3 +119,34 @@ def test_training_step_backward_runs(dev):
     loss.backward()
     for name, p in list(bb.named_parameters()) + list(neck.named_parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_pipelined_hot_path_equals_serial(dev, depth):
+    """PipelinedHotPath (sampling hoisted one / two batches ahead on side streams) returns, for every batch of a
+    sequence of DIFFERENT batches, exactly what backbone + neck return when run serially on that batch."""
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pdm_neck import PDMNeck
+    from pdm_ssd_amd.pipeline import PipelinedHotPath
+    from pdm_ssd_amd.pointnet2_backbone import PointNet2MSG
+    torch.manual_seed(0)
+    cfg = {'SA_CONFIG': {'NPOINTS': [256, 64], 'RADIUS': [[0.5, 1.0], [1.0, 2.0]], 'NSAMPLE': [[16, 32], [16, 32]],
+                         'MLPS': [[[16, 16], [16, 32]], [[32, 32], [32, 64]]]}, 'FP_MLPS': [[32, 32], [64, 64]]}
+    backbone = PointNet2MSG(cfg, input_channels=4).to(dev).eval()
+    neck = PDMNeck({'SOURCE_LAYER': 1, 'FEATURE_DIM': 32, 'DILATION': [3, 3, 1], 'SH_DEGREE': 1, 'INPUT_CHANNELS': 48},
+                   grid_size=[1408, 1600, 40], voxel_size=[0.05, 0.05, 0.1],
+                   point_cloud_range=list(synthetic.KITTI_RANGE)).to(dev).eval()
+    B, N = 2, 1024
+    batches = [torch.from_numpy(synthetic.to_batch_points(synthetic.lidar_like_clouds(B, N, 100 + i))).to(dev) for i in range(5)]
+    with torch.no_grad():
+        ref = []
+        for p in batches:
+            bd = neck(backbone({'batch_size': B, 'points': p}))
+            ref.append((bd['point_features'].clone(), bd['spatial_features'].clone()))
+        pipe = PipelinedHotPath(backbone, neck, depth=depth)
+        pipe.prime(batches[0], B, points_next=batches[1])
+        for i in range(3):
+            bd = pipe.step(batches[i], batches[i + 1], B, points_next2=batches[i + 2])
+            torch.cuda.synchronize()
+            assert torch.equal(bd['point_features'], ref[i][0]), f"batch {i}"
+            assert torch.equal(bd['spatial_features'], ref[i][1]), f"batch {i}"
