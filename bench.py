@@ -273,7 +273,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
-    ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=[1, 2],
                     help="batches whose sampling chain is in flight beside the feature path (pdm_ssd_amd/pipeline.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")

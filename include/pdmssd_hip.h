@@ -174,6 +174,10 @@ int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const fl
                          const int *dims, const float *wpack, const float *bias, float *out_pm,
                          int out_stride, int cout);
 
+/* count device-to-device copies dst[k] <- src[k] (bytes[k] each; host arrays) in one launch per 48 buffers.
+ * Plumbing for the stream pipeline's hand-over buffers, not a reference operator. */
+int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes);
+
 /* ---- PDM neck (build-defined spec, DESIGN.md "PDM spec"; no reference source exists) ------- */
 
 /* Multi-centre scatter-add of dilated, SH x Gaussian weighted point features into a BEV grid.

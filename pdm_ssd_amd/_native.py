@@ -36,6 +36,7 @@ _SIGNATURES = {
     "pdm_group_concat": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
+    "pdm_copy_many": [_i, _vp, _vp, _vp],
     "pdm_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
@@ -97,3 +98,20 @@ def call(name, stream, *args):
     if rc != 0:
         msg = l.pdm_last_error().decode("utf-8", "replace")
         raise NativeLibraryError(f"{name} failed with code {rc}: {msg}")
+
+
+def copy_many(dst, src):
+    """dst[k].copy_(src[k]) for lists of same-shaped contiguous CUDA tensors, in one kernel launch."""
+    import torch
+    n = len(dst)
+    assert n == len(src)
+    if n == 0:
+        return
+    for d, s_ in zip(dst, src):
+        assert d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.shape == s_.shape, (d.shape, s_.shape)
+    P = ctypes.c_void_p * n
+    dp = P(*[d.data_ptr() for d in dst])
+    sp = P(*[s_.data_ptr() for s_ in src])
+    nb = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d in dst])
+    call("pdm_copy_many", torch.cuda.current_stream(dst[0].device).cuda_stream, n,
+         ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p))

@@ -24,7 +24,58 @@ int check_launch(const char *what) {
     return (int)e;
 }
 
+// Several device-to-device copies in ONE launch (the pipeline's hand-over of ~25 small tensors costs ~10 us per
+// hipMemcpyAsync otherwise).  The table travels by value in the kernel arguments.
+constexpr int COPY_MAX = 48;
+struct CopyTable {
+    void *dst[COPY_MAX];
+    const void *src[COPY_MAX];
+    unsigned long long bytes[COPY_MAX];
+};
+
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
+    const int k = blockIdx.y;
+    const unsigned long long n = t.bytes[k];
+    char *__restrict__ d = static_cast<char *>(t.dst[k]);
+    const char *__restrict__ s = static_cast<const char *>(t.src[k]);
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+        const unsigned long long n16 = n >> 4;
+        for (unsigned long long i = tid; i < n16; i += stride)
+            reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(s)[i];
+        for (unsigned long long i = (n16 << 4) + tid; i < n; i += stride) d[i] = s[i];
+    } else {
+        for (unsigned long long i = tid; i < n; i += stride) d[i] = s[i];
+    }
+}
+
 }  // namespace pdm
+
+extern "C" int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes) {
+    using namespace pdm;
+    PDM_REQUIRE(count >= 0, PDM_E_BADARG, "copy_many: count=%d", count);
+    PDM_REQUIRE(count == 0 || (dst && src && bytes), PDM_E_BADARG, "copy_many: null table");
+    for (int base = 0; base < count; base += COPY_MAX) {
+        CopyTable t;
+        int n = 0;
+        unsigned long long largest = 0;
+        for (int k = base; k < count && n < COPY_MAX; ++k) {
+            if (bytes[k] == 0) continue;
+            PDM_REQUIRE(dst[k] && src[k], PDM_E_BADARG, "copy_many: null buffer %d", k);
+            t.dst[n] = dst[k]; t.src[n] = src[k]; t.bytes[n] = bytes[k];
+            largest = bytes[k] > largest ? bytes[k] : largest;
+            ++n;
+        }
+        if (n == 0) continue;
+        const unsigned long long want = (largest / 16 + 255) / 256;
+        const unsigned gx = (unsigned)(want < 1 ? 1 : want > 512 ? 512 : want);
+        hipLaunchKernelGGL(copy_many_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), t);
+        const int rc = check_launch("copy_many");
+        if (rc) return rc;
+    }
+    return 0;
+}
 
 extern "C" int pdm_abi_version(void) { return PDM_ABI_VERSION; }
 extern "C" const char *pdm_last_error(void) { return pdm::g_err; }

@@ -2,6 +2,9 @@
 SA/FP kernels, PDM neck) runs on the main stream, the coordinate-only sampling chain of batch i+1
 (FPS + gather for the four SA layers) runs on a side HIP stream.
 
+The coordinate-only chain also holds the ball-query indices of every SA scale and the three-NN indices and
+weights of every FP module (none of them reads a feature), so the feature path is MLP kernels only.
+
 Why: FPS is one workgroup per cloud — at bs=32 it occupies 32 of the 256 CUs for milliseconds and is
 the longest dependency chain of the step, while everything else is wide.  Nothing in the sampling
 chain depends on features, so it is hoisted one batch ahead; every step still does one full batch of
@@ -19,6 +22,22 @@ the main stream is then the level-1 FPS alone instead of the whole chain; one mo
 """
 import torch
 
+from . import _native
+
+
+def _flat(d):
+    """Tensors of a coordinate_levels() dict in a fixed order."""
+    out = list(d['sampled_xyz'])
+    for lvl in d['ball_idx']:
+        out.extend(lvl)
+    for idx, w in d['fp_interp']:
+        out.extend((idx, w))
+    return out
+
+
+def _merge(a, b):
+    return {k: list(a[k]) + list(b[k]) for k in ('sampled_xyz', 'ball_idx', 'fp_interp')}
+
 
 class PipelinedHotPath:
     def __init__(self, backbone, neck=None, depth=1):
@@ -27,28 +46,39 @@ class PipelinedHotPath:
         self.neck = neck
         self.depth = depth
         self.side = torch.cuda.Stream()
-        self.side2 = torch.cuda.Stream() if depth == 2 else None
         self.neck_stream = torch.cuda.Stream()
-        self.cur = None   # static hand-over buffers: sampled xyz of the batch about to be processed
-        self.half = None  # depth 2: level-1 sampled xyz of the batch after that
+        # depth 2: the short tail of the next batch's chain runs on the neck's stream ahead of the neck (which cannot
+        # start before the SA stack is done anyway) — hipGraph replay starts a fourth parallel branch late
+        self.side2 = self.neck_stream if depth == 2 else None
+        self.cur = None   # static hand-over buffers: coordinate-only results of the batch about to be processed
+        self.half = None  # depth 2: level-1 results of the batch after that
 
     @staticmethod
     def _xyz(points, batch_size):
         return points[:, 1:4].contiguous().view(batch_size, -1, 3)
 
+    @staticmethod
+    def _clone(d):
+        return {'sampled_xyz': [t.clone() for t in d['sampled_xyz']],
+                'ball_idx': [[t.clone() for t in lvl] for lvl in d['ball_idx']],
+                'fp_interp': [(i.clone(), w.clone()) for i, w in d['fp_interp']]}
+
     @torch.no_grad()
     def prime(self, points, batch_size, points_next=None):
-        """Sampling chain for the first batch (not overlapped with anything); depth 2 also needs level 1 of
+        """Coordinate-only chain for the first batch (not overlapped with anything); depth 2 also needs level 1 of
         the second batch (`points_next`, default: the same points)."""
-        self.cur = [t.clone() for t in self.backbone.sample_chain(self._xyz(points, batch_size))]
+        nlev = len(self.backbone.SA_modules)
+        self.cur = self._clone(self.backbone.coordinate_levels(self._xyz(points, batch_size), 0, nlev))
         if self.depth == 2:
             nxt = points if points_next is None else points_next
-            self.half = self.backbone.sample_levels(self._xyz(nxt, batch_size), 0, 1)[0].clone()
+            self.half = self._clone(self.backbone.coordinate_levels(self._xyz(nxt, batch_size), 0, 1))
 
     @torch.no_grad()
     def step(self, points_cur, points_next, batch_size, extra=None, points_next2=None):
-        """Features of `points_cur` (its sampling is in self.cur) || sampling of `points_next`
-        (depth 2: || levels 2..L of `points_next` || level 1 of `points_next2`)."""
+        """Features of `points_cur` (its coordinate-only results are in self.cur) || coordinate-only chain of
+        `points_next` (depth 2: || levels 2..L of `points_next` || level 1 of `points_next2`).
+        The coordinate-only chain = FPS + gather, ball-query indices and three-NN weights of every level: nothing in
+        it reads a feature, so only the MLP kernels (and the neck) stay on the feature path."""
         assert self.cur is not None, "call prime() first"
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
@@ -56,18 +86,19 @@ class PipelinedHotPath:
         if self.depth == 2:
             assert points_next2 is not None and self.half is not None
             self.side2.wait_stream(main)
-            with torch.cuda.stream(self.side):      # the long one: 16384 -> 4096 of the batch after next
-                nxt_half = self.backbone.sample_levels(self._xyz(points_next2, batch_size), 0, 1)[0]
+            with torch.cuda.stream(self.side):      # the long one: 16384 -> 4096 FPS of the batch after next
+                nxt_half = self.backbone.coordinate_levels(self._xyz(points_next2, batch_size), 0, 1)
             with torch.cuda.stream(self.side2):     # the tail of the next batch's chain
-                nxt = [self.half] + self.backbone.sample_levels(self.half, 1, nlev)
+                nxt = _merge(self.half, self.backbone.coordinate_levels(self.half['sampled_xyz'][0], 1, nlev))
         else:
             with torch.cuda.stream(self.side):
-                nxt = self.backbone.sample_chain(self._xyz(points_next, batch_size))
-        bd = {'batch_size': batch_size, 'points': points_cur, 'sampled_xyz': self.cur}
+                nxt = self.backbone.coordinate_levels(self._xyz(points_next, batch_size), 0, nlev)
+        bd = {'batch_size': batch_size, 'points': points_cur}
+        bd.update(self.cur)
         if extra:
             bd.update(extra)
         if self.neck is not None:
-            # the neck reads only SA outputs: run it (atomic-bound scatter) beside the FP layers (MFMA-bound)
+            # the neck reads only SA outputs: run it beside the FP layers
             def start_neck(d):
                 self.neck_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.neck_stream):
@@ -79,8 +110,8 @@ class PipelinedHotPath:
         main.wait_stream(self.side)
         if self.depth == 2:
             main.wait_stream(self.side2)
-        for c, n in zip(self.cur, nxt):
-            c.copy_(n)
-        if self.depth == 2:
-            self.half.copy_(nxt_half)
+        # hand-over into the static buffers (addresses must not change under hipGraph replay): one multi-tensor copy
+        _native.copy_many(_flat(self.cur), _flat(nxt))
+        if self.depth == 2:   # a second launch: self.half is a SOURCE of the first one (level 1 of `nxt`)
+            _native.copy_many(_flat(self.half), _flat(nxt_half))
         return bd

@@ -69,6 +69,22 @@ class PointNet2MSG(nn.Module):
         return self.sample_levels(xyz, 0, len(self.SA_modules))
 
     @torch.no_grad()
+    def coordinate_levels(self, xyz_in, first, last):
+        """Everything levels [first, last) compute from coordinates alone, starting from `xyz_in` = the input cloud of
+        level `first`: sampled xyz (FPS + gather), the ball-query indices of every scale, and the three-NN
+        (idx, weight) of the FP module that interpolates level k+1 back onto level k.  Lists indexed by level."""
+        out = {'sampled_xyz': [], 'ball_idx': [], 'fp_interp': []}
+        src = xyz_in
+        for k in range(first, last):
+            sa = self.SA_modules[k]
+            new_xyz = sa.sample(src)
+            out['sampled_xyz'].append(new_xyz)
+            out['ball_idx'].append(sa.query(src, new_xyz))
+            out['fp_interp'].append(pointnet2_modules.PointnetFPModule.interpolation(src.contiguous(), new_xyz))
+            src = new_xyz
+        return out
+
+    @torch.no_grad()
     def sample_levels(self, xyz, first, last):
         """Levels [first, last) of the sampling chain, starting from `xyz` = the input of level `first`."""
         out = []
@@ -93,9 +109,12 @@ class PointNet2MSG(nn.Module):
 
         l_xyz, l_features = [xyz], [features]
         presampled = batch_dict.get('sampled_xyz', None)
+        ball_idx = batch_dict.get('ball_idx', None)      # optional, from coordinate_levels()
+        fp_interp = batch_dict.get('fp_interp', None)
         for k, sa in enumerate(self.SA_modules):
             li_xyz, li_features = sa(l_xyz[-1], l_features[-1],
-                                     new_xyz=None if presampled is None else presampled[k])
+                                     new_xyz=None if presampled is None else presampled[k],
+                                     idx_list=None if ball_idx is None else ball_idx[k])
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         batch_dict['sa_xyz'] = list(l_xyz)
@@ -107,7 +126,9 @@ class PointNet2MSG(nn.Module):
             after_sa(batch_dict)
 
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
-            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+            # FP module i interpolates level len+i onto level len+i-1: fp_interp is indexed by the coarser level - 1
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i],
+                                                   interp=None if fp_interp is None else fp_interp[len(l_xyz) + i - 1])
 
         point_features = l_features[0].permute(0, 2, 1).contiguous()  # (B, N, C)
         batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])

@@ -65,7 +65,14 @@ class _PointnetSAModuleBase(nn.Module):
             packs.append(pk)
         return packs
 
-    def _forward_fused(self, packs, xyz, features, new_xyz):
+    @torch.no_grad()
+    def query(self, xyz, new_xyz):
+        """Neighbour indices of every scale, [(B,M,nsample) int32]: coordinate-only, so a caller may compute them
+        ahead of time (pdm_ssd_amd/pipeline.py) and pass them to forward(..., idx_list=)."""
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        return [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+
+    def _forward_fused(self, packs, xyz, features, new_xyz, idx_list=None):
         B, M = new_xyz.shape[0], new_xyz.shape[1]
         feat_pm = None if features is None else features.transpose(1, 2).contiguous()  # (B,N,C) point-major
         xyz = xyz.contiguous()
@@ -84,7 +91,8 @@ class _PointnetSAModuleBase(nn.Module):
             z = torch.empty((B, xyz.shape[1], prepack.width), dtype=torch.float32, device=xyz.device)
             fused.rows_forward(prepack, feat_pm, z, relu_last=False)
         for i, (grouper, pk) in enumerate(zip(self.groupers, packs)):
-            idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            idx = idx_list[i] if idx_list is not None else \
+                pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
             if pre is not None:
                 fused.sa_scale_forward_pre(pk, xyz, new_xyz, z, prepack.offsets[i], idx, out_pm, coff)
             else:
@@ -92,7 +100,8 @@ class _PointnetSAModuleBase(nn.Module):
             coff += pk.cout
         return new_xyz, out_pm.transpose(1, 2)  # logical (B, C, M) over point-major storage
 
-    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None,
+                idx_list=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B, sum_k mlps[k][-1], npoint).
 
         In eval mode without autograd each scale runs as one fused HIP kernel (gather + MLP on fp32 MFMA
@@ -102,7 +111,7 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = self.sample(xyz)
         packs = self._fused_packs(xyz, features)
         if packs is not None and all(pk.cout % 4 == 0 for pk in packs):
-            return self._forward_fused(packs, xyz, features, new_xyz)
+            return self._forward_fused(packs, xyz, features, new_xyz, idx_list)
         if features is not None:
             features = features.contiguous()
         pooled = []
@@ -158,8 +167,14 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = _shared_mlp(mlp)
 
+    @staticmethod
+    @torch.no_grad()
+    def interpolation(unknown, known):
+        """(idx, weight) of ref :153-156: coordinate-only, may be computed ahead and passed as forward(..., interp=)."""
+        return pointnet2_utils.three_nn_weights(unknown, known)
+
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
-                known_feats: torch.Tensor) -> torch.Tensor:
+                known_feats: torch.Tensor, interp=None) -> torch.Tensor:
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B, mlp[-1], n).
 
         In eval mode without autograd, interpolation + concat + MLP run as one fused HIP kernel and the
@@ -168,7 +183,9 @@ class PointnetFPModule(nn.Module):
         if known is not None:
             fused_ok = not (self.training or torch.is_grad_enabled()) and getattr(self, 'use_fused', True) \
                 and known_feats.is_cuda and known_feats.dtype == torch.float32
-            if fused_ok:
+            if fused_ok and interp is not None:
+                idx, weight = interp
+            elif fused_ok:
                 idx, weight = pointnet2_utils.three_nn_weights(unknown, known)   # ref :153-156 in two launches
             else:
                 dist, idx = pointnet2_utils.three_nn(unknown.contiguous(), known.contiguous())

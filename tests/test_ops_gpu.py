@@ -432,3 +432,17 @@ def test_three_nn_weights_matches_reference_glue(dev):
     assert torch.isfinite(w).all() and torch.allclose(w.sum(-1), torch.ones_like(w[..., 0]), atol=1e-6)
     e_idx, e_w = pu.three_nn_weights(unknown[:, :0].contiguous(), known)
     assert e_idx.shape == (3, 0, 3) and e_w.shape == (3, 0, 3)
+
+
+def test_copy_many_one_launch(dev):
+    from pdm_ssd_amd import _native
+    torch.manual_seed(1)
+    shapes = [(3, 5), (1,), (0, 4), (1000, 3), (7, 11, 13), (2, 4096, 32)] * 10     # 60 buffers: two launches of <= 48
+    src = [torch.randn(s, device=dev) if i % 2 else torch.randint(0, 1 << 30, s, device=dev, dtype=torch.int32)
+           for i, s in enumerate(shapes)]
+    src[3] = torch.randn(1001, 3, device=dev)[1:]                                    # 12-byte offset: unaligned path
+    dst = [torch.full_like(t, 7) for t in src]
+    _native.copy_many(dst, src)
+    for d, s_ in zip(dst, src):
+        assert torch.equal(d, s_)
+    _native.copy_many([], [])
