@@ -854,6 +854,12 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
 #undef PDM_CHAIN
 }
 
+int rows_gemm_launch(void *stream, int rows, int cin, const float *in_pm, int k0, int c1, const float *wpack,
+                     const float *bias, int relu_last, float *out_pm, int out_stride, int cout);   // rows_gemm.hip
+int fp_pre_gemm_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
+                       const float *skip_pm, const int *idx, const float *weight, int k1, int c2,
+                       const float *wpack, const float *bias, float *out_pm, int out_stride, int cout);
+static int g_fused_gemm = 1;        // 0: single-layer rows go through the chain kernel instead of the LDS-tiled GEMM
 static int g_fused_reg = 1;         // 0 switches the register-resident SA form off (A/B measurements)
 static int g_fused_waves = 0;
 static int g_fused_tiles = 0;
@@ -933,6 +939,7 @@ static void allow_lds(const void *fn, size_t bytes) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) done.insert(fn);
 }
 extern "C" int pdm_tune_fused_lds_cap(int bytes) { const int old = g_fused_lds_cap; if (bytes >= 16 * 1024 && bytes <= 160 * 1024) g_fused_lds_cap = bytes; return old; }
+extern "C" int pdm_tune_fused_gemm(int on) { const int old = g_fused_gemm; g_fused_gemm = on != 0; return old; }
 extern "C" int pdm_tune_fused_reg(int on) { const int old = g_fused_reg; g_fused_reg = on != 0; return old; }
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
 extern "C" int pdm_tune_fused_groups(int n) { const int old = g_fused_groups; g_fused_groups = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0; return old; }
@@ -1084,6 +1091,11 @@ static int fp_fused_launch(void *stream, int mode, int relu_last, int b, int n, 
     FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout, mode == 1 ? z_pm : nullptr, z_stride};
     const bool pre_form = mode == 1;
     PDM_REQUIRE(!pre_form || (long long)m * z_stride < (1ll << 31), PDM_E_TOOLARGE, "fp_mlp_fused_pre: m * z_stride overflows 32-bit row offsets");
+    if (g_fused_gemm && pre_form && nlayers == 2 && c_skip <= 4 && d.K[0] == 16 && d.K[1] >= 64 && d.K[2] >= 64 &&
+        (long long)b * n >= 32768 && (long long)b * n < (1ll << 31) && z_stride >= d.K[1])
+        // wide second layer over many rows: LDS-tiled GEMM, layer 1 made on the fly while staging (rows_gemm.hip)
+        return fp_pre_gemm_launch(stream, b, n, m, c_skip, z_pm, z_stride, skip_pm, idx, weight, d.K[1], d.K[2], wpack, bias,
+                                  out_pm, out_stride, cout);
     const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q)) * sizeof(float);
     PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "fp_mlp_fused: needs %zu bytes of LDS", lds_bytes);
     const long long niter = ((ntiles + NT - 1) / NT + G - 1) / G;
@@ -1120,6 +1132,11 @@ extern "C" int pdm_rows_mlp_fused(void *stream, int rows, int cin, const float *
                                   const int *dims, const float *wpack, const float *bias, int relu_last,
                                   float *out_pm, int out_stride, int cout) {
     PDM_REQUIRE(rows >= 0 && cin >= 1, PDM_E_BADARG, "rows_mlp_fused: rows=%d cin=%d", rows, cin);
+    if (g_fused_gemm && nlayers == 1 && dims && dims[0] % 16 == 0 && dims[1] % 16 == 0 && dims[0] >= cin && dims[0] >= 32 &&
+        dims[1] >= 64 && (long long)((rows + 127) / 128) * ((dims[1] + 127) / 128) >= 256 && in_pm && wpack && bias && out_pm && cout > 0 && cout <= dims[1] && cout <= out_stride &&
+        out_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(out_pm) | reinterpret_cast<uintptr_t>(wpack) |
+                                 reinterpret_cast<uintptr_t>(bias)) & 15) == 0)
+        return rows_gemm_launch(stream, rows, cin, in_pm, dims[0], dims[1], wpack, bias, relu_last, out_pm, out_stride, cout);
     return fp_fused_launch(stream, 2, relu_last, 1, rows, 1, 0, cin, nullptr, nullptr, 0, in_pm, nullptr, nullptr, nlayers,
                            dims, wpack, bias, out_pm, out_stride, cout);
 }
