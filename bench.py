@@ -390,8 +390,8 @@ def main():
     except Exception:
         pass
 
-    def pmc_traffic(prefix):
-        rows = [v for k, v in pmc.items() if k.startswith(prefix) and v["launches"] > 0]
+    def pmc_traffic(*prefixes):
+        rows = [v for k, v in pmc.items() if k.startswith(prefixes) and v["launches"] > 0]
         if not rows:
             return None
         return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
@@ -419,10 +419,11 @@ def main():
         per_launch_flop = sum(executed[o["op"]] for o in sa_ops) / calls
         per_launch_s = sum(o["ms_per_step"] for o in sa_ops) / 1e3 / calls
         ach = per_launch_flop / per_launch_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "pdm::sa_mlp_fused_kernel (pdm_sa_mlp_fused, pdm_sa_mlp_fused_pre)",
+        roofline = {"bound": "mfma", "kernel": "pdm::sa_mlp_fused_kernel + pdm::sa_reg_mlp_kernel (all launches of "
+                                               "pdm_sa_mlp_fused and pdm_sa_mlp_fused_pre: the 8 SA scales)",
                     "achieved": round(ach, 2),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic("pdm::sa_mlp_fused_kernel"), "traffic_unit": "HBM bytes per launch (PMC)",
+                    "traffic": pmc_traffic("pdm::sa_mlp_fused_kernel", "pdm::sa_reg_mlp_kernel"), "traffic_unit": "HBM bytes per launch (PMC)",
                     "launches_per_step": calls,
                     "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop),
                     "flops_counted": "executed (hoisted first layer), unpadded"}
