@@ -174,6 +174,34 @@ int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const fl
                          const int *dims, const float *wpack, const float *bias, float *out_pm,
                          int out_stride, int cout);
 
+/* ---- pointnet2_stack: ragged ("stacked") batches -----------------------
+ * One entry per function of the reference's pointnet2_stack_cuda extension that the PointNet++ modules use
+ * (pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp): points of all samples concatenated, per-sample
+ * counts in int32 DEVICE arrays (*_batch_cnt, B entries, B <= 1024).  Same arithmetic as the batch entries.
+ *   ball_query_wrapper_stack           ball_query.cpp      idx (M,nsample) LOCAL to the sample, caller-zeroed;
+ *                                                           an empty ball stores idx[0] = -1 (ball_query_gpu.cu:66)
+ *   group_points[_grad]_wrapper_stack  group_points.cpp    out (M,C,nsample); grad_features (N,C) caller-zeroed
+ *   three_nn_wrapper_stack             interpolate.cpp     dist2 (N,3), idx (N,3) GLOBAL; +inf / start when the
+ *                                                           sample has fewer than three known points
+ *   three_interpolate[_grad]_wrapper_stack                 features (M,C) -> out (N,C); grad caller-zeroed
+ *   stack_farthest_point_sampling_wrapper  sampling.cpp    GLOBAL indices, packed per sample; temp = 1e10 */
+int pdm_stack_ball_query(void *stream, int B, int M, float radius, int nsample, const float *new_xyz,
+                         const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt, int *idx);
+int pdm_stack_group_points(void *stream, int B, int M, int C, int nsample, const float *features,
+                           const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt, float *out);
+int pdm_stack_group_points_grad(void *stream, int B, int M, int C, int N, int nsample, const float *grad_out,
+                                const int *idx, const int *idx_batch_cnt, const int *features_batch_cnt,
+                                float *grad_features);
+int pdm_stack_three_nn(void *stream, int B, int N, const float *unknown, const int *unknown_batch_cnt,
+                       const float *known, const int *known_batch_cnt, float *dist2, int *idx);
+int pdm_stack_three_interpolate(void *stream, int N, int C, const float *features, const int *idx,
+                                const float *weight, float *out);
+int pdm_stack_three_interpolate_grad(void *stream, int N, int C, const float *grad_out, const int *idx,
+                                     const float *weight, float *grad_features);
+/* max_n = largest per-sample point count (host value; selects the kernel instantiation) */
+int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
+                                      const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points);
+
 /* count device-to-device copies dst[k] <- src[k] (bytes[k] each; host arrays) in one launch per 48 buffers.
  * Plumbing for the stream pipeline's hand-over buffers, not a reference operator. */
 int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes);

@@ -25,7 +25,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pdm_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pointnet2_stack_oracle.c", "pdm_oracle.c", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -266,3 +266,81 @@ def pdm_scatter_grad(xyz, feat, sh, inv2s2, origin, cell, inv_cell, dims, kernel
                                        dsh.ctypes.data_as(_f32p), dinv.ctypes.data_as(_f32p))
     assert rc == 0, rc
     return dfeat, dsh, dinv
+
+
+# ---- pointnet2_stack (ragged batches): oracle/pointnet2_stack_oracle.c ---------------------------------------
+
+def stack_ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """pointnet2_stack/pointnet2_utils.py:11-42 -> (idx (M,nsample) int32 local to the sample, empty_ball_mask (M,))."""
+    xyz, px = _f(xyz); new_xyz, pn = _f(new_xyz)
+    xc, pxc = _i(xyz_batch_cnt); nc, pnc = _i(new_xyz_batch_cnt)
+    M = new_xyz.shape[0]
+    idx = np.zeros((M, nsample), dtype=np.int32)
+    lib().oracle_stack_ball_query(len(xc), M, ctypes.c_float(radius), int(nsample), pn, pnc, px, pxc,
+                                  idx.ctypes.data_as(_i32p))
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def stack_grouping_operation(features, features_batch_cnt, idx, idx_batch_cnt):
+    """(N,C), (M,nsample) -> (M,C,nsample).  pointnet2_stack/pointnet2_utils.py:55-86."""
+    features, pf = _f(features); idx, pi = _i(idx)
+    fc, pfc = _i(features_batch_cnt); ic, pic = _i(idx_batch_cnt)
+    M, ns = idx.shape
+    C = features.shape[1]
+    out = np.empty((M, C, ns), dtype=np.float32)
+    lib().oracle_stack_group_points(len(ic), M, C, ns, pf, pfc, pi, pic, out.ctypes.data_as(_f32p))
+    return out
+
+
+def stack_grouping_operation_grad(grad_out, idx, idx_batch_cnt, features_batch_cnt, N):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx)
+    fc, pfc = _i(features_batch_cnt); ic, pic = _i(idx_batch_cnt)
+    M, C, ns = grad_out.shape
+    g = np.zeros((N, C), dtype=np.float32)
+    lib().oracle_stack_group_points_grad(len(ic), M, C, N, ns, pg, pi, pic, pfc, g.ctypes.data_as(_f32p))
+    return g
+
+
+def stack_three_nn(unknown, unknown_batch_cnt, known, known_batch_cnt):
+    """-> (dist (N,3) = sqrt(dist2), idx (N,3) int32 GLOBAL).  pointnet2_stack/pointnet2_utils.py:230-254."""
+    unknown, pu = _f(unknown); known, pk = _f(known)
+    uc, puc = _i(unknown_batch_cnt); kc, pkc = _i(known_batch_cnt)
+    N = unknown.shape[0]
+    d2 = np.zeros((N, 3), dtype=np.float32)
+    idx = np.zeros((N, 3), dtype=np.int32)
+    lib().oracle_stack_three_nn(len(uc), N, pu, puc, pk, pkc, d2.ctypes.data_as(_f32p), idx.ctypes.data_as(_i32p))
+    with np.errstate(invalid="ignore"):
+        return np.sqrt(d2), idx
+
+
+def stack_three_interpolate(features, idx, weight):
+    features, pf = _f(features); idx, pi = _i(idx); weight, pw = _f(weight)
+    N, C = idx.shape[0], features.shape[1]
+    out = np.empty((N, C), dtype=np.float32)
+    lib().oracle_stack_three_interpolate(N, C, pf, pi, pw, out.ctypes.data_as(_f32p))
+    return out
+
+
+def stack_three_interpolate_grad(grad_out, idx, weight, M):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx); weight, pw = _f(weight)
+    N, C = grad_out.shape
+    g = np.zeros((M, C), dtype=np.float32)
+    lib().oracle_stack_three_interpolate_grad(N, C, pg, pi, pw, g.ctypes.data_as(_f32p))
+    return g
+
+
+def stack_furthest_point_sample(xyz, xyz_batch_cnt, npoint):
+    """-> idx (sum npoint,) int32 GLOBAL.  npoint: int or per-sample list.  pointnet2_stack/pointnet2_utils.py:193-218."""
+    xyz, px = _f(xyz)
+    xc, pxc = _i(xyz_batch_cnt)
+    B = len(xc)
+    if np.isscalar(npoint):
+        npoint = [int(npoint)] * B
+    mc, pmc = _i(npoint)
+    temp = np.full((xyz.shape[0],), 1e10, dtype=np.float32)
+    out = np.zeros((int(mc.sum()),), dtype=np.int32)
+    rc = lib().oracle_stack_furthest_point_sampling(B, px, temp.ctypes.data_as(_f32p), pxc, out.ctypes.data_as(_i32p), pmc)
+    assert rc == 0
+    return out

@@ -37,6 +37,13 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
+    "pdm_stack_ball_query": [_i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_stack_group_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_stack_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_stack_three_nn": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdm_stack_three_interpolate": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdm_stack_three_interpolate_grad": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdm_stack_furthest_point_sampling": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],

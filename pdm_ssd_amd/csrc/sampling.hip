@@ -115,21 +115,44 @@ __device__ __forceinline__ FpsPick block_pick(float wmax, FpsPick mine, FpsRec (
     return out;
 }
 
+// Ragged ("stacked") batches (pointnet2_stack/src/sampling_gpu.cu:187-319): per-sample point and sample counts,
+// samples packed back to back, GLOBAL indices out; the reference always runs 1024 logical threads there.
+struct FpsRagged {
+    const int *cnt;    // null = batch mode
+    const int *mcnt;
+};
+struct FpsWhere { int start, ostart, n, m; };
+__device__ __forceinline__ FpsWhere fps_where(const FpsRagged &rg, int b, int n, int m) {
+    FpsWhere w;
+    if (rg.cnt) {
+        int s = 0, o = 0;
+        for (int k = 0; k < b; ++k) { s += rg.cnt[k]; o += rg.mcnt[k]; }
+        w.start = s; w.ostart = o; w.n = rg.cnt[b]; w.m = rg.mcnt[b];
+    } else {
+        w.start = b * n; w.ostart = b * m; w.n = n; w.m = m;
+    }
+    return w;
+}
+
 // Register-resident FPS.  S = the reference's logical thread count (power of two <= 1024).
 // T = min(S, BLOCK) physical threads are active; each plays R = S/T reference threads (the ones the
 // tree's first log2(R) levels merge into one slot, visited in the order those levels prefer) and
 // holds I = PPT/R points of each in registers: visiting index v -> residue bitrev(v / I), step v % I.
 template <int BLOCK, int PPT>
-__global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int logS,
+__global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n_, int m_, int S, int logS,
                                                         const float *__restrict__ xyz_all,
                                                         float *__restrict__ temp_all,
-                                                        int *__restrict__ idx_all) {
+                                                        int *__restrict__ idx_all, FpsRagged rg) {
     using vec = float __attribute__((ext_vector_type(PPT)));
     __shared__ FpsRec rec[2][16];
     const int b = blockIdx.x;
-    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
-    float *__restrict__ temp = temp_all + (size_t)b * n;
-    int *__restrict__ idxs = idx_all + (size_t)b * m;
+    const FpsWhere wh = fps_where(rg, b, n_, m_);
+    const int n = wh.n, m = wh.m;
+    const int gofs = rg.cnt ? wh.start : 0;   // stacked batches report global indices
+    if (m <= 0) return;                       // whole workgroup
+    const float *__restrict__ xyz = xyz_all + (size_t)wh.start * 3;
+    float *__restrict__ temp = temp_all + (size_t)wh.start;
+    int *__restrict__ idxs = idx_all + (size_t)wh.ostart;
 
     const int T = S < BLOCK ? S : BLOCK;
     const int logT = S < BLOCK ? logS : __builtin_ctz(BLOCK);
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int
     FpsPick cur;
     cur.k = 0;
     cur.x = xyz[0]; cur.y = xyz[1]; cur.z = xyz[2];
-    if (p == 0) idxs[0] = 0;
+    if (p == 0) idxs[0] = gofs;
     const int wave_base = (threadIdx.x >> 6) * 64;
     for (int j = 1; j < m; ++j) {
         float best = active ? -1.0f : -2.0f;
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int
 #else
         cur = block_pick<BLOCK>(wmax, mine, rec, j & 1);
 #endif
-        if (p == 0) idxs[j] = cur.k;
+        if (p == 0) idxs[j] = cur.k + gofs;
     }
 
 #pragma unroll
@@ -227,21 +250,25 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(int n, int m, int S, int
 // Any n: points and min-distances stream from global memory (L2-resident) every iteration.
 // Same arithmetic and tie order; used when n > 16 * 1024.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fps_stream_kernel(int n, int m, int S, int logS,
+__global__ __launch_bounds__(BLOCK) void fps_stream_kernel(int n_, int m_, int S, int logS,
                                                            const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all,
-                                                           int *__restrict__ idx_all) {
+                                                           int *__restrict__ idx_all, FpsRagged rg) {
     __shared__ FpsRec rec[2][16];
     const int b = blockIdx.x;
-    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
-    float *__restrict__ temp = temp_all + (size_t)b * n;
-    int *__restrict__ idxs = idx_all + (size_t)b * m;
+    const FpsWhere wh = fps_where(rg, b, n_, m_);
+    const int n = wh.n, m = wh.m;
+    const int gofs = rg.cnt ? wh.start : 0;
+    if (m <= 0) return;
+    const float *__restrict__ xyz = xyz_all + (size_t)wh.start * 3;
+    float *__restrict__ temp = temp_all + (size_t)wh.start;
+    int *__restrict__ idxs = idx_all + (size_t)wh.ostart;
     const int p = threadIdx.x;
     const bool active = p < S;
     const int t = logS > 0 ? (int)(__brev((unsigned)p) >> (32 - logS)) : 0;
 
     int old = 0;
-    if (p == 0) idxs[0] = 0;
+    if (p == 0) idxs[0] = gofs;
     for (int j = 1; j < m; ++j) {
         const float x1 = xyz[(size_t)old * 3 + 0];
         const float y1 = xyz[(size_t)old * 3 + 1];
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void fps_stream_kernel(int n, int m, int S, 
         mine.k = __builtin_amdgcn_readlane(besti, wl);
         mine.x = mine.y = mine.z = 0.0f;
         old = block_pick<BLOCK>(wmax, mine, rec, j & 1).k;
-        if (p == 0) idxs[j] = old;
+        if (p == 0) idxs[j] = old + gofs;
     }
 }
 
@@ -706,7 +733,7 @@ extern "C" int pdm_tune_fps_variant(int v) { const int old = g_fps_variant; g_fp
 
 #define FPS_LAUNCH(BLOCK, PPT)                                                                  \
     hipLaunchKernelGGL((fps_reg_kernel<BLOCK, PPT>), dim3(b), dim3(BLOCK), 0, as_stream(stream), \
-                       n, m, S, logS, points, temp, idx)
+                       n, m, S, logS, points, temp, idx, rg)
 
 extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, const float *points,
                                            float *temp, int *idx) {
@@ -717,6 +744,7 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     int logS = 0;
     const int S = ref_block_threads(n, &logS);
     const int per = (n + S - 1) / S;  // points per reference thread
+    const FpsRagged rg{nullptr, nullptr};
     if (S <= 64) {
         FPS_LAUNCH(64, 2);
     } else if (S <= 256) {
@@ -738,9 +766,33 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
         else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n,
-                           m, S, logS, points, temp, idx);
+                           m, S, logS, points, temp, idx, rg);
     }
     return check_launch("furthest_point_sampling");
+}
+
+// Stacked batches (reference stack_farthest_point_sampling_wrapper, pointnet2_stack/src/sampling.cpp): sample b has
+// xyz_batch_cnt[b] points and yields num_sampled_points[b] GLOBAL indices, packed sample after sample.  max_n = the
+// largest per-sample point count (host value: it selects the register-resident instantiation).  Tie order is the
+// reference's 1024-thread tree for every sample size.  Samples with num_sampled_points > 0 need >= 1 point.
+extern "C" int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
+                                                 const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points) {
+    PDM_REQUIRE(B >= 0 && max_n >= 0, PDM_E_BADARG, "stack_fps: B=%d max_n=%d", B, max_n);
+    if (B == 0 || max_n == 0) return 0;
+    PDM_REQUIRE(xyz && temp && xyz_batch_cnt && idxs && num_sampled_points, PDM_E_BADARG, "stack_fps: null pointer");
+    const FpsRagged rg{xyz_batch_cnt, num_sampled_points};
+    const int S = 1024, logS = 10, b = B, n = 0, m = 0;
+    const float *points = xyz;
+    int *idx = idxs;
+    const int per = (max_n + 1023) / 1024;
+    if (per <= 1) FPS_LAUNCH(1024, 1);
+    else if (per <= 2) FPS_LAUNCH(1024, 2);
+    else if (per <= 4) FPS_LAUNCH(1024, 4);
+    else if (per <= 8) FPS_LAUNCH(1024, 8);
+    else if (per <= 16) FPS_LAUNCH(1024, 16);
+    else hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, S, logS, points,
+                            temp, idx, rg);
+    return check_launch("stack_furthest_point_sampling");
 }
 
 // Large clouds (n > 16384): G = ceil(n / 16384) cooperating workgroups per cloud, exchange slots in the

@@ -120,3 +120,76 @@ def test_distance_modes_differ_only_in_last_bits():
             o.set_dist_mode(o.DIST_PINNED)
     # rows that flip are rare (a point within 1 ulp of the sphere); the count is reported in DESIGN.md
     assert all(v <= 8 for v in flips.values()), flips
+
+
+# ---- pointnet2_stack oracle (ragged batches) -----------------------------------------------------------------
+
+def _ragged(rng, counts):
+    return [rng.uniform(0, 10, (n, 3)).astype(np.float32) for n in counts]
+
+
+def test_stack_oracle_equals_batch_oracle_on_equal_counts():
+    """Same arithmetic as the batch operators: on an equal-count batch the stacked results are the batch results
+    with the documented index conventions (ball query local, three_nn / FPS global)."""
+    rng = np.random.default_rng(3)
+    B, N, M = 3, 700, 60
+    xyz = rng.uniform(0, 10, (B, N, 3)).astype(np.float32)
+    flat, cnt = xyz.reshape(-1, 3), [N] * B
+    fi = o.furthest_point_sample(xyz, M, block_size=1024)          # the stack kernel always runs 1024 threads
+    np.testing.assert_array_equal(o.stack_furthest_point_sample(flat, cnt, M).reshape(B, M), fi + np.arange(B)[:, None] * N)
+    new = np.stack([xyz[b, fi[b]] for b in range(B)])
+    sidx, empty = o.stack_ball_query(1.5, 16, flat, cnt, new.reshape(-1, 3), [M] * B)
+    np.testing.assert_array_equal(sidx.reshape(B, M, 16), o.ball_query(1.5, 16, xyz, new))
+    assert not empty.any()
+    d, i = o.three_nn(xyz, new)
+    sd, si = o.stack_three_nn(flat, cnt, new.reshape(-1, 3), [M] * B)
+    np.testing.assert_array_equal(si.reshape(B, N, 3), i + np.arange(B)[:, None, None] * M)
+    np.testing.assert_array_equal(sd.reshape(B, N, 3), d)
+
+
+def test_stack_ball_query_known_answers():
+    # sample 0: 4 points on a line; sample 1: 2 points; centres: one per sample + one empty ball
+    xyz = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0], [10, 0, 0], [10.5, 0, 0]], np.float32)
+    new = np.array([[1.1, 0, 0], [50, 0, 0], [10.2, 0, 0]], np.float32)
+    idx, empty = o.stack_ball_query(1.0, 4, xyz, [4, 2], new, [2, 1])
+    np.testing.assert_array_equal(idx[0], [1, 2, 1, 1])      # |1.1-1|, |1.1-2| < 1 (strict), padded with the first hit
+    np.testing.assert_array_equal(idx[1], [0, 0, 0, 0])      # empty ball: row zeroed, mask set
+    np.testing.assert_array_equal(idx[2], [0, 1, 0, 0])      # indices are LOCAL to sample 1
+    np.testing.assert_array_equal(empty, [False, True, False])
+    # a centre past the counted ones belongs to the last sample (the kernels' linear scan)
+    idx2, _ = o.stack_ball_query(1.0, 2, xyz, [4, 2], np.array([[10.1, 0, 0]] * 4, np.float32), [1, 1])
+    np.testing.assert_array_equal(idx2[2], [0, 1])
+
+
+def test_stack_three_nn_short_sample_and_interpolate():
+    known = np.array([[0, 0, 0], [1, 0, 0], [5, 0, 0], [6, 0, 0], [7, 0, 0], [8, 0, 0]], np.float32)
+    unknown = np.array([[0.4, 0, 0], [6.1, 0, 0]], np.float32)
+    dist, idx = o.stack_three_nn(unknown, [1, 1], known, [2, 4])
+    np.testing.assert_array_equal(idx[0], [0, 1, 0])          # only two candidates: third slot = 0 + start, dist inf
+    assert np.isinf(dist[0, 2]) and np.allclose(dist[0, :2], [0.4, 0.6])
+    np.testing.assert_array_equal(idx[1], [3, 4, 2])          # GLOBAL indices (start of sample 1 = 2)
+    feats = np.arange(12, dtype=np.float32).reshape(6, 2)
+    w = np.array([[0.5, 0.5, 0.0], [0.2, 0.3, 0.5]], np.float32)
+    out = o.stack_three_interpolate(feats, idx, w)
+    np.testing.assert_allclose(out[1], 0.2 * feats[3] + 0.3 * feats[4] + 0.5 * feats[2], rtol=1e-6)
+    g = o.stack_three_interpolate_grad(np.ones((2, 2), np.float32), idx, w, 6)
+    np.testing.assert_allclose(g[:, 0], [0.5, 0.5, 0.5, 0.2, 0.3, 0.0], rtol=1e-6)
+
+
+def test_stack_group_and_fps_ragged():
+    rng = np.random.default_rng(5)
+    pts = _ragged(rng, [5, 1300, 40])
+    flat = np.concatenate(pts)
+    out = o.stack_furthest_point_sample(flat, [5, 1300, 40], [3, 64, 0])
+    assert out.shape == (67,) and out[0] == 0 and out[3] == 5          # first pick of every sample = its first point
+    assert (out[:3] < 5).all() and ((out[3:] >= 5) & (out[3:] < 1305)).all()
+    for b, (s, m) in enumerate([(0, 3), (5, 64)]):                      # each sample alone gives the same picks
+        alone = o.stack_furthest_point_sample(pts[b], [len(pts[b])], [m])
+        np.testing.assert_array_equal(out[[0, 3][b]:[3, 67][b]], alone + s)
+    feats = rng.standard_normal((1345, 3)).astype(np.float32)
+    idx = np.array([[0, 4], [1299, 7], [39, 0]], np.int32)
+    grouped = o.stack_grouping_operation(feats, [5, 1300, 40], idx, [1, 1, 1])
+    np.testing.assert_array_equal(grouped[1, :, 0], feats[5 + 1299])
+    np.testing.assert_array_equal(grouped[2, :, 1], feats[1305])
+    g = o.stack_grouping_operation_grad(np.ones_like(grouped), idx, [1, 1, 1], [5, 1300, 40], 1345)
+    assert g.sum() == grouped.size and g[1305, 0] == 1 and g[0, 0] == 1
