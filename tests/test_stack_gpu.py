@@ -146,3 +146,68 @@ def test_stack_wrappers_reject_misuse(dev):
         su.stack_farthest_point_sample(xyz, torch.tensor([4, 4], dtype=torch.int32, device=dev), 2)   # counts != rows
     with pytest.raises(ValueError):
         su.stack_farthest_point_sample(xyz, torch.tensor([10, 0], dtype=torch.int32, device=dev), [2, 1])
+
+
+def _randomize_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+@pytest.mark.parametrize("cin", [0, 5, 32])
+def test_stack_sa_module_fused_equals_unfused(dev, cin):
+    """StackSAModuleMSG in eval/no-grad (fused MFMA kernels on the stacked batch as one sample, empty balls patched)
+    against its own torch path; 32 input channels also exercises the hoisted first layer."""
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    torch.manual_seed(cin)
+    counts, mcounts = [900, 300, 1200], [40, 25, 64]
+    xyz = ragged_clouds(counts, 5)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    new = np.concatenate([xyz[starts[b]:starts[b] + m] for b, m in enumerate(mcounts)])
+    new[10] += 200.0                                                  # an empty ball in sample 0
+    feats = None if cin == 0 else torch.randn(sum(counts), cin, device=dev)
+    sa = sm.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[cin, 16, 32], [cin, 32, 48]]).to(dev).eval()
+    _randomize_bn(sa, 3)
+    xc, nc = T(np.array(counts, np.int32), dev), T(np.array(mcounts, np.int32), dev)
+    with torch.no_grad():
+        _, a = sa(T(xyz, dev), xc, T(new, dev), nc, feats)
+        assert '_pdm_fused_cache' in sa.__dict__
+        sa.use_fused = False
+        _, b = sa(T(xyz, dev), xc, T(new, dev), nc, feats)
+    assert a.shape == b.shape == (129, 80)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    sa.train()                                                        # autograd path
+    f = None if feats is None else feats.clone().requires_grad_(True)
+    _, c = sa(T(xyz, dev), xc, T(new, dev), nc, f)
+    c.sum().backward()
+    assert all(p.grad is not None for p in sa.parameters()) and (f is None or f.grad is not None)
+
+
+def test_stack_fp_module_fused_equals_unfused(dev):
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    torch.manual_seed(1)
+    ucounts, kcounts = [700, 260], [90, 40]
+    unknown, known = ragged_clouds(ucounts, 8), ragged_clouds(kcounts, 80)
+    fp = sm.StackPointnetFPModule(mlp=[24 + 6, 32, 16]).to(dev).eval()
+    _randomize_bn(fp, 4)
+    uf, kf = torch.randn(960, 6, device=dev), torch.randn(130, 24, device=dev)
+    uc, kc = T(np.array(ucounts, np.int32), dev), T(np.array(kcounts, np.int32), dev)
+    with torch.no_grad():
+        a = fp(T(unknown, dev), uc, T(known, dev), kc, uf, kf)
+        fp.use_fused = False
+        b = fp(T(unknown, dev), uc, T(known, dev), kc, uf, kf)
+    assert a.shape == (960, 16)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_build_local_aggregation_module_contract(dev):
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    cfg = {'NAME': 'StackSAModuleMSG', 'MLPS': [[16, 16], [16, 32]], 'POOL_RADIUS': [0.4, 0.8], 'NSAMPLE': [16, 16]}
+    layer, cout = sm.build_local_aggregation_module(8, cfg)
+    assert cout == 48 and cfg['MLPS'][0][0] == 11                    # input channels prepended, +3 for xyz, in place
+    assert sorted(layer.state_dict())[0] == 'mlps.0.0.weight' and layer.mlps[0][0].weight.shape == (16, 11, 1, 1)
+    with pytest.raises(NotImplementedError):
+        sm.build_local_aggregation_module(8, {'NAME': 'VectorPoolAggregationModuleMSG'})
