@@ -125,6 +125,38 @@ __global__ __launch_bounds__(256) void three_nn_weights_kernel(long long rows, c
     if (dist) { dist[r * 3 + 0] = d0; dist[r * 3 + 1] = d1; dist[r * 3 + 2] = d2; }
 }
 
+// The same backward with the scatter kept on chip: one workgroup owns `tc` channel rows (tc * m floats of LDS) of one
+// sample, streams grad_out[b, c, :] coalesced, adds into LDS with ds_add_f32 and writes every grad_points row once.
+// The global-atomic form above issues 64 scattered 4-byte atomics per wave instruction (17 ms for FP1 at bs=32);
+// this one is bound by the LDS atomic rate.
+__global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_lds_kernel(
+    int c, int n, int m, int tc, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points) {
+    extern __shared__ float s_acc[];   // tc x m
+    const int b = blockIdx.y, c0 = blockIdx.x * tc;
+    const int nc = min(tc, c - c0);
+    for (int e = threadIdx.x; e < nc * m; e += TI_THREADS) s_acc[e] = 0.0f;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += TI_THREADS) {
+        const int *id = idx + ((size_t)b * n + j) * 3;
+        const float *w = weight + ((size_t)b * n + j) * 3;
+        const int i0 = id[0], i1 = id[1], i2 = id[2];
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        for (int ci = 0; ci < nc; ++ci) {
+            const float g = grad_out[((size_t)b * c + c0 + ci) * n + j];
+            float *row = s_acc + ci * m;
+            atomicAdd(row + i0, g * w0);
+            atomicAdd(row + i1, g * w1);
+            atomicAdd(row + i2, g * w2);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc * m; e += TI_THREADS) {
+        const int ci = e / m, k = e - ci * m;
+        grad_points[((size_t)b * c + c0 + ci) * m + k] += s_acc[e];   // rows are exclusive to this workgroup
+    }
+}
+
 }  // namespace pdm
 
 using namespace pdm;
@@ -170,6 +202,16 @@ extern "C" int pdm_three_interpolate_grad(void *stream, int b, int c, int n, int
     if (b == 0 || c == 0 || n == 0) return 0;
     PDM_REQUIRE(grad_out && idx && weight && grad_points, PDM_E_BADARG, "three_interpolate_grad: null pointer");
     PDM_REQUIRE(b <= 65535 && divup(c, TI_CG) <= 65535, PDM_E_TOOLARGE, "three_interpolate_grad: exceeds grid");
+    if (m >= 1 && m <= 16384) {
+        // known-point rows of a few channels fit LDS: accumulate there (LDS atomics), write each row once
+        int tc = 16384 / m;
+        tc = tc > 8 ? 8 : tc;
+        tc = tc > c ? c : tc;
+        dim3 grid(divup(c, tc), b);
+        hipLaunchKernelGGL(three_interpolate_grad_lds_kernel, grid, dim3(TI_THREADS), (size_t)tc * m * sizeof(float),
+                           as_stream(stream), c, n, m, tc, grad_out, idx, weight, grad_points);
+        return check_launch("three_interpolate_grad");
+    }
     dim3 grid(divup(n, TI_THREADS), divup(c, TI_CG), b);
     hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(TI_THREADS), 0, as_stream(stream), c,
                        n, m, grad_out, idx, weight, grad_points);

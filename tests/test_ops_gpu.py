@@ -191,7 +191,7 @@ def test_three_nn_exact_ties_prefer_lower_index(oracle, dev):
     np.testing.assert_array_equal(i.cpu().numpy(), ref_i)
 
 
-@pytest.mark.parametrize("C,m,n", [(1024, 64, 256), (256, 1024, 4096), (5, 33, 77)])
+@pytest.mark.parametrize("C,m,n", [(1024, 64, 256), (256, 1024, 4096), (5, 33, 77), (9, 4096, 9000), (3, 20000, 500)])
 def test_three_interpolate_and_grad(oracle, dev, C, m, n):
     rng = np.random.default_rng(C)
     feat = rng.standard_normal((2, C, m)).astype(np.float32)
