@@ -202,6 +202,17 @@ int pdm_stack_three_interpolate_grad(void *stream, int N, int C, const float *gr
 int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
                                       const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points);
 
+/* ---- diagnostics (process-global tuning switches used by tools/diag/ A/B measurements; every setting gives
+ * identical results; each returns the previous value; not for production callers) ------------------------- */
+int pdm_tune_fps_variant(int v);        /* 8192 < n <= 16384: 0 pruned 1024x16 (default), 3 pruned 512x32, 1 / 2 unpruned */
+int pdm_tune_fused_waves(int w);        /* channel-split waves per workgroup: 0 heuristic, 1/2/4/8 */
+int pdm_tune_fused_tiles(int t);        /* 16-position tiles per group: 0 heuristic, 1, 2 */
+int pdm_tune_fused_groups(int n);       /* position groups per workgroup: 0 heuristic, 1/2/4/8 */
+int pdm_tune_fused_wg_per_cu(int n);    /* grid cap = 256 CUs x n workgroups */
+int pdm_tune_fused_lds_cap(int bytes);  /* LDS a two-tile workgroup may take (<= 160 KB) */
+int pdm_tune_fused_reg(int on);         /* register-resident SA form for small scales */
+int pdm_tune_fused_gemm(int on);        /* LDS-tiled GEMM for single-layer rows / two-layer FP with tiny skip */
+
 /* count device-to-device copies dst[k] <- src[k] (bytes[k] each; host arrays) in one launch per 48 buffers.
  * Plumbing for the stream pipeline's hand-over buffers, not a reference operator. */
 int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes);

@@ -943,7 +943,7 @@ extern "C" int pdm_tune_fused_gemm(int on) { const int old = g_fused_gemm; g_fus
 extern "C" int pdm_tune_fused_reg(int on) { const int old = g_fused_reg; g_fused_reg = on != 0; return old; }
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
 extern "C" int pdm_tune_fused_groups(int n) { const int old = g_fused_groups; g_fused_groups = (n == 1 || n == 2 || n == 4 || n == 8) ? n : 0; return old; }
-extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = t; return old; }  // kept for ABI stability; no effect
+extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fused_tiles = t; return old; }  // 0 = heuristic, 1 / 2 = force tiles per group
 
 #define FUSED_LAUNCH2(KERNEL, W, G, PRE, blocks, lds_bytes, ...)                                              \
     do {                                                                                                       \
