@@ -376,8 +376,11 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     __shared__ unsigned short order[BLOCK * PPT];  // sorted point indices, then (slot, thread) -> index
     __shared__ float red[6][NW];
     __shared__ int wsum[NW];
-    const int b = MULTI ? blockIdx.x / G : blockIdx.x;
-    const int grp = MULTI ? blockIdx.x - b * G : 0;
+    // MULTI: workgroups are dealt to the 8 XCDs round-robin by blockIdx; the G workgroups of one cloud take ids
+    // b, b + nb, b + 2 nb, ... so that (when nb is a multiple of 8) they share an XCD and its L2 for the exchange
+    const int nb_ = MULTI ? (int)gridDim.x / G : 1;
+    const int b = MULTI ? (int)blockIdx.x % nb_ : blockIdx.x;
+    const int grp = MULTI ? (int)blockIdx.x / nb_ : 0;
     const int per = MULTI ? (n_total + G - 1) / G : n_total;   // points per workgroup (<= BLOCK*PPT)
     const int k0 = grp * per;                                   // first global index of this workgroup
     const int n = max(0, min(per, n_total - k0));               // its point count
