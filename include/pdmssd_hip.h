@@ -202,6 +202,15 @@ int pdm_stack_three_interpolate_grad(void *stream, int N, int C, const float *gr
 int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
                                       const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points);
 
+/* ---- input path -------------------------------------------------------
+ * sample_points (pcdet/datasets/processor/data_processor.py:182-212) + the batch-index column of collate_batch
+ * (pcdet/datasets/dataset.py:237-244) for B raw clouds resident in HBM: raw (sum counts, C) rows [x, y, z, ...],
+ * counts (B) int32 on the device, out (B * num_points, 1 + C) rows [cloud, x, y, z, ...]; choice (B * num_points)
+ * int32 or NULL receives the chosen raw row per output row.  The random draw is defined by counter-based hashes of
+ * (seed, cloud, row) — DESIGN.md section 10 — not by numpy's RNG.  num_points <= 16384, 3 <= C <= 16. */
+int pdm_sample_points(void *stream, int B, int num_points, unsigned seed, int C, const float *raw,
+                      const int *counts, float *out, int *choice);
+
 /* ---- diagnostics (process-global tuning switches used by tools/diag/ A/B measurements; every setting gives
  * identical results; each returns the previous value; not for production callers) ------------------------- */
 int pdm_tune_fps_variant(int v);        /* 8192 < n <= 16384: 0 pruned 1024x16 (default), 3 pruned 512x32, 1 / 2 unpruned */

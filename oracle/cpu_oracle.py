@@ -344,3 +344,59 @@ def stack_furthest_point_sample(xyz, xyz_batch_cnt, npoint):
     rc = lib().oracle_stack_furthest_point_sampling(B, px, temp.ctypes.data_as(_f32p), pxc, out.ctypes.data_as(_i32p), pmc)
     assert rc == 0
     return out
+
+
+# ---- input path (N1): the build-defined draw of pdm_sample_points, in numpy ------------------------------------
+
+def _fmix32(h):
+    h = np.asarray(h, dtype=np.uint32).copy()
+    with np.errstate(over="ignore"):
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85ebca6b); h ^= h >> np.uint32(13); h *= np.uint32(0xc2b2ae35)
+        h ^= h >> np.uint32(16)
+    return h
+
+
+def _ip_key(seed, cloud, stream, i):
+    with np.errstate(over="ignore"):
+        base = _fmix32(np.uint32(seed) ^ (np.uint32(cloud) * np.uint32(0x9E3779B1)) ^ (np.uint32(stream) * np.uint32(0x7F4A7C15)))
+        return _fmix32(base + np.asarray(i, dtype=np.uint32) * np.uint32(0x9E3779B9))
+
+
+def sample_points_choice(points, num_points, seed, cloud):
+    """Raw-row index per output row for ONE cloud (points (N,C)), following data_processor.py:189-210 with the draw
+    defined in pdm_ssd_amd/csrc/input_path.hip: k random members = the k smallest (key_1, i); shuffle = ascending
+    (key_2 or key_3 for the extra copy, i, copy)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    N, P = pts.shape[0], int(num_points)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    depth = np.sqrt(((x * x).astype(np.float32) + (y * y).astype(np.float32)).astype(np.float32) + (z * z).astype(np.float32))
+    near = depth.astype(np.float32) < np.float32(40.0)
+    idx = np.arange(N, dtype=np.int64)
+    k1 = _ip_key(seed, cloud, 1, idx)
+
+    def draw(members, k):
+        order = np.lexsort((members, k1[members]))          # by key, then index
+        return members[order[:k]]
+
+    if P < N:
+        far = idx[~near]
+        chosen = np.concatenate([far, draw(idx[near], P - len(far))]) if P > len(far) else draw(idx, P)
+        copy = np.zeros(len(chosen), dtype=np.int64)
+    else:
+        extra = draw(idx, P - N)
+        chosen = np.concatenate([idx, extra])
+        copy = np.concatenate([np.zeros(N, dtype=np.int64), np.ones(len(extra), dtype=np.int64)])
+    k2 = np.where(copy == 1, _ip_key(seed, cloud, 3, chosen), _ip_key(seed, cloud, 2, chosen))
+    order = np.lexsort((copy, chosen, k2))
+    return chosen[order].astype(np.int32)
+
+
+def sample_points_batch(clouds, num_points, seed):
+    """list of (N_i, C) arrays -> (points (B*num_points, 1+C) rows [cloud, x, y, z, ...], choice (B*num_points,))."""
+    rows, choices = [], []
+    for b, c in enumerate(clouds):
+        ch = sample_points_choice(c, num_points, seed, b)
+        sel = np.asarray(c, dtype=np.float32)[ch]
+        rows.append(np.concatenate([np.full((len(ch), 1), b, dtype=np.float32), sel], axis=1))
+        choices.append(ch)
+    return np.concatenate(rows), np.concatenate(choices)

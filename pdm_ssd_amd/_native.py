@@ -37,6 +37,7 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
+    "pdm_sample_points": [_i, _i, ctypes.c_uint, _i, _vp, _vp, _vp, _vp],
     "pdm_stack_ball_query": [_i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_stack_group_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_stack_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
