@@ -130,3 +130,51 @@ def test_gpu_ops_match_regression_vectors(vec, dev):
     d, i3 = pu.three_nn(xyz, new_xyz)
     np.testing.assert_array_equal(i3.cpu().numpy(), vec['nn_idx'])
     np.testing.assert_array_equal(pu.three_interpolate(t(vec['interp_feat']), i3, t(vec['interp_w'])).cpu().numpy(), vec['interp_out'])
+
+
+# ---- pointnet2_stack: fixtures produced by the reference's own stack modules (tests/golden/gen_stack_fixtures.py) ----
+
+@pytest.fixture(scope="module")
+def sref():
+    return np.load(os.path.join(G, "ref_stack_modules.npz"))
+
+
+def test_stack_query_and_group_matches_reference_glue(sref):
+    """The reference's stack QueryAndGroup.forward (mask, centre subtraction, zeroing of empty balls, concat) ==
+    the same composition of this repo's stack oracle."""
+    idx, empty = o.stack_ball_query(0.4, 8, sref['xyz'], sref['counts'], sref['new_xyz'], sref['mcounts'])
+    np.testing.assert_array_equal(idx, sref['qg_idx'])
+    gx = o.stack_grouping_operation(sref['xyz'], sref['counts'], idx, sref['mcounts']) - sref['new_xyz'][:, :, None]
+    gf = o.stack_grouping_operation(sref['feat'], sref['counts'], idx, sref['mcounts'])
+    gx[empty] = 0; gf[empty] = 0
+    np.testing.assert_array_equal(np.concatenate([gx, gf], 1), sref['qg_out'])
+    assert empty[5] and (sref['qg_out'][5] == 0).all()
+
+
+def test_stack_module_state_dicts_load_strictly(sref):
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    _load(sm.StackSAModuleMSG(radii=[0.4, 0.8], nsamples=[8, 16], mlps=[[4, 8, 16], [4, 8, 24]]), sref, 'sa_state.')
+    _load(sm.StackPointnetFPModule(mlp=[20, 12, 8]), sref, 'fp_state.')
+
+
+@pytest.mark.gpu
+def test_gpu_stack_modules_match_reference_fixtures(sref, dev):
+    """HIP stack operators + this repo's stack modules (fused MFMA path and torch path) against the outputs of the
+    reference's StackSAModuleMSG / StackPointnetFPModule / QueryAndGroup / stack_farthest_point_sample."""
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_utils as su
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xyz, new_xyz, feat, xc, nc = t(sref['xyz']), t(sref['new_xyz']), t(sref['feat']), t(sref['counts']), t(sref['mcounts'])
+    grouped, idx = su.QueryAndGroup(0.4, 8, use_xyz=True)(xyz, xc, new_xyz, nc, feat)
+    np.testing.assert_array_equal(idx.cpu().numpy(), sref['qg_idx'])
+    np.testing.assert_array_equal(grouped.cpu().numpy(), sref['qg_out'])
+    np.testing.assert_array_equal(su.stack_farthest_point_sample(xyz, xc, [10, 5, 8]).cpu().numpy(), sref['fps_idx'])
+    sa = _load(sm.StackSAModuleMSG(radii=[0.4, 0.8], nsamples=[8, 16], mlps=[[4, 8, 16], [4, 8, 24]]), sref, 'sa_state.').to(dev)
+    fp = _load(sm.StackPointnetFPModule(mlp=[20, 12, 8]), sref, 'fp_state.').to(dev)
+    for fused_path in (True, False):
+        sa.use_fused = fp.use_fused = fused_path
+        with torch.no_grad():
+            _, nf = sa(xyz, xc, new_xyz, nc, feat)
+            fo = fp(xyz, xc, new_xyz, nc, feat, t(sref['fp_kfeat']))
+        np.testing.assert_allclose(nf.cpu().numpy(), sref['sa_out'], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(fo.cpu().numpy(), sref['fp_out'], rtol=1e-4, atol=1e-4)
