@@ -202,6 +202,21 @@ int pdm_stack_three_interpolate_grad(void *stream, int N, int C, const float *gr
 int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
                                       const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points);
 
+/* ---- rotated-box IoU / NMS ---------------------------------------------
+ * One entry per function of the reference's iou3d_nms_cuda extension (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp):
+ *   boxes_overlap_bev_gpu / boxes_iou_bev_gpu        iou3d_nms.cpp:55,96     (na, nb) areas / BEV IoUs
+ *   boxes_aligned_overlap_bev_gpu, paired_boxes_overlap_bev_gpu  :37,76      element-wise overlap of two box lists
+ *   nms_gpu / nms_normal_gpu                         iou3d_nms.cpp:137,186   greedy suppression of score-sorted boxes
+ * Boxes are rows of 7 floats [x, y, z, dx, dy, dz, heading].  pdm_nms differs from the reference in mechanism only:
+ * the suppression mask is reduced on the device; keep (n) int64 and *num_out are DEVICE buffers, workspace >=
+ * pdm_nms_workspace_bytes(n). */
+int pdm_boxes_overlap_bev(void *stream, int na, const float *boxes_a, int nb, const float *boxes_b, float *out);
+int pdm_boxes_iou_bev(void *stream, int na, const float *boxes_a, int nb, const float *boxes_b, float *out);
+int pdm_boxes_aligned_overlap_bev(void *stream, int n, const float *boxes_a, const float *boxes_b, float *out);
+size_t pdm_nms_workspace_bytes(int n);
+int pdm_nms(void *stream, int n, const float *boxes, float thresh, int normal, void *workspace,
+            size_t workspace_bytes, long long *keep, int *num_out);
+
 /* ---- input path -------------------------------------------------------
  * sample_points (pcdet/datasets/processor/data_processor.py:182-212) + the batch-index column of collate_batch
  * (pcdet/datasets/dataset.py:237-244) for B raw clouds resident in HBM: raw (sum counts, C) rows [x, y, z, ...],

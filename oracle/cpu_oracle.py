@@ -25,7 +25,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pointnet2_stack_oracle.c", "pdm_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pointnet2_stack_oracle.c", "iou3d_oracle.c", "pdm_oracle.c", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -400,3 +400,31 @@ def sample_points_batch(clouds, num_points, seed):
         rows.append(np.concatenate([np.full((len(ch), 1), b, dtype=np.float32), sel], axis=1))
         choices.append(ch)
     return np.concatenate(rows), np.concatenate(choices)
+
+
+# ---- rotated-box IoU / NMS (N2): oracle/iou3d_oracle.c ---------------------------------------------------------
+
+def boxes_overlap_bev(boxes_a, boxes_b, iou=False):
+    a, pa = _f(boxes_a); b, pb = _f(boxes_b)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().oracle_boxes_pairwise_bev(1 if iou else 0, a.shape[0], pa, b.shape[0], pb, out.ctypes.data_as(_f32p))
+    return out
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    return boxes_overlap_bev(boxes_a, boxes_b, iou=True)
+
+
+def boxes_aligned_overlap_bev(boxes_a, boxes_b):
+    a, pa = _f(boxes_a); b, pb = _f(boxes_b)
+    out = np.zeros((a.shape[0],), dtype=np.float32)
+    lib().oracle_boxes_aligned_overlap_bev(a.shape[0], pa, pb, out.ctypes.data_as(_f32p))
+    return out
+
+
+def nms(sorted_boxes, thresh, normal=False):
+    """Greedy NMS over boxes already in descending score order -> kept positions (int64)."""
+    b, pb = _f(sorted_boxes)
+    keep = np.zeros((b.shape[0],), dtype=np.int64)
+    k = lib().oracle_nms(1 if normal else 0, b.shape[0], pb, ctypes.c_float(thresh), keep.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+    return keep[:k]

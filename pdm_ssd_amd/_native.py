@@ -37,6 +37,10 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
+    "pdm_boxes_overlap_bev": [_i, _vp, _i, _vp, _vp],
+    "pdm_boxes_iou_bev": [_i, _vp, _i, _vp, _vp],
+    "pdm_boxes_aligned_overlap_bev": [_i, _vp, _vp, _vp],
+    "pdm_nms": [_i, _vp, _f, _i, _vp, ctypes.c_size_t, _vp, _vp],
     "pdm_sample_points": [_i, _i, ctypes.c_uint, _i, _vp, _vp, _vp, _vp],
     "pdm_stack_ball_query": [_i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_stack_group_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -64,7 +68,7 @@ _SIGNATURES = {
 }
 EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes",
            "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes",
-           "pdm_gather_bev_workspace_bytes"] + list(_SIGNATURES)
+           "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -91,6 +95,8 @@ def lib():
         l.pdm_gather_bev_workspace_bytes.argtypes = [_i] * 6
         l.pdm_three_nn_grid_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_three_nn_grid_workspace_bytes.argtypes = [_i, _i]
+        l.pdm_nms_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_nms_workspace_bytes.argtypes = [_i]
         if l.pdm_abi_version() != ABI_VERSION:
             raise NativeLibraryError(
                 f"libpdmssd_hip.so ABI {l.pdm_abi_version()} != expected {ABI_VERSION}; rebuild it")

@@ -193,3 +193,34 @@ def test_stack_group_and_fps_ragged():
     np.testing.assert_array_equal(grouped[2, :, 1], feats[1305])
     g = o.stack_grouping_operation_grad(np.ones_like(grouped), idx, [1, 1, 1], [5, 1300, 40], 1345)
     assert g.sum() == grouped.size and g[1305, 0] == 1 and g[0, 0] == 1
+
+
+# ---- rotated-box IoU / NMS oracle (closed-form answers) --------------------------------------------------------
+
+def test_iou3d_oracle_closed_form_areas():
+    b = lambda x, y, dx, dy, h: [x, y, 0.0, dx, dy, 1.0, h]
+    boxes = np.array([b(0, 0, 4, 2, 0.0), b(0, 0, 4, 2, np.pi / 2), b(1, 0, 4, 2, 0.0), b(10, 10, 1, 1, 0.3),
+                      b(0, 0, 2, 2, 0.0), b(0, 0, 2, 2, np.pi / 4), b(0.5, 0.5, 1, 1, np.pi)], np.float32)
+    ov = o.boxes_overlap_bev(boxes, boxes)
+    np.testing.assert_allclose(np.diag(ov), boxes[:, 3] * boxes[:, 4], rtol=1e-5)        # a box with itself
+    np.testing.assert_allclose(ov[0, 1], 4.0, rtol=1e-5)                                   # 4x2 against its 90 degree turn: 2x2
+    np.testing.assert_allclose(ov[0, 2], 6.0, rtol=1e-5)                                   # shifted by 1 along x: 3x2
+    assert ov[0, 3] == 0.0 and ov[3, 0] == 0.0                                             # disjoint
+    np.testing.assert_allclose(ov[4, 5], 8.0 * (np.sqrt(2.0) - 1.0), rtol=1e-5)            # square vs 45 degree square: octagon
+    np.testing.assert_allclose(ov[4, 6], 1.0, rtol=1e-5)                                   # contained unit square, heading pi
+    np.testing.assert_allclose(ov, ov.T, rtol=1e-5, atol=1e-6)
+    iou = o.boxes_iou_bev(boxes, boxes)
+    np.testing.assert_allclose(iou[0, 2], 6.0 / 10.0, rtol=1e-5)
+    np.testing.assert_allclose(o.boxes_aligned_overlap_bev(boxes, boxes[::-1].copy()), [ov[i, 6 - i] for i in range(7)], rtol=1e-6)
+
+
+def test_iou3d_oracle_nms_known_answer():
+    b = lambda x, y, h=0.0: [x, y, 0.0, 2.0, 2.0, 1.0, h]
+    # in score order: A; B overlaps A by 1x2 (IoU 1/3); C overlaps A by 1.8x2 (IoU 0.818); D far away; E overlaps B strongly
+    boxes = np.array([b(0, 0), b(1.0, 0), b(0.2, 0), b(10, 0), b(1.1, 0, 0.05)], np.float32)
+    np.testing.assert_array_equal(o.nms(boxes, 0.5), [0, 1, 3])          # C removed by A, E removed by B
+    # at 0.3 B (IoU 1/3 with A) goes too, so nothing suppresses E any more (its IoU with A is about 0.29): E is kept
+    np.testing.assert_array_equal(o.nms(boxes, 0.3), [0, 3, 4])
+    np.testing.assert_array_equal(o.nms(boxes, 0.9), [0, 1, 2, 3, 4])
+    np.testing.assert_array_equal(o.nms(boxes, 0.5, normal=True), [0, 1, 3])
+    assert len(o.nms(boxes[:0], 0.5)) == 0
