@@ -216,6 +216,9 @@ int pdm_boxes_aligned_overlap_bev(void *stream, int n, const float *boxes_a, con
 size_t pdm_nms_workspace_bytes(int n);
 int pdm_nms(void *stream, int n, const float *boxes, float thresh, int normal, void *workspace,
             size_t workspace_bytes, long long *keep, int *num_out);
+/* roiaware_pool3d's points_in_boxes_gpu (roiaware_pool3d.cpp / roiaware_pool3d_kernel.cu:313-336): boxes (B,T,7),
+ * pts (B,M,3) -> box_idx (B,M) = first containing box of the sample's list, -1 for background (every entry written). */
+int pdm_points_in_boxes(void *stream, int B, int T, int M, const float *boxes, const float *pts, int *box_idx);
 
 /* ---- input path -------------------------------------------------------
  * sample_points (pcdet/datasets/processor/data_processor.py:182-212) + the batch-index column of collate_batch

@@ -428,3 +428,12 @@ def nms(sorted_boxes, thresh, normal=False):
     keep = np.zeros((b.shape[0],), dtype=np.int64)
     k = lib().oracle_nms(1 if normal else 0, b.shape[0], pb, ctypes.c_float(thresh), keep.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
     return keep[:k]
+
+
+def points_in_boxes(points, boxes):
+    """points (B,M,3), boxes (B,T,7) -> (B,M) int32 first containing box or -1 (roiaware_pool3d_kernel.cu:313-336)."""
+    pts, pp = _f(points); bx, pb = _f(boxes)
+    B, M, _ = pts.shape
+    out = np.zeros((B, M), dtype=np.int32)
+    lib().oracle_points_in_boxes(B, bx.shape[1], M, pb, pp, out.ctypes.data_as(_i32p))
+    return out

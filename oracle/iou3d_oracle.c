@@ -151,3 +151,27 @@ int oracle_nms(int normal, int n, const float *boxes, float thresh, long long *k
     free(removed);
     return kept;
 }
+
+/* pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:16-36, 313-336 — for every point the FIRST box (in list
+ * order) that contains it, -1 for background.  Inside: |z - cz| <= dz/2 and, after rotating the offset by -heading,
+ * |lx| < dx/2 + 1e-5 and |ly| < dy/2 + 1e-5 (the reference evaluates these comparisons in double: dz / 2.0, the
+ * float MARGIN promoted).  boxes (B, T, 7), pts (B, M, 3) -> box_idx (B, M). */
+int oracle_points_in_boxes(int B, int T, int M, const float *boxes, const float *pts, int *box_idx) {
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < M; ++p) {
+            const float *pt = pts + ((size_t)b * M + p) * 3;
+            int found = -1;
+            for (int k = 0; k < T && found < 0; ++k) {
+                const float *bx = boxes + ((size_t)b * T + k) * 7;
+                if ((double)fabsf(pt[2] - bx[2]) > (double)bx[5] / 2.0) continue;
+                const float sx = pt[0] - bx[0], sy = pt[1] - bx[1];
+                const float c = cosf(-bx[6]), s = sinf(-bx[6]);
+                const float lx = sx * c + sy * (-s), ly = sx * s + sy * c;
+                const float margin = 1e-5f;
+                if (fabs((double)lx) < (double)bx[3] / 2.0 + (double)margin && fabs((double)ly) < (double)bx[4] / 2.0 + (double)margin) found = k;
+            }
+            box_idx[(size_t)b * M + p] = found;
+        }
+    return 0;
+}

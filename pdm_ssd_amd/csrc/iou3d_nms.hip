@@ -242,3 +242,48 @@ extern "C" int pdm_nms(void *stream, int n, const float *boxes, float thresh, in
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, as_stream(stream), n, cb, mask, keep, num_out);
     return check_launch("nms(scan)");
 }
+
+// ---- points_in_boxes (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:313-336): the first box of the
+// sample's list that contains each point, -1 for background.  Boxes staged in LDS in chunks of 128.
+namespace pdm {
+__global__ __launch_bounds__(256) void points_in_boxes_kernel(int T, int M, const float *__restrict__ boxes,
+                                                              const float *__restrict__ pts, int *__restrict__ box_idx) {
+    __shared__ float sb[128 * 7];
+    const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < M;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) {
+        const float *pt = pts + ((size_t)b * M + p) * 3;
+        x = pt[0]; y = pt[1]; z = pt[2];
+    }
+    int found = -1;
+    for (int k0 = 0; k0 < T; k0 += 128) {
+        const int nk = min(128, T - k0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nk * 7; e += blockDim.x) sb[e] = boxes[((size_t)b * T + k0) * 7 + e];
+        __syncthreads();
+        if (!live || found >= 0) continue;
+        for (int k = 0; k < nk; ++k) {
+            const float *bx = sb + k * 7;
+            if ((double)fabsf(z - bx[2]) > (double)bx[5] / 2.0) continue;
+            const float sx = x - bx[0], sy = y - bx[1];
+            const float c = cosf(-bx[6]), s = sinf(-bx[6]);
+            const float lx = sx * c + sy * (-s), ly = sx * s + sy * c;
+            if (fabs((double)lx) < (double)bx[3] / 2.0 + (double)1e-5f && fabs((double)ly) < (double)bx[4] / 2.0 + (double)1e-5f) {
+                found = k0 + k;
+                break;
+            }
+        }
+    }
+    if (live) box_idx[(size_t)b * M + p] = found;
+}
+}  // namespace pdm
+
+extern "C" int pdm_points_in_boxes(void *stream, int B, int T, int M, const float *boxes, const float *pts, int *box_idx) {
+    PDM_REQUIRE(B >= 0 && T >= 0 && M >= 0 && B <= 65535, PDM_E_BADARG, "points_in_boxes: B=%d T=%d M=%d", B, T, M);
+    if (B == 0 || M == 0) return 0;
+    PDM_REQUIRE(pts && box_idx && (T == 0 || boxes), PDM_E_BADARG, "points_in_boxes: null pointer");
+    hipLaunchKernelGGL(pdm::points_in_boxes_kernel, dim3(pdm::divup(M, 256), B), dim3(256), 0, pdm::as_stream(stream), T, M, boxes, pts,
+                       box_idx);
+    return pdm::check_launch("points_in_boxes");
+}

@@ -100,3 +100,15 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
 def nms_normal_gpu(boxes, scores, thresh, **kwargs):
     """ref :139-152 — NMS on the axis-aligned footprints (headings ignored)."""
     return _nms(boxes, scores, thresh, None, normal=True)
+
+
+def points_in_boxes_gpu(points, boxes):
+    """pcdet/ops/roiaware_pool3d/roiaware_pool3d_utils.py:28-41 — points (B, M, 3), boxes (B, T, 7) ->
+    box_idxs_of_pts (B, M) int32: the first box of the sample's list containing the point, -1 = background."""
+    assert boxes.shape[0] == points.shape[0]
+    assert boxes.shape[2] == 7 and points.shape[2] == 3
+    B, M, _ = points.shape
+    pts, bxs = points.float().contiguous(), boxes.float().contiguous()
+    out = torch.full((B, M), -1, dtype=torch.int32, device=points.device)
+    _native.call("pdm_points_in_boxes", _stream(points), B, boxes.shape[1], M, bxs.data_ptr(), pts.data_ptr(), out.data_ptr())
+    return out

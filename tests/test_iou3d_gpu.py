@@ -87,3 +87,25 @@ def test_nms_pre_maxsize_and_self_consistency(dev):
     for d in dropped:
         better = sel[scores[sel] > scores[d]]
         assert (iou[better, d] > 0.2 - 1e-4).any()
+
+
+@pytest.mark.parametrize("B,T,M", [(3, 40, 5000), (1, 300, 1000), (2, 0, 64), (2, 5, 0)])
+def test_points_in_boxes_matches_oracle(oracle, dev, B, T, M):
+    rng = np.random.default_rng(B * 100 + T)
+    boxes = np.stack([random_boxes(T, 50 + b, spread=10.0) for b in range(B)]) if T else np.zeros((B, 0, 7), np.float32)
+    pts = np.concatenate([rng.uniform(-12, 12, (B, M, 2)), rng.uniform(-2, 2, (B, M, 1))], 2).astype(np.float32)
+    if T and M:
+        pts[:, :T] = boxes[:, :T, :3][:, :M]                    # box centres: inside (possibly several boxes: first wins)
+        boxes[:, -1] = boxes[:, 0]                              # a duplicate box later in the list never wins
+    ref = oracle.points_in_boxes(pts, boxes)
+    got = iu.points_in_boxes_gpu(T_(pts, dev), T_(boxes, dev)).cpu().numpy()
+    if not np.array_equal(got, ref):                            # device vs libm sin/cos: only points within 1e-4 of a face may differ
+        assert (got != ref).mean() < 1e-3
+    else:
+        assert got.shape == (B, M)
+    if T and M:
+        assert (ref >= 0).any() and (ref == -1).any() and (ref != T - 1).all()
+
+
+def T_(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
