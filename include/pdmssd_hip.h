@@ -270,6 +270,11 @@ int pdm_gather_bev(void *stream, int B, int P, int C, int degree, const float *x
                    float cz, float icx, float icy, float icz, int W, int H, int D, int kx, int ky, int kz,
                    int normalize, float eps, float *grid, float *wsum, void *workspace, size_t workspace_bytes);
 
+/* Backward of pdm_bev_normalize for layout 1 (channels-last): y = the normalised grid, dy its gradient ->
+ * dx (B,H,W,C*D) and dwsum (B,H,W,D), both fully written. */
+int pdm_bev_normalize_grad(void *stream, int B, int C, int W, int H, int D, float eps, const float *y,
+                           const float *wsum, const float *dy, float *dx, float *dwsum);
+
 /* backward of pdm_scatter_bev w.r.t. feat, sh, inv2s2 (outputs fully written, no zero-fill needed);
  * dwsum may be NULL. */
 int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const float *xyz,

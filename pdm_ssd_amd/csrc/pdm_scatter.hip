@@ -362,6 +362,48 @@ extern "C" int pdm_bev_normalize(void *stream, int B, int C, int W, int H, int D
     return check_launch("pdm_bev_normalize");
 }
 
+// Backward of the normalisation y = x / w (where |w| > eps, else y = x) for the channels-last layout, one wave per BEV
+// cell: dx = dy / w and dw = -(1/w) sum_c dy_c y_c in the same pass over the cell's C*D contiguous values.
+__global__ __launch_bounds__(256) void pdm_normalize_grad_kernel(long long cells_xy, int C, int D, float eps,
+                                                                 const float *__restrict__ y, const float *__restrict__ wsum,
+                                                                 const float *__restrict__ dy, float *__restrict__ dx,
+                                                                 float *__restrict__ dwsum) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int CD = C * D;
+    for (long long cell = wave0; cell < cells_xy; cell += nwaves) {
+        const float *yy = y + cell * CD, *gg = dy + cell * CD;
+        float *xx = dx + cell * CD;
+        for (int z = 0; z < D; ++z) {
+            const float w = wsum[cell * D + z];
+            const bool on = fabsf(w) > eps;
+            const float inv = on ? 1.0f / w : 1.0f;
+            float acc = 0.0f;
+            for (int c = lane; c < C; c += 64) {
+                const int q = c * D + z;
+                const float g = gg[q];
+                acc += g * yy[q];
+                xx[q] = g * inv;
+            }
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) dwsum[cell * D + z] = on ? -inv * acc : 0.0f;
+        }
+    }
+}
+
+extern "C" int pdm_bev_normalize_grad(void *stream, int B, int C, int W, int H, int D, float eps, const float *y,
+                                      const float *wsum, const float *dy, float *dx, float *dwsum) {
+    PDM_REQUIRE(B >= 0 && C >= 0 && W > 0 && H > 0 && D > 0, PDM_E_BADARG, "pdm_bev_normalize_grad: bad size");
+    const long long cells = (long long)B * H * W;
+    if (cells == 0 || C == 0) return 0;
+    PDM_REQUIRE(y && wsum && dy && dx && dwsum, PDM_E_BADARG, "pdm_bev_normalize_grad: null pointer");
+    const long long want = (cells + 3) / 4;
+    hipLaunchKernelGGL(pdm_normalize_grad_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, as_stream(stream),
+                       cells, C, D, eps, y, wsum, dy, dx, dwsum);
+    return check_launch("pdm_bev_normalize_grad");
+}
+
 extern "C" int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const float *xyz,
                                     const float *feat, const float *sh, const float *inv2s2,
                                     float ox, float oy, float oz, float cx, float cy, float cz,

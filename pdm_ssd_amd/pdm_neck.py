@@ -86,10 +86,7 @@ class PDMNeck(nn.Module):
             if torch.is_grad_enabled() and (feat.requires_grad or sh.requires_grad):
                 B = grid.shape[0]
                 if self.layout == 1:
-                    w = wsum.unsqueeze(-2)                                    # (B,H,W,1,D)
-                    g5 = grid.view(B, self.grid.H, self.grid.W, self.feature_dim, self.grid.D)
-                    g5 = torch.where(w.abs() > 1e-6, g5 / torch.where(w.abs() > 1e-6, w, torch.ones_like(w)), g5)
-                    grid = g5.view_as(grid)
+                    grid = pdm_ops.bev_normalize(grid, wsum, self.feature_dim, self.grid)   # one kernel each way
                 else:
                     w = wsum.permute(0, 3, 1, 2).unsqueeze(1)                 # (B,1,D,H,W)
                     g5 = grid.view(B, self.feature_dim, self.grid.D, self.grid.H, self.grid.W)

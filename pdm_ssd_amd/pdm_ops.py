@@ -101,6 +101,38 @@ def bev_normalize_(grid, wsum, C, grid_spec, layout=1, eps=1e-6):
     return grid
 
 
+class BevNormalize(Function):
+    """grid / wsum where |wsum| > eps (channels-last layout), IN PLACE on `grid`, differentiable w.r.t. both:
+    one kernel forward, one kernel backward (the torch expression costs six passes over the 0.6 GB grid)."""
+
+    @staticmethod
+    def forward(ctx, grid, wsum, C, grid_spec, eps):
+        g = grid_spec
+        grid = grid.contiguous()
+        _native.call("pdm_bev_normalize", _stream(grid), grid.shape[0], C, g.W, g.H, g.D, 1, float(eps), grid.data_ptr(),
+                     wsum.data_ptr())
+        ctx.mark_dirty(grid)
+        ctx.save_for_backward(grid, wsum)
+        ctx.spec = (C, g, float(eps))
+        return grid
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, wsum = ctx.saved_tensors
+        C, g, eps = ctx.spec
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(y)
+        dw = torch.empty_like(wsum)
+        _native.call("pdm_bev_normalize_grad", _stream(y), y.shape[0], C, g.W, g.H, g.D, eps, y.data_ptr(), wsum.data_ptr(),
+                     dy.data_ptr(), dx.data_ptr(), dw.data_ptr())
+        return dx, dw, None, None, None
+
+
+def bev_normalize(grid, wsum, C, grid_spec, eps=1e-6):
+    """Differentiable normalisation of a channels-last PDM grid (consumes `grid`)."""
+    return BevNormalize.apply(grid, wsum, C, grid_spec, eps)
+
+
 def pdm_gather(xyz, feat, sh, inv2s2, grid_spec, kernel, degree, normalize=True, eps=1e-6):
     """Inference form of pdm_scatter (+ normalise): no autograd, no atomics, bitwise reproducible.
     Returns (grid (B,H,W,C*D) channels-last storage, wsum (B,H,W,D)); every cell is written."""

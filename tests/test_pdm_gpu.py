@@ -196,3 +196,26 @@ def test_neck_module_contract(dev):
     with torch.no_grad():
         sf2 = neck({'sa_xyz': bd['sa_xyz'], 'sa_features': bd['sa_features']})['spatial_features']
     assert torch.isfinite(sf2).all()
+
+
+@pytest.mark.parametrize("D,C", [(1, 128), (2, 32), (3, 5)])
+def test_bev_normalize_function_matches_torch_autograd(dev, D, C):
+    """BevNormalize (one kernel forward, one backward) against the torch expression it replaces, values and both gradients."""
+    torch.manual_seed(D * 10 + C)
+    g = pdm_ops.BevGrid(RANGE, (3.2, 3.2, 4.0 / D))
+    B = 2
+    x0 = torch.randn(B, g.H, g.W, C * D, device=dev)
+    w0 = torch.randn(B, g.H, g.W, D, device=dev)
+    w0[torch.rand_like(w0) < 0.3] = 0.0                       # untouched cells: passed through
+    dy = torch.randn_like(x0)
+    x1, w1 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    w5 = w1.unsqueeze(-2)
+    x5 = x1.view(B, g.H, g.W, C, D)
+    ref = torch.where(w5.abs() > 1e-6, x5 / torch.where(w5.abs() > 1e-6, w5, torch.ones_like(w5)), x5).view_as(x1)
+    ref.backward(dy)
+    x2, w2 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    out = pdm_ops.bev_normalize(x2 * 1.0, w2, C, g)           # (x2 * 1.0: the Function consumes its input in place)
+    out.backward(dy)
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(x2.grad, x1.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(w2.grad, w1.grad, rtol=1e-4, atol=1e-4)
