@@ -129,15 +129,16 @@ __global__ __launch_bounds__(256) void three_nn_weights_kernel(long long rows, c
 // sample, streams grad_out[b, c, :] coalesced, adds into LDS with ds_add_f32 and writes every grad_points row once.
 // The global-atomic form above issues 64 scattered 4-byte atomics per wave instruction (17 ms for FP1 at bs=32);
 // this one is bound by the LDS atomic rate.
-__global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_lds_kernel(
+constexpr int TIL_THREADS = 1024;   // 16 waves per workgroup: the loop is a chain of dependent loads, occupancy hides it
+__global__ __launch_bounds__(TIL_THREADS) void three_interpolate_grad_lds_kernel(
     int c, int n, int m, int tc, const float *__restrict__ grad_out, const int *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ grad_points) {
     extern __shared__ float s_acc[];   // tc x m
     const int b = blockIdx.y, c0 = blockIdx.x * tc;
     const int nc = min(tc, c - c0);
-    for (int e = threadIdx.x; e < nc * m; e += TI_THREADS) s_acc[e] = 0.0f;
+    for (int e = threadIdx.x; e < nc * m; e += TIL_THREADS) s_acc[e] = 0.0f;
     __syncthreads();
-    for (int j = threadIdx.x; j < n; j += TI_THREADS) {
+    for (int j = threadIdx.x; j < n; j += TIL_THREADS) {
         const int *id = idx + ((size_t)b * n + j) * 3;
         const float *w = weight + ((size_t)b * n + j) * 3;
         const int i0 = id[0], i1 = id[1], i2 = id[2];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_lds_kernel(
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nc * m; e += TI_THREADS) {
+    for (int e = threadIdx.x; e < nc * m; e += TIL_THREADS) {
         const int ci = e / m, k = e - ci * m;
         grad_points[((size_t)b * c + c0 + ci) * m + k] += s_acc[e];   // rows are exclusive to this workgroup
     }
@@ -208,7 +209,7 @@ extern "C" int pdm_three_interpolate_grad(void *stream, int b, int c, int n, int
         tc = tc > 8 ? 8 : tc;
         tc = tc > c ? c : tc;
         dim3 grid(divup(c, tc), b);
-        hipLaunchKernelGGL(three_interpolate_grad_lds_kernel, grid, dim3(TI_THREADS), (size_t)tc * m * sizeof(float),
+        hipLaunchKernelGGL(three_interpolate_grad_lds_kernel, grid, dim3(TIL_THREADS), (size_t)tc * m * sizeof(float),
                            as_stream(stream), c, n, m, tc, grad_out, idx, weight, grad_points);
         return check_launch("three_interpolate_grad");
     }
