@@ -301,8 +301,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
-    ap.add_argument("--pipeline-depth", type=int, default=2, choices=[1, 2],
-                    help="batches whose sampling chain is in flight beside the feature path (pdm_ssd_amd/pipeline.py)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, choices=[1, 2, 3, 4, 5],
+                    help="batches whose sampling chain is in flight beside the feature path; >= 3 also cuts the level-1 "
+                         "FPS into depth - 1 resumable segments run side by side (pdm_ssd_amd/pipeline.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")
     ap.add_argument("--train", action="store_true",
@@ -334,7 +335,8 @@ def main():
 
     def step_pipelined():
         # features of this batch || sampling of the following batch(es) (same synthetic cloud every step)
-        bd = pipe.step(points, points, B, extra={'points_per_sample_checked': True}, points_next2=points)
+        bd = pipe.step(points, points, B, extra={'points_per_sample_checked': True}, points_next2=points,
+                       points_ahead=[points] * args.pipeline_depth)
         return bd['spatial_features'], bd['point_features']
 
     step = step_serial if args.serial else step_pipelined
@@ -346,7 +348,12 @@ def main():
         # per-sample point-count check of the backbone (host sync) done once, outside the timed region
         counts = torch.bincount(points[:, 0].long(), minlength=B)
         assert int(counts.min()) == int(counts.max()) == N
-        pipe.prime(points, B)
+        if args.pipeline_depth >= 3 and not (1024 < N <= 16384):
+            raise SystemExit("--pipeline-depth >= 3 needs 1024 < points <= 16384 (resumable FPS segments)")
+        if args.pipeline_depth >= 3:
+            pipe.prime_segmented([points] * args.pipeline_depth, B)
+        else:
+            pipe.prime(points, B)
         for _ in range(max(1, args.warmup)):
             step()
         torch.cuda.synchronize()
@@ -440,18 +447,27 @@ def main():
     # dominant roofline-bounded kernel of the step: the fused SA kernel (fp32 MFMA), all its launches (both entry
     # points).  FPS takes longer but is a latency-bound dependency chain (one workgroup per cloud) with no
     # bandwidth or matrix roofline; it is listed under "ops" with its iteration rate.
-    sa_ops = [o for o in ops if o["op"] in ("pdm_sa_mlp_fused", "pdm_sa_mlp_fused_pre")]
+    # (with the neighbour lists compacted the SA kernels only run the distinct neighbours — on sparse clouds a small
+    # part of the step — so the dominant MFMA entry point is picked by measured time, not by name)
+    KERNELS_OF = {"pdm_sa_mlp_fused": ("pdm::sa_mlp_fused_kernel", "pdm::sa_reg_mlp_kernel"),
+                  "pdm_sa_mlp_fused_pre": ("pdm::sa_mlp_fused_kernel",),
+                  "pdm_sa_mlp_packed": ("pdm::sa_packed_fused_kernel", "pdm::sa_reg_packed_kernel"),
+                  "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
+                  "pdm_fp_mlp_fused_pre": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<true>"),
+                  "pdm_rows_mlp_fused": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
+    sa_ops = sorted(mlp_ops, key=lambda o: -o["ms_per_step"])[:1]
     roofline = None
     if sa_ops:
         calls = sum(o["calls_per_step"] for o in sa_ops)
         per_launch_flop = sum(executed[o["op"]] for o in sa_ops) / calls
         per_launch_s = sum(o["ms_per_step"] for o in sa_ops) / 1e3 / calls
         ach = per_launch_flop / per_launch_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "pdm::sa_mlp_fused_kernel + pdm::sa_reg_mlp_kernel (all launches of "
-                                               "pdm_sa_mlp_fused and pdm_sa_mlp_fused_pre: the 8 SA scales)",
+        kernels = KERNELS_OF.get(sa_ops[0]["op"], ())
+        roofline = {"bound": "mfma", "kernel": " + ".join(kernels) + f" (all launches of {sa_ops[0]['op']}, the MFMA entry "
+                                               "point with the most time in the step)",
                     "achieved": round(ach, 2),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic("pdm::sa_mlp_fused_kernel", "pdm::sa_reg_mlp_kernel"), "traffic_unit": "HBM bytes per launch (PMC)",
+                    "traffic": pmc_traffic(*kernels) if kernels else None, "traffic_unit": "HBM bytes per launch (PMC)",
                     "launches_per_step": calls,
                     "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop),
                     "flops_counted": "executed (hoisted first layer), unpadded"}
@@ -486,6 +502,10 @@ def main():
                    "overlap": "none" if args.serial else
                               ("FPS chain of batch i+1 on a side stream under the feature half of batch i "
                                "(pdm_ssd_amd/pipeline.py)" if args.pipeline_depth == 1 else
+                               f"level-1 FPS cut into {args.pipeline_depth - 1} resumable segments: one launch per step runs "
+                               f"segment s of batch i+{args.pipeline_depth}-s side by side, the rest of batch i+1's coordinate "
+                               "chain on the neck's stream, under the feature half of batch i; every step does one full "
+                               "batch of every kind of work (pdm_ssd_amd/pipeline.py)" if args.pipeline_depth >= 3 else
                                "sampling two batches deep: level-1 FPS of batch i+2 and levels 2-4 of batch i+1 on side "
                                "streams under the feature half of batch i; every step does one full batch of every "
                                "kind of work (pdm_ssd_amd/pipeline.py)"),

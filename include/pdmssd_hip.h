@@ -79,6 +79,13 @@ size_t pdm_furthest_point_sampling_ws_bytes(int b, int n);
 int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m, const float *points, float *temp,
                                    int *idx, void *workspace, size_t workspace_bytes);
 
+/* The same operator as resumable segments (no reference counterpart; same indices): job q computes samples
+ * [j0[q], j1[q]) of its own batch of b clouds, continuing from the state an earlier segment left in temp[q] (running
+ * min-distances, 1e10 everywhere before the first segment) and idx[q] (samples [0, j0)).  The 1..4 jobs of a call
+ * belong to different batches and run side by side in one launch; host arrays of device pointers.  1024 < n <= 16384. */
+int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, int n, int m, const float *const *points,
+                                     float *const *temp, int *const *idx, const int *j0, const int *j1);
+
 /* replaces three_nn_wrapper_fast              interpolate.cpp:18-26 -> interpolate_gpu.cu:16-81
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) squared distances, idx (B,n,3). */
 int pdm_three_nn(void *stream, int b, int n, int m, const float *unknown, const float *known,
@@ -169,6 +176,23 @@ int pdm_sa_mlp_fused_pre(void *stream, int b, int n, int m, int nsample, const f
                          const float *new_xyz, const float *z_pm, int z_stride, int z_coff, const int *idx,
                          int nlayers, const int *dims, const float *wpack, const float *bias, float *out_pm,
                          int out_stride, int out_coff, int cout);
+/* Neighbour-list compaction for the fused SA kernels (no reference counterpart: ball_query pads short
+ * neighbourhoods with copies of the first hit, pointnet2/src/ball_query_gpu.cu:38-46, and the reference runs the
+ * shared MLP over those copies; max-pool over a multiset = max-pool over the set, so they can be dropped).
+ *   pdm_sa_pack: idx (B,M,nsample) int32, nsample 16 or 32 -> pack (pdm_sa_pack_rows(b,m,nsample) x 2 int32:
+ *     {source row b*n + neighbour, centre b*m + j | -1 dead}) and meta (8 int32: first row of the segment classes
+ *     L = 1,2,4,8,16,32, total rows, live rows).  A centre with cnt significant slots (1 + the last slot that differs
+ *     from slot 0) owns 2^ceil(log2 cnt) consecutive rows; classes are tile-aligned, order = centre order.
+ *   pdm_sa_mlp_packed: pdm_sa_mlp_fused (z_pm null) / pdm_sa_mlp_fused_pre (z_pm set) over that list; results are
+ *     bit-identical to the unpacked entry points. */
+size_t pdm_sa_pack_workspace_bytes(int b, int m);
+size_t pdm_sa_pack_rows(int b, int m, int nsample);
+int pdm_sa_pack(void *stream, int b, int n, int m, int nsample, const int *idx, void *workspace,
+                size_t workspace_bytes, int *pack, int *meta);
+int pdm_sa_mlp_packed(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
+                      const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride, int z_coff,
+                      const int *pack, const int *meta, int nlayers, const int *dims, const float *wpack,
+                      const float *bias, float *out_pm, int out_stride, int out_coff, int cout);
 int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
                          const float *skip_pm, const int *idx, const float *weight, int nlayers,
                          const int *dims, const float *wpack, const float *bias, float *out_pm,

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "pdm_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp],
     "pdm_furthest_point_sampling_ws": [_i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_furthest_point_sampling_jobs": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -54,6 +55,8 @@ _SIGNATURES = {
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused_pre": [_i] * 4 + [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i],
+    "pdm_sa_pack": [_i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    "pdm_sa_mlp_packed": [_i] * 5 + [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_tune_fps_variant": None,
     "pdm_tune_fused_waves": None,
     "pdm_tune_fused_tiles": None,
@@ -70,7 +73,8 @@ _SIGNATURES = {
 }
 EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes",
            "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes",
-           "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes"] + list(_SIGNATURES)
+           "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
+           "pdm_sa_pack_rows"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -98,6 +102,10 @@ def lib():
         l.pdm_three_nn_grid_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_three_nn_grid_workspace_bytes.argtypes = [_i, _i]
         l.pdm_nms_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_sa_pack_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_sa_pack_workspace_bytes.argtypes = [_i, _i]
+        l.pdm_sa_pack_rows.restype = ctypes.c_size_t
+        l.pdm_sa_pack_rows.argtypes = [_i, _i, _i]
         l.pdm_nms_workspace_bytes.argtypes = [_i]
         if l.pdm_abi_version() != ABI_VERSION:
             raise NativeLibraryError(

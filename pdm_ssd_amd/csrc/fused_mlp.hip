@@ -117,6 +117,35 @@ __device__ __forceinline__ f4 row16_max_nonneg4(f4 f) {
     return f;
 }
 
+// max over aligned groups of L (1, 2, 4, 8, >= 16 -> 16) lanes of a DPP row = the first log2 L stages of the butterfly
+// above; every lane of a group ends up with the group's maximum.  L is wave-uniform.
+__device__ __forceinline__ f4 seg_max_nonneg4(f4 f, int L) {
+    if (L <= 1) return f;
+    const float fx = f.x, fy = f.y, fz = f.z, fw = f.w;
+    int a = __float_as_int(fx), b = __float_as_int(fy), c = __float_as_int(fz), d = __float_as_int(fw);
+#define PDM_DPP4(CTRL)                                                        \
+    "v_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_max_i32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_max_i32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+    if (L >= 16)
+        asm volatile("s_nop 1\n\t" PDM_DPP4("quad_perm:[1,0,3,2]") PDM_DPP4("quad_perm:[2,3,0,1]")
+                     PDM_DPP4("row_half_mirror") PDM_DPP4("row_mirror") "s_nop 1"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if (L == 8)
+        asm volatile("s_nop 1\n\t" PDM_DPP4("quad_perm:[1,0,3,2]") PDM_DPP4("quad_perm:[2,3,0,1]")
+                     PDM_DPP4("row_half_mirror") "s_nop 1"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if (L == 4)
+        asm volatile("s_nop 1\n\t" PDM_DPP4("quad_perm:[1,0,3,2]") PDM_DPP4("quad_perm:[2,3,0,1]") "s_nop 1"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else
+        asm volatile("s_nop 1\n\t" PDM_DPP4("quad_perm:[1,0,3,2]") "s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef PDM_DPP4
+    f.x = __int_as_float(a); f.y = __int_as_float(b); f.z = __int_as_float(c); f.w = __int_as_float(d);
+    return f;
+}
+
 // ---- B-operand providers: float4 of channels [16kb + 4g, +4) of this lane's position ------------
 
 struct LdsIn {
@@ -270,6 +299,36 @@ struct PoolOut {
         const int c0 = 16 * mb + 4 * g;
         if (c0 + 4 <= cout) {
             *reinterpret_cast<f4 *>(orow + c0) = v;  // host guarantees 16-byte alignment of orow
+        } else {
+            if (c0 < cout) orow[c0] = v.x;
+            if (c0 + 1 < cout) orow[c0 + 1] = v.y;
+            if (c0 + 2 < cout) orow[c0 + 2] = v.z;
+        }
+    }
+};
+
+// SA epilogue of the compacted form (sa_pack.hip): a tile of class L holds 16/L whole centres (L = 32: half of one);
+// orow is set on the first lane of every live segment only.
+struct SegPoolOut {
+    float *pool;   // LDS, K_last floats: combines the tile pair of an L = 32 centre
+    float *orow;   // &out[centre][coff] on writer lanes, else null
+    int cout, g, L;
+    bool first_tile, last_tile;
+    __device__ __forceinline__ void operator()(int mb, f4 v) const {
+        v = seg_max_nonneg4(v, L);
+        if (!orow) return;
+        float *p = pool + 16 * mb + 4 * g;
+        if (!first_tile) {
+            const f4 o = *reinterpret_cast<const f4 *>(p);
+            v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
+        }
+        if (!last_tile) {
+            *reinterpret_cast<f4 *>(p) = v;
+            return;
+        }
+        const int c0 = 16 * mb + 4 * g;
+        if (c0 + 4 <= cout) {
+            *reinterpret_cast<f4 *>(orow + c0) = v;
         } else {
             if (c0 < cout) orow[c0] = v.x;
             if (c0 + 1 < cout) orow[c0 + 1] = v.y;
@@ -629,6 +688,68 @@ __global__ __launch_bounds__(64 * W * PSW) void sa_mlp_fused_kernel(MlpDesc d, S
     }
 }
 
+// class (segment length) of the tile that starts at `row`: classes are stored in ascending L, meta[k] = first row of class k
+__device__ __forceinline__ int pack_tile_L(int row, int m1, int m2, int m3, int m4, int m5) {
+    return 1 << ((row >= m1) + (row >= m2) + (row >= m3) + (row >= m4) + (row >= m5));
+}
+
+// The same SA scale over the compacted row list of sa_pack.hip: work unit = an aligned PAIR of 16-row tiles (the two
+// tiles of an L = 32 centre pool through `pool`; every other tile is self-contained), NT = 2 takes the pair at once,
+// NT = 1 in two sub-steps.  The number of pairs is read from meta[6] (device memory): the grid is sized for the worst
+// case and surplus workgroups leave at once.
+template <int W, int NT, int MAXNB, int PSW, bool PRE>
+__global__ __launch_bounds__(64 * W * PSW) void sa_packed_fused_kernel(MlpDesc d, SaArgs a,
+                                                                       const int2 *__restrict__ pack,
+                                                                       const int *__restrict__ meta,
+                                                                       const float *__restrict__ wpack,
+                                                                       const float *__restrict__ bias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_all % W, grp = wave_all / W;
+    const int pos = lane & 15, g = lane >> 4;
+    const int region = NT * 16 * (d.lds_p + d.lds_q) + d.pool_floats;
+    float *P = lds + grp * region;
+    float *Q = P + NT * 16 * d.lds_p;
+    float *pool = Q + NT * 16 * d.lds_q;
+    const int m1 = meta[1], m2 = meta[2], m3 = meta[3], m4 = meta[4], m5 = meta[5];
+    const int npairs = meta[6] >> 5;
+    constexpr int NSUB = 2 / NT;
+    for (int base = blockIdx.x * PSW; base < npairs; base += gridDim.x * PSW) {
+        const int unit = base + grp;  // groups past the end run dead tiles so barriers still match
+        for (int sub = 0; sub < NSUB; ++sub) {
+            Tiles<SaIn<PRE>, NT> in;
+            Tiles<SegPoolOut, NT> out;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tile = unit * 2 + sub * NT + t;
+                const bool live = unit < npairs;
+                const int2 e = pack[live ? tile * 16 + pos : 0];
+                const int L = pack_tile_L(tile * 16, m1, m2, m3, m4, m5);
+                const int ctr = live ? e.y : -1;
+                const float *c3 = a.new_xyz + (size_t)(ctr >= 0 ? ctr : 0) * 3;
+                const float *p3 = a.xyz + (size_t)e.x * 3;
+                const float rx = p3[0] - c3[0], ry = p3[1] - c3[1], rz = p3[2] - c3[2];  // pointnet2_utils.py:252
+                if constexpr (PRE) {
+                    in.t[t].zrow = a.z + (size_t)e.x * a.z_stride + a.z_coff + 4 * g;
+                    in.t[t].rx = g == 0 ? rx : 0.f; in.t[t].ry = g == 0 ? ry : 0.f; in.t[t].rz = g == 0 ? rz : 0.f;
+                } else {
+                    in.t[t].frow = a.cin > 0 ? a.feat + (size_t)e.x * a.cin : nullptr;
+                    in.t[t].rx = rx; in.t[t].ry = ry; in.t[t].rz = rz;
+                    in.t[t].cin = a.cin; in.t[t].g = g;
+                    in.t[t].vec = (a.cin & 3) == 0 && a.cin > 0;
+                }
+                const bool writer = ctr >= 0 && (pos & ((L < 16 ? L : 16) - 1)) == 0;
+                out.t[t].pool = pool;
+                out.t[t].orow = writer ? a.out + (size_t)ctr * a.out_stride + a.out_coff : nullptr;
+                out.t[t].cout = a.cout; out.t[t].g = g; out.t[t].L = L;
+                out.t[t].first_tile = L < 32 || (tile & 1) == 0;
+                out.t[t].last_tile = L < 32 || (tile & 1) == 1;
+            }
+            run_mlp<W, NT, MAXNB, PSW, PRE>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn<PRE>, NT>{&in}, TilesOut<SegPoolOut, NT>{&out});
+        }
+    }
+}
+
 template <int W, int NT, int MAXNB, int PSW, bool PRE>
 __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, FpArgs a,
                                                                     const float *__restrict__ wpack,
@@ -854,6 +975,132 @@ __global__ __launch_bounds__(256) void sa_reg_mlp_kernel(SaArgs a, const float *
 #undef PDM_CHAIN
 }
 
+// Register-resident form over the compacted row list (sa_pack.hip): one wave = one aligned tile pair per step.
+template <int B1, int B2, int B3>
+__global__ __launch_bounds__(256) void sa_reg_packed_kernel(SaArgs a, const int2 *__restrict__ pack,
+                                                            const int *__restrict__ meta,
+                                                            const float *__restrict__ wpack,
+                                                            const float *__restrict__ bias) {
+    constexpr int NT = 2;
+    const int lane = threadIdx.x & 63, pos = lane & 15, g = lane >> 4;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int m1 = meta[1], m2 = meta[2], m3 = meta[3], m4 = meta[4], m5 = meta[5];
+    const int npairs = meta[6] >> 5;
+    if (wave_id >= npairs) return;
+    const f4 *__restrict__ w1 = reinterpret_cast<const f4 *>(wpack) + lane;
+    const f4 *__restrict__ w2 = w1 + 64 * B1;
+    const f4 *__restrict__ w3 = w2 + 64 * B2 * B1;
+    f4 A1[B1], A2[B2][B1], A3[B3][B2];
+#pragma unroll
+    for (int mb = 0; mb < B1; ++mb) A1[mb] = w1[64 * mb];
+#pragma unroll
+    for (int mb = 0; mb < B2; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < B1; ++kb) A2[mb][kb] = w2[64 * (mb * B1 + kb)];
+#pragma unroll
+    for (int mb = 0; mb < B3; ++mb)
+#pragma unroll
+        for (int kb = 0; kb < B2; ++kb) A3[mb][kb] = w3[64 * (mb * B2 + kb)];
+    const float *__restrict__ bias1 = bias + 4 * g, *__restrict__ bias2 = bias1 + 16 * B1, *__restrict__ bias3 = bias2 + 16 * B2;
+#define PDM_CHAIN(ACC, A, B)                                                          \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, ACC, 0, 0, 0);           \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, ACC, 0, 0, 0);           \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, ACC, 0, 0, 0);           \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, ACC, 0, 0, 0);
+    int2 e_next[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) e_next[t] = pack[(wave_id * 2 + t) * 16 + pos];
+    for (int unit = wave_id; unit < npairs; unit += nwaves) {
+        f4 in[NT];
+        int ctr[NT], L[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int2 e = e_next[t];
+            ctr[t] = e.y;
+            L[t] = pack_tile_L((unit * 2 + t) * 16, m1, m2, m3, m4, m5);
+            const float *c3 = a.new_xyz + (size_t)(e.y >= 0 ? e.y : 0) * 3;
+            const size_t src = (size_t)e.x;
+            const float *p3 = a.xyz + src * 3;
+            const float rel[3] = {p3[0] - c3[0], p3[1] - c3[1], p3[2] - c3[2]};   // pointnet2_utils.py:252
+            float v[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int c = 4 * g + s_, e_ = c - a.cin;
+                v[s_] = c < a.cin ? a.feat[src * a.cin + c] : e_ == 0 ? rel[0] : e_ == 1 ? rel[1] : e_ == 2 ? rel[2] : 0.0f;
+            }
+            in[t] = f4{v[0], v[1], v[2], v[3]};
+        }
+        {
+            const int nunit = unit + nwaves;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) e_next[t] = pack[nunit < npairs ? (nunit * 2 + t) * 16 + pos : 0];
+        }
+        f4 h1[NT][B1], h2[NT][B2];
+#pragma unroll
+        for (int mb = 0; mb < B1; ++mb) {
+            const f4 bi = *reinterpret_cast<const f4 *>(bias1 + 16 * mb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f4 acc = bi;
+                PDM_CHAIN(acc, A1[mb], in[t])
+                h1[t][mb] = floor4(acc, 0.0f);
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+            const f4 bi = *reinterpret_cast<const f4 *>(bias2 + 16 * mb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f4 acc = bi;
+#pragma unroll
+                for (int kb = 0; kb < B1; ++kb) { PDM_CHAIN(acc, A2[mb][kb], h1[t][kb]) }
+                h2[t][mb] = floor4(acc, 0.0f);
+            }
+        }
+        const bool pair = L[0] >= 32;   // wave-uniform: both tiles belong to one centre
+        float *orow[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int Lw = L[t] < 16 ? L[t] : 16;
+            const bool writer = ctr[t] >= 0 && (pos & (Lw - 1)) == 0 && !(pair && t == 1);
+            orow[t] = writer ? a.out + (size_t)ctr[t] * a.out_stride + a.out_coff : nullptr;
+        }
+#pragma unroll
+        for (int mb = 0; mb < B3; ++mb) {
+            const f4 bi = *reinterpret_cast<const f4 *>(bias3 + 16 * mb);
+            f4 v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f4 acc = bi;
+#pragma unroll
+                for (int kb = 0; kb < B2; ++kb) { PDM_CHAIN(acc, A3[mb][kb], h2[t][kb]) }
+                v[t] = floor4(acc, 0.0f);
+            }
+            if (pair) {
+                v[0].x = fmaxf(v[0].x, v[1].x); v[0].y = fmaxf(v[0].y, v[1].y);
+                v[0].z = fmaxf(v[0].z, v[1].z); v[0].w = fmaxf(v[0].w, v[1].w);
+                v[0] = seg_max_nonneg4(v[0], 16);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = seg_max_nonneg4(v[t], L[t]);
+            }
+            const int c0 = 16 * mb + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (!orow[t]) continue;
+                if (c0 + 4 <= a.cout) {
+                    *reinterpret_cast<f4 *>(orow[t] + c0) = v[t];
+                } else {
+                    if (c0 < a.cout) orow[t][c0] = v[t].x;
+                    if (c0 + 1 < a.cout) orow[t][c0 + 1] = v[t].y;
+                    if (c0 + 2 < a.cout) orow[t][c0 + 2] = v[t].z;
+                }
+            }
+        }
+    }
+#undef PDM_CHAIN
+}
+
 int rows_gemm_launch(void *stream, int rows, int cin, const float *in_pm, int k0, int c1, const float *wpack,
                      const float *bias, int relu_last, float *out_pm, int out_stride, int cout);   // rows_gemm.hip
 int fp_pre_gemm_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
@@ -983,12 +1230,21 @@ extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fu
 static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
                            const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride,
                            int z_coff, const int *idx, int nlayers, const int *dims, const float *wpack,
-                           const float *bias, float *out_pm, int out_stride, int out_coff, int cout) {
+                           const float *bias, float *out_pm, int out_stride, int out_coff, int cout,
+                           const int *pack = nullptr, const int *meta = nullptr) {
     PDM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && cin >= 0 && nsample > 0, PDM_E_BADARG, "sa_mlp_fused: bad size");
     PDM_REQUIRE(nsample % 16 == 0, PDM_E_BADARG, "sa_mlp_fused: nsample=%d must be a multiple of 16", nsample);
     if (b == 0 || m == 0) return 0;
-    PDM_REQUIRE(xyz && new_xyz && idx && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
+    PDM_REQUIRE(xyz && new_xyz && (idx || (pack && meta)) && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
                 "sa_mlp_fused: null pointer");
+    const bool packed = pack != nullptr;
+    if (packed) {
+        PDM_REQUIRE(nsample == 16 || nsample == 32, PDM_E_BADARG, "sa_mlp_packed: nsample=%d (16 or 32)", nsample);
+        PDM_REQUIRE((long long)b * m * nsample + 256 < (1ll << 31) && (reinterpret_cast<uintptr_t>(pack) & 7) == 0,
+                    PDM_E_BADARG, "sa_mlp_packed: row list too long or misaligned");
+    }
+    const int2 *pack2 = reinterpret_cast<const int2 *>(pack);
+    const long long cap_pairs = (long long)pdm_sa_pack_rows(b, m, nsample) / 32;
     MlpDesc d;
     int W = 1, NT = 1, G = 1;
     const long long sa_tiles = (long long)b * m * (nsample / 16);
@@ -1021,7 +1277,11 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
         const int blocks_r = (int)(want < capr ? want : capr);
 #define PDM_REG_LAUNCH(X, Y, Z)                                                                                          \
     if (b1 == X && b2 == Y && b3 == Z) {                                                                                \
-        if (nsample >= 32)                                                                                              \
+        if (packed) {                                                                                                   \
+            const long long wantp = (cap_pairs + 3) / 4;                                                                \
+            hipLaunchKernelGGL((sa_reg_packed_kernel<X, Y, Z>), dim3((int)(wantp < capr ? wantp : capr)), dim3(256), 0, \
+                               as_stream(stream), a, pack2, meta, wpack, bias);                                         \
+        } else if (nsample >= 32)                                                                                              \
             hipLaunchKernelGGL((sa_reg_mlp_kernel<X, Y, Z, true>), dim3(blocks_r), dim3(256), 0, as_stream(stream), a, wpack, bias);  \
         else                                                                                                            \
             hipLaunchKernelGGL((sa_reg_mlp_kernel<X, Y, Z, false>), dim3(blocks_r), dim3(256), 0, as_stream(stream), a, wpack, bias); \
@@ -1032,10 +1292,14 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
 #undef PDM_REG_LAUNCH
     }
     const int tpc_ = nsample / 16;
-    const long long units_ = tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
+    const long long units_ = packed ? cap_pairs : tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
     const long long niter = (units_ + G - 1) / G;
     const long long cap = (long long)256 * g_fused_wg_per_cu;
     const int blocks = (int)(niter < cap ? niter : cap);
+    if (packed) {
+        FUSED_DISPATCH(sa_packed_fused_kernel, W, G, blocks, lds_bytes, d, a, pack2, meta, wpack, bias);
+        return check_launch("sa_mlp_packed");
+    }
     FUSED_DISPATCH(sa_mlp_fused_kernel, W, G, blocks, lds_bytes, d, a, wpack, bias);
     return check_launch("sa_mlp_fused");
 }
@@ -1059,6 +1323,19 @@ extern "C" int pdm_sa_mlp_fused_pre(void *stream, int b, int n, int m, int nsamp
     PDM_REQUIRE(z_pm || b == 0 || m == 0, PDM_E_BADARG, "sa_mlp_fused_pre: null z");
     return sa_fused_launch(stream, b, n, m, 0, nsample, xyz, new_xyz, nullptr, z_pm, z_stride, z_coff, idx, nlayers,
                            dims, wpack, bias, out_pm, out_stride, out_coff, cout);
+}
+
+// The same SA scale over a compacted neighbour list (pdm_sa_pack): duplicate padding rows are not computed.
+// z_pm null = unhoisted form (feat_pm rows, cin channels); non-null = hoisted form (feat_pm / cin ignored).
+extern "C" int pdm_sa_mlp_packed(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
+                                 const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride,
+                                 int z_coff, const int *pack, const int *meta, int nlayers, const int *dims,
+                                 const float *wpack, const float *bias, float *out_pm, int out_stride, int out_coff,
+                                 int cout) {
+    PDM_REQUIRE((pack && meta) || b == 0 || m == 0, PDM_E_BADARG, "sa_mlp_packed: null row list");
+    return sa_fused_launch(stream, b, n, m, z_pm ? 0 : cin, nsample, xyz, new_xyz, z_pm ? nullptr : feat_pm, z_pm,
+                           z_stride, z_coff, nullptr, nlayers, dims, wpack, bias, out_pm, out_stride, out_coff, cout,
+                           pack, meta);
 }
 
 // mode 0: FP module (known rows interpolated in the kernel); 1: FP module with pre-projected known rows z;

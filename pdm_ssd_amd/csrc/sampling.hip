@@ -363,12 +363,32 @@ struct __attribute__((aligned(16))) FpsRecR {
 // {payload, iteration} granules (agent-scope relaxed atomics = sc1 stores/loads, the data-tagged hand-off of
 // the CDNA guide: no flag, no fence) and picks the best of the G records.  All G workgroups of a cloud must be
 // resident together: the host launches at most 256 workgroups at a time.  Every spin is bounded.
+// Resumable segments (pdm_furthest_point_sampling_jobs): up to 4 jobs in one launch, job q = iterations [j0, j1) of
+// the FPS of its own batch of `nb` clouds, continuing from the state an earlier segment left in temp (running
+// min-distances) and idx (samples [0, j0)).  njobs == 0: the kernel's plain arguments, iterations [1, m).
+struct FpsSeg {
+    int njobs, nb;
+    const float *xyz[4];
+    float *temp[4];
+    int *idx[4];
+    int j0[4], j1[4];
+};
+#define FPS_SEG_PICK(F, q) ((q) == 0 ? seg.F[0] : (q) == 1 ? seg.F[1] : (q) == 2 ? seg.F[2] : seg.F[3])
+
 template <int BLOCK, int PPT, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, int G,
-                                                          const float *__restrict__ xyz_all,
-                                                          float *__restrict__ temp_all,
-                                                          int *__restrict__ idx_all,
-                                                          unsigned long long *__restrict__ xch_all) {
+                                                          const float *__restrict__ xyz_arg,
+                                                          float *__restrict__ temp_arg,
+                                                          int *__restrict__ idx_arg,
+                                                          unsigned long long *__restrict__ xch_all,
+                                                          const FpsSeg seg) {
+    const bool segd = !MULTI && seg.njobs > 0;
+    const int job = segd ? (int)blockIdx.x / seg.nb : 0;   // static indices only: a runtime index would spill the struct
+    const float *__restrict__ xyz_all = segd ? FPS_SEG_PICK(xyz, job) : xyz_arg;
+    float *__restrict__ temp_all = segd ? FPS_SEG_PICK(temp, job) : temp_arg;
+    int *__restrict__ idx_all = segd ? FPS_SEG_PICK(idx, job) : idx_arg;
+    const int jb0 = segd ? FPS_SEG_PICK(j0, job) : 1;
+    const int jb1 = segd ? FPS_SEG_PICK(j1, job) : m;
     constexpr int NW = BLOCK / 64, HPT = 4096 / BLOCK;  // waves, histogram bins per thread
     using vec = float __attribute__((ext_vector_type(PPT)));
     __shared__ FpsRecR rec[2][16];
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     // MULTI: workgroups are dealt to the 8 XCDs round-robin by blockIdx; the G workgroups of one cloud take ids
     // b, b + nb, b + 2 nb, ... so that (when nb is a multiple of 8) they share an XCD and its L2 for the exchange
     const int nb_ = MULTI ? (int)gridDim.x / G : 1;
-    const int b = MULTI ? (int)blockIdx.x % nb_ : blockIdx.x;
+    const int b = MULTI ? (int)blockIdx.x % nb_ : segd ? (int)blockIdx.x % seg.nb : blockIdx.x;
     const int grp = MULTI ? (int)blockIdx.x / nb_ : 0;
     const int per = MULTI ? (n_total + G - 1) / G : n_total;   // points per workgroup (<= BLOCK*PPT)
     const int k0 = grp * per;                                   // first global index of this workgroup
@@ -560,9 +580,9 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
 
     // ---- iterations
     FpsPick cur;
-    cur.k = 0;
-    cur.x = xyz0[0]; cur.y = xyz0[1]; cur.z = xyz0[2];
-    if (p == 0 && grp == 0) idxs[0] = 0;
+    cur.k = jb0 > 1 ? idxs[jb0 - 1] : 0;   // a later segment continues from the last sample of the one before
+    cur.x = xyz0[(size_t)cur.k * 3]; cur.y = xyz0[(size_t)cur.k * 3 + 1]; cur.z = xyz0[(size_t)cur.k * 3 + 2];
+    if (p == 0 && grp == 0 && jb0 <= 1) idxs[0] = 0;
     __shared__ float fin[8];
     // cached wave result (uniform)
     bool have = false;
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     FpsPick mine;
     mine.k = 0; mine.x = mine.y = mine.z = 0.0f;
     int mrank = 0x7FFFFFFF;
-    for (int j = 1; j < m; ++j) {
+    for (int j = jb0; j < jb1; ++j) {
         // lower bound of every computed distance between cur and a point of this wave's box
         const float gx = fmaxf(0.0f, fmaxf(blo[0] - cur.x, cur.x - bhi[0]));
         const float gy = fmaxf(0.0f, fmaxf(blo[1] - cur.y, cur.y - bhi[1]));
@@ -765,13 +785,42 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     } else if (per <= 16) {
         if (g_fps_variant == 1) FPS_LAUNCH(512, 32);
         else if (g_fps_variant == 2) FPS_LAUNCH(1024, 16);
-        else if (g_fps_variant == 3) hipLaunchKernelGGL((fps_pruned_kernel<512, 32, false>), dim3(b), dim3(512), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr);
-        else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr);
+        else if (g_fps_variant == 3) hipLaunchKernelGGL((fps_pruned_kernel<512, 32, false>), dim3(b), dim3(512), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr, FpsSeg{});
+        else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr, FpsSeg{});
     } else {
         hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n,
                            m, S, logS, points, temp, idx, rg);
     }
     return check_launch("furthest_point_sampling");
+}
+
+// Resumable FPS: job q computes samples [j0[q], j1[q]) of its own batch (b clouds of n points, m samples), reading the
+// state of an earlier call from temp[q] (running min-distances; 1e10 everywhere before the first segment) and idx[q]
+// (samples [0, j0)), and leaving the state for the next segment there.  The segments of one batch, run in order,
+// give exactly the indices of one pdm_furthest_point_sampling call; the jobs of one call belong to DIFFERENT batches
+// and run side by side in one launch (pdm_ssd_amd/pipeline.py spreads the long level-1 FPS over several steps).
+// Register-resident pruned form only: 1024 < n <= 16384.
+extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, int n, int m,
+                                                const float *const *points, float *const *temp, int *const *idx,
+                                                const int *j0, const int *j1) {
+    PDM_REQUIRE(njobs >= 1 && njobs <= 4, PDM_E_BADARG, "fps_jobs: njobs=%d not in [1,4]", njobs);
+    PDM_REQUIRE(b >= 0 && m >= 1, PDM_E_BADARG, "fps_jobs: b=%d m=%d", b, m);
+    PDM_REQUIRE(n > 1024 && n <= 16384, PDM_E_BADARG, "fps_jobs: n=%d outside (1024, 16384]", n);
+    PDM_REQUIRE(points && temp && idx && j0 && j1, PDM_E_BADARG, "fps_jobs: null table");
+    if (b == 0) return 0;
+    FpsSeg seg{};
+    seg.njobs = njobs;
+    seg.nb = b;
+    for (int q = 0; q < njobs; ++q) {
+        PDM_REQUIRE(points[q] && temp[q] && idx[q], PDM_E_BADARG, "fps_jobs: null pointer in job %d", q);
+        PDM_REQUIRE(j0[q] >= 1 && j0[q] <= j1[q] && j1[q] <= m, PDM_E_BADARG, "fps_jobs: job %d range [%d, %d) of %d", q,
+                    j0[q], j1[q], m);
+        seg.xyz[q] = points[q]; seg.temp[q] = temp[q]; seg.idx[q] = idx[q];
+        seg.j0[q] = j0[q]; seg.j1[q] = j1[q];
+    }
+    hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b * njobs), dim3(1024), 0, as_stream(stream), n, m, 1,
+                       (const float *)nullptr, (float *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, seg);
+    return check_launch("furthest_point_sampling_jobs");
 }
 
 // Stacked batches (reference stack_farthest_point_sampling_wrapper, pointnet2_stack/src/sampling.cpp): sample b has
@@ -828,7 +877,7 @@ extern "C" int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m,
         const int nb = b - b0 < chunk ? b - b0 : chunk;
         hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, true>), dim3(nb * G), dim3(1024), 0, as_stream(stream), n, m, G,
                            points + (size_t)b0 * n * 3, temp + (size_t)b0 * n, idx + (size_t)b0 * m,
-                           reinterpret_cast<unsigned long long *>(workspace) + (size_t)b0 * 2 * G * 6);
+                           reinterpret_cast<unsigned long long *>(workspace) + (size_t)b0 * 2 * G * 6, FpsSeg{});
         int rc = check_launch("furthest_point_sampling_ws");
         if (rc) return rc;
     }

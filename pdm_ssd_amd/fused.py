@@ -240,6 +240,39 @@ def sa_scale_forward_pre(pk, xyz, new_xyz, z, z_coff, idx, out_pm, out_coff):
                  out_pm.data_ptr(), out_pm.shape[2], out_coff, pk.cout)
 
 
+def sa_pack(idx, n):
+    """Compacted neighbour list of one SA scale (csrc/sa_pack.hip): idx (B,M,ns) int32 with ns in (16, 32), n = points
+    per source cloud -> (pack (rows,2) int32, meta (8,) int32).  Padding copies of the first hit are dropped, so the
+    fused kernels run the shared MLP over the distinct neighbours only (bit-identical pooled result)."""
+    B, M, ns = idx.shape
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and ns in (16, 32)
+    l = _native.lib()
+    rows = l.pdm_sa_pack_rows(B, M, ns)
+    pack = torch.empty((rows, 2), dtype=torch.int32, device=idx.device)
+    meta = torch.empty((8,), dtype=torch.int32, device=idx.device)
+    ws_bytes = l.pdm_sa_pack_workspace_bytes(B, M)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=idx.device)
+    _native.call("pdm_sa_pack", _stream(idx), B, n, M, ns, idx.data_ptr(), ws.data_ptr(), ws_bytes, pack.data_ptr(),
+                 meta.data_ptr())
+    return pack, meta
+
+
+def sa_scale_forward_packed(pk, xyz, new_xyz, feat_pm, z, z_coff, packed, ns, out_pm, out_coff):
+    """One SA scale over a compacted neighbour list `packed` = sa_pack(idx, N); z None = unhoisted form (feat_pm rows),
+    else the hoisted form of sa_scale_forward_pre."""
+    pack, meta = packed
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    cin = 0 if (feat_pm is None or z is not None) else feat_pm.shape[2]
+    assert pk.cin == cin + 3
+    if FLOP_COUNTER is not None:
+        _count("pdm_sa_mlp_packed", int(meta[6].item()), pk)   # rows actually run (a sync: accounting passes only)
+    _native.call("pdm_sa_mlp_packed", _stream(xyz), B, N, M, cin, ns, xyz.data_ptr(), new_xyz.data_ptr(),
+                 0 if cin == 0 else feat_pm.data_ptr(), 0 if z is None else z.data_ptr(),
+                 0 if z is None else z.shape[2], z_coff, pack.data_ptr(), meta.data_ptr(), pk.nlayers, pk.dims_ptr,
+                 pk.wpack.data_ptr(), pk.bias.data_ptr(), out_pm.data_ptr(), out_pm.shape[2], out_coff, pk.cout)
+
+
 def fp_forward_pre(pk, z, skip_pm, idx, weight, out_pm):
     """FP module whose first layer's known-feature part was applied to the known points: z (B,m,width)."""
     B, m, _ = z.shape

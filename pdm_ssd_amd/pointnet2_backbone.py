@@ -69,15 +69,16 @@ class PointNet2MSG(nn.Module):
         return self.sample_levels(xyz, 0, len(self.SA_modules))
 
     @torch.no_grad()
-    def coordinate_levels(self, xyz_in, first, last):
+    def coordinate_levels(self, xyz_in, first, last, first_idx=None):
         """Everything levels [first, last) compute from coordinates alone, starting from `xyz_in` = the input cloud of
-        level `first`: sampled xyz (FPS + gather), the ball-query indices of every scale, and the three-NN
-        (idx, weight) of the FP module that interpolates level k+1 back onto level k.  Lists indexed by level."""
+        level `first`: sampled xyz (FPS + gather), the ball-query indices of every scale (compacted, see
+        fused.sa_pack), and the three-NN (idx, weight) of the FP module that interpolates level k+1 back onto level k.
+        Lists indexed by level.  first_idx = FPS indices of level `first` computed elsewhere (pipeline.py)."""
         out = {'sampled_xyz': [], 'ball_idx': [], 'fp_interp': []}
         src = xyz_in
         for k in range(first, last):
             sa = self.SA_modules[k]
-            new_xyz = sa.sample(src)
+            new_xyz = sa.sample(src) if (k > first or first_idx is None) else sa.sample_from_idx(src, first_idx)
             out['sampled_xyz'].append(new_xyz)
             out['ball_idx'].append(sa.query(src, new_xyz))
             out['fp_interp'].append(pointnet2_modules.PointnetFPModule.interpolation(src.contiguous(), new_xyz))

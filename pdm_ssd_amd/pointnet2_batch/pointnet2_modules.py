@@ -43,7 +43,11 @@ class _PointnetSAModuleBase(nn.Module):
         """FPS + gather of the sampled coordinates (ref :30-35) -> (B, npoint, 3)."""
         if self.npoint is None:
             return None
-        idx = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+        return self.sample_from_idx(xyz, pointnet2_utils.farthest_point_sample(xyz, self.npoint))
+
+    @staticmethod
+    def sample_from_idx(xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """The gather half of sample(): FPS indices (B,npoint) -> (B,npoint,3)."""
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         return pointnet2_utils.gather_operation(xyz_flipped, idx).transpose(1, 2).contiguous()
 
@@ -74,7 +78,16 @@ class _PointnetSAModuleBase(nn.Module):
         """Neighbour indices of every scale, [(B,M,nsample) int32]: coordinate-only, so a caller may compute them
         ahead of time (pdm_ssd_amd/pipeline.py) and pass them to forward(..., idx_list=)."""
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
-        return [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+        return [self._maybe_pack(pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
+                for g in self.groupers]
+
+    def _maybe_pack(self, idx, n):
+        """Compact the neighbour list for the fused kernels (fused.sa_pack) when the module takes its fused inference
+        path: (pack, meta) instead of the (B,M,nsample) tensor.  `use_pack = False` keeps the dense list."""
+        if (getattr(self, 'use_pack', True) and idx.shape[2] in (16, 32) and not self.training
+                and not torch.is_grad_enabled() and getattr(self, 'use_fused', True)):
+            return fused.sa_pack(idx, n)
+        return idx
 
     def _forward_fused(self, packs, xyz, features, new_xyz, idx_list=None):
         B, M = new_xyz.shape[0], new_xyz.shape[1]
@@ -96,8 +109,11 @@ class _PointnetSAModuleBase(nn.Module):
             fused.rows_forward(prepack, feat_pm, z, relu_last=False)
         for i, (grouper, pk) in enumerate(zip(self.groupers, packs)):
             idx = idx_list[i] if idx_list is not None else \
-                pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-            if pre is not None:
+                self._maybe_pack(pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz), xyz.shape[1])
+            if isinstance(idx, tuple):   # compacted list: padding copies of the first hit are not computed
+                fused.sa_scale_forward_packed(pk, xyz, new_xyz, feat_pm, None if pre is None else z,
+                                              0 if pre is None else prepack.offsets[i], idx, grouper.nsample, out_pm, coff)
+            elif pre is not None:
                 fused.sa_scale_forward_pre(pk, xyz, new_xyz, z, prepack.offsets[i], idx, out_pm, coff)
             else:
                 fused.sa_scale_forward(pk, xyz, new_xyz, feat_pm, idx, out_pm, coff)

@@ -50,6 +50,29 @@ class FarthestPointSampling(Function):
 farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
 
 
+def fps_segments(jobs, npoint):
+    """Resumable FPS, several batches side by side in ONE launch (pdm_furthest_point_sampling_jobs): jobs = list of
+    (xyz (B,N,3), temp (B,N), idx (B,npoint), j0, j1); job q computes samples [j0, j1) of its batch in place, continuing
+    from the state an earlier segment left in temp / idx (temp = 1e10 everywhere before the first segment, j0 = 1).
+    The segments of one batch, run in order, give exactly farthest_point_sample(xyz, npoint)."""
+    import ctypes
+    from .. import _native
+    assert 1 <= len(jobs) <= 4
+    B, N, _ = jobs[0][0].shape
+    for xyz, temp, idx, j0, j1 in jobs:
+        assert xyz.is_contiguous() and temp.is_contiguous() and idx.is_contiguous()
+        assert xyz.shape == (B, N, 3) and temp.shape == (B, N) and idx.shape == (B, npoint)
+        assert xyz.dtype == torch.float32 and temp.dtype == torch.float32 and idx.dtype == torch.int32
+    n = len(jobs)
+    P = ctypes.c_void_p * n
+    I = ctypes.c_int * n
+    _native.call("pdm_furthest_point_sampling_jobs", torch.cuda.current_stream(jobs[0][0].device).cuda_stream, n, B, N,
+                 npoint, ctypes.cast(P(*[j[0].data_ptr() for j in jobs]), ctypes.c_void_p),
+                 ctypes.cast(P(*[j[1].data_ptr() for j in jobs]), ctypes.c_void_p),
+                 ctypes.cast(P(*[j[2].data_ptr() for j in jobs]), ctypes.c_void_p),
+                 ctypes.cast(I(*[j[3] for j in jobs]), ctypes.c_void_p), ctypes.cast(I(*[j[4] for j in jobs]), ctypes.c_void_p))
+
+
 class GatherOperation(Function):
     """ref pointnet2_utils.py:39-70 — features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
 

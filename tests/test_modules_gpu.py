@@ -150,3 +150,35 @@ def test_pipelined_hot_path_equals_serial(dev, depth):
             torch.cuda.synchronize()
             assert torch.equal(bd['point_features'], ref[i][0]), f"batch {i}"
             assert torch.equal(bd['spatial_features'], ref[i][1]), f"batch {i}"
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_segmented_fps_pipeline_equals_serial(dev, depth):
+    """depth >= 3: the level-1 FPS is cut into depth - 1 resumable segments that run for different batches side by side;
+    every batch of a sequence of DIFFERENT batches still comes out exactly as from the serial path."""
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pdm_neck import PDMNeck
+    from pdm_ssd_amd.pipeline import PipelinedHotPath
+    from pdm_ssd_amd.pointnet2_backbone import PointNet2MSG
+    torch.manual_seed(0)
+    cfg = {'SA_CONFIG': {'NPOINTS': [301, 64], 'RADIUS': [[0.5, 1.0], [1.0, 2.0]], 'NSAMPLE': [[16, 32], [16, 32]],
+                         'MLPS': [[[16, 16], [16, 32]], [[32, 32], [32, 64]]]}, 'FP_MLPS': [[32, 32], [64, 64]]}
+    backbone = PointNet2MSG(cfg, input_channels=4).to(dev).eval()
+    neck = PDMNeck({'SOURCE_LAYER': 1, 'FEATURE_DIM': 32, 'DILATION': [3, 3, 1], 'SH_DEGREE': 1, 'INPUT_CHANNELS': 48},
+                   grid_size=[1408, 1600, 40], voxel_size=[0.05, 0.05, 0.1],
+                   point_cloud_range=list(synthetic.KITTI_RANGE)).to(dev).eval()
+    B, N, S = 2, 2048, depth - 1
+    nb = 4 + S + 1
+    batches = [torch.from_numpy(synthetic.to_batch_points(synthetic.lidar_like_clouds(B, N, 300 + i))).to(dev) for i in range(nb)]
+    with torch.no_grad():
+        ref = []
+        for p in batches[:4]:
+            bd = neck(backbone({'batch_size': B, 'points': p}))
+            ref.append((bd['point_features'].clone(), bd['spatial_features'].clone()))
+        pipe = PipelinedHotPath(backbone, neck, depth=depth)
+        pipe.prime_segmented(batches[:S + 1], B)
+        for i in range(4):
+            bd = pipe.step(batches[i], None, B, points_ahead=batches[i + 1:i + 2 + S])
+            torch.cuda.synchronize()
+            assert torch.equal(bd['point_features'], ref[i][0]), f"batch {i}"
+            assert torch.equal(bd['spatial_features'], ref[i][1]), f"batch {i}"

@@ -446,3 +446,28 @@ def test_copy_many_one_launch(dev):
     for d, s_ in zip(dst, src):
         assert torch.equal(d, s_)
     _native.copy_many([], [])
+
+
+@pytest.mark.parametrize("n,m,cuts", [(16384, 1024, [1, 300, 1024]), (5000, 700, [1, 2, 350, 351, 700]), (2048, 64, [1, 64])])
+def test_fps_resumable_segments_match_one_call(dev, n, m, cuts):
+    """pdm_furthest_point_sampling_jobs: the segments of one batch, run in order (each beside a segment of ANOTHER
+    batch in the same launch), give exactly the indices and final min-distances of the one-call operator."""
+    cl_a = torch.from_numpy(np.ascontiguousarray(synthetic.lidar_like_clouds(3, n, 77)[:, :, :3])).to(dev)
+    cl_b = torch.from_numpy(np.ascontiguousarray(synthetic.uniform_clouds(3, n, 78)[:, :, :3])).to(dev)
+    want_a, want_b = pu.furthest_point_sample(cl_a, m), pu.furthest_point_sample(cl_b, m)
+    st = {k: (torch.full((3, n), 1e10, device=dev), torch.full((3, m), -1, dtype=torch.int32, device=dev)) for k in "ab"}
+    segs = list(zip(cuts[:-1], cuts[1:]))
+    # batch b runs one segment behind batch a, so most launches hold two jobs at different stages
+    for step in range(len(segs) + 1):
+        jobs = []
+        if step < len(segs):
+            jobs.append((cl_a, st["a"][0], st["a"][1], segs[step][0], segs[step][1]))
+        if step >= 1:
+            jobs.append((cl_b, st["b"][0], st["b"][1], segs[step - 1][0], segs[step - 1][1]))
+        pu.fps_segments(jobs, m)
+    assert torch.equal(st["a"][1], want_a) and torch.equal(st["b"][1], want_b)
+    ref_temp = torch.full((3, n), 1e10, device=dev)
+    ref_idx = torch.empty((3, m), dtype=torch.int32, device=dev)
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as hipops
+    hipops.farthest_point_sampling_wrapper(3, n, m, cl_a, ref_temp, ref_idx)
+    assert torch.equal(st["a"][0], ref_temp)
