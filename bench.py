@@ -331,6 +331,11 @@ def main():
         bd = neck(bd)
         return bd['spatial_features'], bd['point_features']
 
+    fps_wgs = (args.pipeline_depth - 1) * B * ((N + 16383) // 16384)
+    if args.pipeline_depth >= 3 and not (1024 < N <= 131072 and (N <= 16384 or fps_wgs <= 256)):
+        print(f"[bench] resumable FPS segments need 1024 < points <= 131072 and co-resident workgroups; "
+              f"{N} points x {B} clouds -> --pipeline-depth 2", file=sys.stderr)
+        args.pipeline_depth = 2
     pipe = PipelinedHotPath(backbone, neck, depth=args.pipeline_depth)
 
     def step_pipelined():
@@ -348,8 +353,6 @@ def main():
         # per-sample point-count check of the backbone (host sync) done once, outside the timed region
         counts = torch.bincount(points[:, 0].long(), minlength=B)
         assert int(counts.min()) == int(counts.max()) == N
-        if args.pipeline_depth >= 3 and not (1024 < N <= 16384):
-            raise SystemExit("--pipeline-depth >= 3 needs 1024 < points <= 16384 (resumable FPS segments)")
         if args.pipeline_depth >= 3:
             pipe.prime_segmented([points] * args.pipeline_depth, B)
         else:

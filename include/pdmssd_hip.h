@@ -82,9 +82,12 @@ int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m, const floa
 /* The same operator as resumable segments (no reference counterpart; same indices): job q computes samples
  * [j0[q], j1[q]) of its own batch of b clouds, continuing from the state an earlier segment left in temp[q] (running
  * min-distances, 1e10 everywhere before the first segment) and idx[q] (samples [0, j0)).  The 1..4 jobs of a call
- * belong to different batches and run side by side in one launch; host arrays of device pointers.  1024 < n <= 16384. */
+ * belong to different batches and run side by side in one launch; host arrays of device pointers.  1024 < n <= 16384,
+ * or 16384 < n <= 131072 with workspace[q] = pdm_furthest_point_sampling_ws_bytes(b, n) bytes per job (8-byte aligned;
+ * the cooperating workgroups must all be resident: njobs * b * ceil(n/16384) <= 256); workspace may be null otherwise. */
 int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, int n, int m, const float *const *points,
-                                     float *const *temp, int *const *idx, const int *j0, const int *j1);
+                                     float *const *temp, int *const *idx, const int *j0, const int *j1,
+                                     void *const *workspace, size_t workspace_bytes);
 
 /* replaces three_nn_wrapper_fast              interpolate.cpp:18-26 -> interpolate_gpu.cu:16-81
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) squared distances, idx (B,n,3). */

@@ -371,6 +371,7 @@ struct FpsSeg {
     const float *xyz[4];
     float *temp[4];
     int *idx[4];
+    unsigned long long *xch[4];   // MULTI: each job's own exchange slots
     int j0[4], j1[4];
 };
 #define FPS_SEG_PICK(F, q) ((q) == 0 ? seg.F[0] : (q) == 1 ? seg.F[1] : (q) == 2 ? seg.F[2] : seg.F[3])
@@ -380,10 +381,13 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
                                                           const float *__restrict__ xyz_arg,
                                                           float *__restrict__ temp_arg,
                                                           int *__restrict__ idx_arg,
-                                                          unsigned long long *__restrict__ xch_all,
+                                                          unsigned long long *__restrict__ xch_arg,
                                                           const FpsSeg seg) {
-    const bool segd = !MULTI && seg.njobs > 0;
-    const int job = segd ? (int)blockIdx.x / seg.nb : 0;   // static indices only: a runtime index would spill the struct
+    const bool segd = seg.njobs > 0;
+    const int per_job = segd ? seg.nb * (MULTI ? G : 1) : (int)gridDim.x;   // workgroups of one job
+    const int job = segd ? (int)blockIdx.x / per_job : 0;   // static indices only: a runtime index would spill the struct
+    const int blk = (int)blockIdx.x - job * per_job;        // workgroup number inside the job
+    unsigned long long *__restrict__ xch_all = segd ? FPS_SEG_PICK(xch, job) : xch_arg;
     const float *__restrict__ xyz_all = segd ? FPS_SEG_PICK(xyz, job) : xyz_arg;
     float *__restrict__ temp_all = segd ? FPS_SEG_PICK(temp, job) : temp_arg;
     int *__restrict__ idx_all = segd ? FPS_SEG_PICK(idx, job) : idx_arg;
@@ -398,9 +402,9 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     __shared__ int wsum[NW];
     // MULTI: workgroups are dealt to the 8 XCDs round-robin by blockIdx; the G workgroups of one cloud take ids
     // b, b + nb, b + 2 nb, ... so that (when nb is a multiple of 8) they share an XCD and its L2 for the exchange
-    const int nb_ = MULTI ? (int)gridDim.x / G : 1;
-    const int b = MULTI ? (int)blockIdx.x % nb_ : segd ? (int)blockIdx.x % seg.nb : blockIdx.x;
-    const int grp = MULTI ? (int)blockIdx.x / nb_ : 0;
+    const int nb_ = MULTI ? per_job / G : 1;
+    const int b = MULTI ? blk % nb_ : blk;
+    const int grp = MULTI ? blk / nb_ : 0;
     const int per = MULTI ? (n_total + G - 1) / G : n_total;   // points per workgroup (<= BLOCK*PPT)
     const int k0 = grp * per;                                   // first global index of this workgroup
     const int n = max(0, min(per, n_total - k0));               // its point count
@@ -799,15 +803,27 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
 // (samples [0, j0)), and leaving the state for the next segment there.  The segments of one batch, run in order,
 // give exactly the indices of one pdm_furthest_point_sampling call; the jobs of one call belong to DIFFERENT batches
 // and run side by side in one launch (pdm_ssd_amd/pipeline.py spreads the long level-1 FPS over several steps).
-// Register-resident pruned form only: 1024 < n <= 16384.
+// Register-resident pruned forms only: 1024 < n <= 16384 (one workgroup per cloud) or, with a workspace of
+// pdm_furthest_point_sampling_ws_bytes(b, n) bytes PER JOB, 16384 < n <= 131072 (cooperating workgroups; all of them must be
+// co-resident: njobs * b * ceil(n/16384) <= 256).
+extern "C" size_t pdm_furthest_point_sampling_ws_bytes(int b, int n);
+
 extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, int n, int m,
                                                 const float *const *points, float *const *temp, int *const *idx,
-                                                const int *j0, const int *j1) {
+                                                const int *j0, const int *j1, void *const *workspace,
+                                                size_t workspace_bytes) {
     PDM_REQUIRE(njobs >= 1 && njobs <= 4, PDM_E_BADARG, "fps_jobs: njobs=%d not in [1,4]", njobs);
     PDM_REQUIRE(b >= 0 && m >= 1, PDM_E_BADARG, "fps_jobs: b=%d m=%d", b, m);
-    PDM_REQUIRE(n > 1024 && n <= 16384, PDM_E_BADARG, "fps_jobs: n=%d outside (1024, 16384]", n);
+    const int G = (n + 16383) / 16384;
+    PDM_REQUIRE(n > 1024 && G <= 8, PDM_E_BADARG, "fps_jobs: n=%d outside (1024, 131072]", n);
     PDM_REQUIRE(points && temp && idx && j0 && j1, PDM_E_BADARG, "fps_jobs: null table");
     if (b == 0) return 0;
+    const size_t ws_need = pdm_furthest_point_sampling_ws_bytes(b, n);
+    // the G workgroups of a cloud wait for each other: every workgroup of the launch must be resident at once
+    PDM_REQUIRE(G == 1 || (long long)njobs * b * G <= 256, PDM_E_TOOLARGE,
+                "fps_jobs: %d jobs x %d clouds x %d workgroups exceed the 256 co-resident workgroups", njobs, b, G);
+    PDM_REQUIRE(G == 1 || (workspace && workspace_bytes >= ws_need), PDM_E_BADARG,
+                "fps_jobs: n=%d needs a workspace of %zu bytes per job", n, ws_need);
     FpsSeg seg{};
     seg.njobs = njobs;
     seg.nb = b;
@@ -817,9 +833,24 @@ extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, 
                     j0[q], j1[q], m);
         seg.xyz[q] = points[q]; seg.temp[q] = temp[q]; seg.idx[q] = idx[q];
         seg.j0[q] = j0[q]; seg.j1[q] = j1[q];
+        if (G > 1) {
+            PDM_REQUIRE(workspace[q] && (reinterpret_cast<uintptr_t>(workspace[q]) & 7) == 0, PDM_E_BADARG,
+                        "fps_jobs: workspace of job %d null or not 8-byte aligned", q);
+            seg.xch[q] = reinterpret_cast<unsigned long long *>(workspace[q]);
+            // stale tags from an earlier segment must not look like iteration numbers of this one
+            hipError_t e = hipMemsetAsync(workspace[q], 0, ws_need, as_stream(stream));
+            if (e != hipSuccess) {
+                set_error("fps_jobs: memset failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+        }
     }
-    hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b * njobs), dim3(1024), 0, as_stream(stream), n, m, 1,
-                       (const float *)nullptr, (float *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, seg);
+    if (G == 1)
+        hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b * njobs), dim3(1024), 0, as_stream(stream), n, m, 1,
+                           (const float *)nullptr, (float *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, seg);
+    else
+        hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, true>), dim3(b * njobs * G), dim3(1024), 0, as_stream(stream), n, m, G,
+                           (const float *)nullptr, (float *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, seg);
     return check_launch("furthest_point_sampling_jobs");
 }
 

@@ -66,11 +66,14 @@ def fps_segments(jobs, npoint):
     n = len(jobs)
     P = ctypes.c_void_p * n
     I = ctypes.c_int * n
+    ws_bytes = _native.lib().pdm_furthest_point_sampling_ws_bytes(B, N)   # 0 unless N > 16384 (cooperating workgroups)
+    ws = [torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=jobs[0][0].device) for _ in jobs] if ws_bytes else []
     _native.call("pdm_furthest_point_sampling_jobs", torch.cuda.current_stream(jobs[0][0].device).cuda_stream, n, B, N,
                  npoint, ctypes.cast(P(*[j[0].data_ptr() for j in jobs]), ctypes.c_void_p),
                  ctypes.cast(P(*[j[1].data_ptr() for j in jobs]), ctypes.c_void_p),
                  ctypes.cast(P(*[j[2].data_ptr() for j in jobs]), ctypes.c_void_p),
-                 ctypes.cast(I(*[j[3] for j in jobs]), ctypes.c_void_p), ctypes.cast(I(*[j[4] for j in jobs]), ctypes.c_void_p))
+                 ctypes.cast(I(*[j[3] for j in jobs]), ctypes.c_void_p), ctypes.cast(I(*[j[4] for j in jobs]), ctypes.c_void_p),
+                 ctypes.cast(P(*[w.data_ptr() for w in ws]), ctypes.c_void_p) if ws else None, ws_bytes)
 
 
 class GatherOperation(Function):

@@ -448,7 +448,8 @@ def test_copy_many_one_launch(dev):
     _native.copy_many([], [])
 
 
-@pytest.mark.parametrize("n,m,cuts", [(16384, 1024, [1, 300, 1024]), (5000, 700, [1, 2, 350, 351, 700]), (2048, 64, [1, 64])])
+@pytest.mark.parametrize("n,m,cuts", [(16384, 1024, [1, 300, 1024]), (5000, 700, [1, 2, 350, 351, 700]), (2048, 64, [1, 64]),
+                                      (40000, 300, [1, 120, 300])])   # last: three cooperating workgroups per cloud
 def test_fps_resumable_segments_match_one_call(dev, n, m, cuts):
     """pdm_furthest_point_sampling_jobs: the segments of one batch, run in order (each beside a segment of ANOTHER
     batch in the same launch), give exactly the indices and final min-distances of the one-call operator."""
