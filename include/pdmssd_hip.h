@@ -311,6 +311,13 @@ int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const fl
                          const float *dgrid, const float *dwsum, float *dfeat, float *dsh,
                          float *dinv2s2);
 
+/* SURVEY.md section 8(f) row N4 -- score-ranked (instance-aware) sampling instead of FPS.  The sampling code of the
+ * PDM-SSD / IA-SSD lineage is absent from the reference snapshot; its analog there is torch.topk over per-point scores.
+ * Build-defined total order: score descending on the order-preserving integer image of the float (-0.0 < +0.0, NaN of
+ * either sign ranks above +inf as in torch.topk), equal images by lower index.
+ * scores (B,n) f32 -> idx (B,k) int32, idx[b,r] = index of the r-th ranked point; k <= n, k <= 16384. */
+int pdm_topk_sampling(void *stream, int b, int n, int k, const float *scores, int *idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -437,3 +437,19 @@ def points_in_boxes(points, boxes):
     out = np.zeros((B, M), dtype=np.int32)
     lib().oracle_points_in_boxes(B, bx.shape[1], M, pb, pp, out.ctypes.data_as(_i32p))
     return out
+
+
+def topk_key(scores):
+    """Sort key of pdm_topk_sampling (csrc/topk_sampling.hip: smaller key = higher rank): order-preserving integer image
+    of the float, inverted; NaN of either sign ranks first."""
+    bits = np.ascontiguousarray(scores, dtype=np.float32).view(np.uint32)
+    mono = np.where(bits & np.uint32(0x80000000), ~bits, bits | np.uint32(0x80000000))
+    key = ~mono
+    return np.where((bits & np.uint32(0x7fffffff)) > np.uint32(0x7f800000), np.uint32(0), key).astype(np.uint32)
+
+
+def topk_sampling(scores, k):
+    """scores (B,N) -> int32 (B,k): indices of the k highest scores, descending; ties by lower index (stable sort)."""
+    scores = np.asarray(scores, dtype=np.float32)
+    key = topk_key(scores)
+    return np.argsort(key, axis=1, kind='stable')[:, :k].astype(np.int32)

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "pdm_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp],
     "pdm_furthest_point_sampling_ws": [_i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_furthest_point_sampling_jobs": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_topk_sampling": [_i, _i, _i, _vp, _vp],
     "pdm_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdm_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -24,6 +24,32 @@ __device__ __forceinline__ float sqdist(float dx, float dy, float dz) {
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// One radix-select round, run by the FIRST WAVE of the workgroup (all 64 lanes): the first of 256 histogram bins at
+// which the running count reaches `remaining` (>= 1), and the count in front of it.  Four bins per lane, one wave scan
+// (a single thread walking the bins is a chain of 256 dependent LDS reads, ~10 us per round).
+__device__ __forceinline__ void radix_pick256(const int *hist, int remaining, int *digit, int *before) {
+    const int lane = threadIdx.x & 63;
+    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const int sum = h0 + h1 + h2 + h3;
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    const int excl = incl - sum;
+    const unsigned long long hit = __ballot(excl < remaining && incl >= remaining);
+    const int src = hit ? __ffsll((long long)hit) - 1 : 63;   // no lane reaches it only if remaining > total: last bins
+    if (lane == src) {
+        int acc = excl, d = 4 * lane;
+        if (acc + h0 < remaining) { acc += h0; ++d;
+            if (acc + h1 < remaining) { acc += h1; ++d;
+                if (acc + h2 < remaining) { acc += h2; ++d; } } }
+        *digit = d;
+        *before = acc;
+    }
+}
+
 }  // namespace pdm
 
 #define PDM_REQUIRE(cond, code, ...)      \

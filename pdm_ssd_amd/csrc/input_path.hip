@@ -99,14 +99,7 @@ __global__ __launch_bounds__(IP_THREADS) void sample_points_kernel(int B, int P,
                 if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, d = 0;
-                for (; d < 256; ++d) {
-                    if (acc + s_hist[d] >= remaining) break;
-                    acc += s_hist[d];
-                }
-                s_digit = d; s_before = acc;
-            }
+            if (tid < 64) radix_pick256(s_hist, remaining, &s_digit, &s_before);
             __syncthreads();
             prefix |= (unsigned)s_digit << shift;
             pmask |= 255u << shift;

@@ -112,3 +112,33 @@ def points_in_boxes_gpu(points, boxes):
     out = torch.full((B, M), -1, dtype=torch.int32, device=points.device)
     _native.call("pdm_points_in_boxes", _stream(points), B, boxes.shape[1], M, bxs.data_ptr(), pts.data_ptr(), out.data_ptr())
     return out
+
+
+def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
+    """ref pcdet/models/model_utils/model_nms_utils.py:6-28 — score threshold, top NMS_PRE_MAXSIZE boxes by score, rotated
+    NMS, first NMS_POST_MAXSIZE survivors; returns (indices into the INPUT boxes, their scores).  nms_config: an
+    object or dict with NMS_TYPE ('nms_gpu' | 'nms_normal_gpu'), NMS_THRESH, NMS_PRE_MAXSIZE, NMS_POST_MAXSIZE.
+    The pre-selection is pdm_topk_sampling (ties by lower index; the reference's torch.topk leaves them unspecified)."""
+    from ..pointnet2_batch.pointnet2_utils import topk_sample
+    get = (lambda k: nms_config[k]) if isinstance(nms_config, dict) else (lambda k: getattr(nms_config, k))
+    src_box_scores = box_scores
+    scores_mask = None
+    if score_thresh is not None:
+        scores_mask = box_scores >= score_thresh
+        box_scores = box_scores[scores_mask]
+        box_preds = box_preds[scores_mask]
+    selected = torch.zeros((0,), dtype=torch.int64, device=box_scores.device)
+    if box_scores.shape[0] > 0:
+        k = min(int(get('NMS_PRE_MAXSIZE')), box_scores.shape[0])
+        if k <= 16384:
+            indices = topk_sample(box_scores.view(1, -1), k)[0].long()
+        else:
+            indices = torch.topk(box_scores, k=k)[1]
+        boxes_for_nms = box_preds[indices]
+        nms_fn = {'nms_gpu': nms_gpu, 'nms_normal_gpu': nms_normal_gpu}[get('NMS_TYPE')]
+        keep_idx, _ = nms_fn(boxes_for_nms[:, 0:7], box_scores[indices], get('NMS_THRESH'))
+        selected = indices[keep_idx[:int(get('NMS_POST_MAXSIZE'))]]
+    if scores_mask is not None:
+        original_idxs = scores_mask.nonzero().view(-1)
+        selected = original_idxs[selected]
+    return selected, src_box_scores[selected]

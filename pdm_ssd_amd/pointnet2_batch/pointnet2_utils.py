@@ -76,6 +76,20 @@ def fps_segments(jobs, npoint):
                  ctypes.cast(P(*[w.data_ptr() for w in ws]), ctypes.c_void_p) if ws else None, ws_bytes)
 
 
+def topk_sample(scores: torch.Tensor, npoint: int) -> torch.Tensor:
+    """Score-ranked sampling (the instance-aware alternative to FPS): scores (B,N) f32 ->
+    int32 (B,npoint), the indices of the npoint highest scores in descending order.  Total order (pdm_topk_sampling):
+    ties by lower index, -0.0 < +0.0, NaN ranks first as in torch.topk; npoint <= N and <= 16384.  No gradient."""
+    from .. import _native
+    assert scores.dim() == 2 and scores.is_cuda
+    scores = scores.detach().float().contiguous()
+    B, N = scores.shape
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=scores.device)
+    _native.call("pdm_topk_sampling", torch.cuda.current_stream(scores.device).cuda_stream, B, N, int(npoint),
+                 scores.data_ptr(), idx.data_ptr())
+    return idx
+
+
 class GatherOperation(Function):
     """ref pointnet2_utils.py:39-70 — features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
 

@@ -224,3 +224,15 @@ def test_iou3d_oracle_nms_known_answer():
     np.testing.assert_array_equal(o.nms(boxes, 0.9), [0, 1, 2, 3, 4])
     np.testing.assert_array_equal(o.nms(boxes, 0.5, normal=True), [0, 1, 3])
     assert len(o.nms(boxes[:0], 0.5)) == 0
+
+
+def test_topk_sampling_kat():
+    """Hand-checkable order of pdm_topk_sampling's spec: NaN (either sign) first, then +inf, descending scores with equal
+    values by lower index, +0.0 above -0.0, -inf last."""
+    import numpy as np
+    from oracle import cpu_oracle as oracle
+    s = np.array([[0.5, np.nan, 0.5, -0.0, 0.0, np.inf, -np.inf, 2.0, -np.nan]], dtype=np.float32)
+    assert oracle.topk_sampling(s, 9).tolist() == [[1, 8, 5, 7, 0, 2, 4, 3, 6]]
+    assert oracle.topk_sampling(s, 3).tolist() == [[1, 8, 5]]
+    t = np.zeros((2, 6), dtype=np.float32)
+    assert oracle.topk_sampling(t, 4).tolist() == [[0, 1, 2, 3]] * 2
