@@ -305,6 +305,9 @@ def main():
                     help="batches whose sampling chain is in flight beside the feature path; >= 3 also cuts the level-1 "
                          "FPS into depth - 1 resumable segments run side by side (pdm_ssd_amd/pipeline.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the first SA layer of every level hoisted instead of choosing per level from the "
+                         "neighbour density of the batch (PointNet2MSG.autotune_hoisting)")
     ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead: bf16-autocast forward+backward+AdamW step of backbone+neck, "
@@ -353,6 +356,8 @@ def main():
         # per-sample point-count check of the backbone (host sync) done once, outside the timed region
         counts = torch.bincount(points[:, 0].long(), minlength=B)
         assert int(counts.min()) == int(counts.max()) == N
+        if not args.no_autotune:
+            hoisting = backbone.autotune_hoisting(points, B)
         if args.pipeline_depth >= 3:
             pipe.prime_segmented([points] * args.pipeline_depth, B)
         else:
@@ -512,7 +517,8 @@ def main():
                                "sampling two batches deep: level-1 FPS of batch i+2 and levels 2-4 of batch i+1 on side "
                                "streams under the feature half of batch i; every step does one full batch of every "
                                "kind of work (pdm_ssd_amd/pipeline.py)"),
-                   "ms_per_step_eager_serial": round(serial_ms, 4)},
+                   "ms_per_step_eager_serial": round(serial_ms, 4),
+                   "sa_first_layer_hoisted": None if args.no_autotune else [d["use_pre"] for d in hoisting]},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,
         "mlp_flops": flop_summary,

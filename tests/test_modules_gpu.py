@@ -182,3 +182,29 @@ def test_segmented_fps_pipeline_equals_serial(dev, depth):
             torch.cuda.synchronize()
             assert torch.equal(bd['point_features'], ref[i][0]), f"batch {i}"
             assert torch.equal(bd['spatial_features'], ref[i][1]), f"batch {i}"
+
+
+def test_autotune_hoisting(dev):
+    """Density-based choice between the hoisted and the plain first SA layer: sparse clouds (every ball holds little more
+    than its centre) switch the wide levels to the plain form over the compacted rows, dense ones keep hoisting; the
+    features agree to 1e-4 either way (fp32 summation order differs)."""
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pointnet2_backbone import PointNet2MSG
+    torch.manual_seed(1)
+    cfg = {'SA_CONFIG': {'NPOINTS': [512, 128], 'RADIUS': [[0.2, 0.4], [0.4, 0.8]], 'NSAMPLE': [[16, 32], [16, 32]],
+                         'MLPS': [[[16, 16, 32], [16, 16, 32]], [[64, 64], [64, 96]]]}, 'FP_MLPS': [[64, 64], [128, 128]]}
+    net = PointNet2MSG(cfg, input_channels=4).to(dev).eval()
+    B, N = 2, 4096
+    sparse = torch.from_numpy(synthetic.to_batch_points(synthetic.uniform_clouds(B, N, 7))).to(dev)
+    with torch.no_grad():
+        before = net({'batch_size': B, 'points': sparse})['point_features'].clone()
+        dec = net.autotune_hoisting(sparse, B)
+        assert len(dec) == 2 and dec[0]['use_pre'] is False          # level 1: one input feature, never hoisted
+        assert dec[1]['use_pre'] is False and dec[1]['plain_macs'] * 1.5 < dec[1]['hoisted_macs']
+        after = net({'batch_size': B, 'points': sparse})['point_features']
+        torch.testing.assert_close(after, before, rtol=1e-4, atol=1e-4)
+        # a dense cloud (everything inside one metre): every ball is full, hoisting stays
+        dense = sparse.clone()
+        dense[:, 1:4] = dense[:, 1:4] * 0.01
+        dec2 = net.autotune_hoisting(dense, B)
+        assert dec2[1]['use_pre'] is True
