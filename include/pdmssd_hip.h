@@ -318,6 +318,9 @@ int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const fl
  * scores (B,n) f32 -> idx (B,k) int32, idx[b,r] = index of the r-th ranked point; k <= n, k <= 16384. */
 int pdm_topk_sampling(void *stream, int b, int n, int k, const float *scores, int *idx);
 
+/* Diagnostics: *slot = the device's constant-rate counter (100 MHz) when `stream` reaches this point. */
+int pdm_mark_time(void *stream, unsigned long long *slot);
+
 #ifdef __cplusplus
 }
 #endif

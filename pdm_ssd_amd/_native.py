@@ -39,6 +39,7 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
+    "pdm_mark_time": [_vp],
     "pdm_boxes_overlap_bev": [_i, _vp, _i, _vp, _vp],
     "pdm_boxes_iou_bev": [_i, _vp, _i, _vp, _vp],
     "pdm_boxes_aligned_overlap_bev": [_i, _vp, _vp, _vp],

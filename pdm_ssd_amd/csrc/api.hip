@@ -77,5 +77,17 @@ extern "C" int pdm_copy_many(void *stream, int count, void *const *dst, const vo
     return 0;
 }
 
+namespace pdm {
+__global__ void mark_time_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
+}  // namespace pdm
+
+// Diagnostics: writes the device's constant-rate counter (100 MHz on gfx950) to *slot when the stream reaches this point —
+// the overlap of the branches of a captured step can be read without a profiler in the way (tools/diag/branch_times.py).
+extern "C" int pdm_mark_time(void *stream, unsigned long long *slot) {
+    PDM_REQUIRE(slot, PDM_E_BADARG, "mark_time: null slot");
+    hipLaunchKernelGGL(pdm::mark_time_kernel, dim3(1), dim3(1), 0, pdm::as_stream(stream), slot);
+    return pdm::check_launch("mark_time");
+}
+
 extern "C" int pdm_abi_version(void) { return PDM_ABI_VERSION; }
 extern "C" const char *pdm_last_error(void) { return pdm::g_err; }

@@ -60,6 +60,8 @@ class PipelinedHotPath:
         # depth 2: the short tail of the next batch's chain runs on the neck's stream ahead of the neck (which cannot
         # start before the SA stack is done anyway) — hipGraph replay starts a fourth parallel branch late
         self.side2 = self.neck_stream if depth == 2 else None
+        # depth >= 3: a third side stream for the rest of the coordinate chain.  That makes four concurrent branches
+        # (main, neck, side, side3) — replaying a capture with a fifth one segfaults inside the ROCm 7.2 runtime.
         self.side3 = torch.cuda.Stream() if depth >= 3 else None
         self.cur = None   # static hand-over buffers: coordinate-only results of the batch about to be processed
         self.half = None  # depth 2: level-1 results of the batch after that
