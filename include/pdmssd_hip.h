@@ -179,6 +179,11 @@ int pdm_sa_mlp_fused_pre(void *stream, int b, int n, int m, int nsample, const f
                          const float *new_xyz, const float *z_pm, int z_stride, int z_coff, const int *idx,
                          int nlayers, const int *dims, const float *wpack, const float *bias, float *out_pm,
                          int out_stride, int out_coff, int cout);
+int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
+                         const float *skip_pm, const int *idx, const float *weight, int nlayers,
+                         const int *dims, const float *wpack, const float *bias, float *out_pm,
+                         int out_stride, int cout);
+
 /* Neighbour-list compaction for the fused SA kernels (no reference counterpart: ball_query pads short
  * neighbourhoods with copies of the first hit, pointnet2/src/ball_query_gpu.cu:38-46, and the reference runs the
  * shared MLP over those copies; max-pool over a multiset = max-pool over the set, so they can be dropped).
@@ -196,10 +201,6 @@ int pdm_sa_mlp_packed(void *stream, int b, int n, int m, int cin, int nsample, c
                       const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride, int z_coff,
                       const int *pack, const int *meta, int nlayers, const int *dims, const float *wpack,
                       const float *bias, float *out_pm, int out_stride, int out_coff, int cout);
-int pdm_fp_mlp_fused_pre(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
-                         const float *skip_pm, const int *idx, const float *weight, int nlayers,
-                         const int *dims, const float *wpack, const float *bias, float *out_pm,
-                         int out_stride, int cout);
 
 /* ---- pointnet2_stack: ragged ("stacked") batches -----------------------
  * One entry per function of the reference's pointnet2_stack_cuda extension that the PointNet++ modules use
