@@ -208,3 +208,32 @@ def test_autotune_hoisting(dev):
         dense[:, 1:4] = dense[:, 1:4] * 0.01
         dec2 = net.autotune_hoisting(dense, B)
         assert dec2[1]['use_pre'] is True
+
+
+def test_full_size_paths_agree(dev):
+    """BASELINE's network at its real point count (PointNet2MSG pointrcnn config + PDM neck, 16384-point clouds): the
+    pipelined step (compacted neighbour lists, level-1 FPS in two resumable segments, three batches in flight) returns
+    bit for bit what the serial path returns, and the compacted SA kernels bit for bit what the dense ones return —
+    size-independent properties at the size the bench runs."""
+    import bench
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pipeline import PipelinedHotPath
+    backbone, neck = bench.build_models(dev)
+    B, N = 4, 16384
+    batches = [torch.from_numpy(synthetic.to_batch_points(
+        (synthetic.lidar_like_clouds if i % 2 else synthetic.uniform_clouds)(B, N, 900 + 10 * i))).to(dev) for i in range(5)]
+    with torch.no_grad():
+        ref = []
+        for p in batches[:2]:
+            bd = neck(backbone({'batch_size': B, 'points': p}))
+            ref.append((bd['point_features'].clone(), bd['spatial_features'].clone()))
+        pipe = PipelinedHotPath(backbone, neck, depth=3)
+        pipe.prime_segmented(batches[:3], B)
+        for i in range(2):
+            bd = pipe.step(batches[i], None, B, points_ahead=batches[i + 1:i + 4])
+            torch.cuda.synchronize()
+            assert torch.equal(bd['point_features'], ref[i][0]) and torch.equal(bd['spatial_features'], ref[i][1]), f"batch {i}"
+        for sa in backbone.SA_modules:
+            sa.use_pack = False
+        bd = neck(backbone({'batch_size': B, 'points': batches[1]}))
+        assert torch.equal(bd['point_features'], ref[1][0]) and torch.equal(bd['spatial_features'], ref[1][1])
