@@ -31,6 +31,8 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
     __shared__ float red[6][BQG_BUILD_T / 64];
     __shared__ int wsum[BQG_BUILD_T / 64];
     __shared__ GridHdr sh;
+    __shared__ float s_h, s_ext[3];
+    __shared__ int s_nonempty, s_again;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
     int *__restrict__ cell_start = cell_start_all + (size_t)b * (BQG_CAP + 1);
@@ -84,24 +86,65 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
         sh.inv_h = 1.0f / h;
         sh.gx = g[0]; sh.gy = g[1]; sh.gz = g[2];
         sh.ncells = g[0] * g[1] * g[2];
-        float *hp = hdr_all + (size_t)b * BQG_HDR;
-        hp[0] = sh.minx; hp[1] = sh.miny; hp[2] = sh.minz; hp[3] = sh.inv_h;
-        reinterpret_cast<int *>(hp)[4] = sh.gx; reinterpret_cast<int *>(hp)[5] = sh.gy;
-        reinterpret_cast<int *>(hp)[6] = sh.gz; reinterpret_cast<int *>(hp)[7] = sh.ncells;
+        s_h = h;
+        s_ext[0] = hi[0] - lo[0]; s_ext[1] = hi[1] - lo[1]; s_ext[2] = hi[2] - lo[2];
     }
     __syncthreads();
-    const GridHdr H = sh;
+    GridHdr H = sh;
 
-    // ---- histogram
-    for (int c = tid; c < H.ncells; c += BQG_BUILD_T) hist[c] = 0;
-    __syncthreads();
-    for (int k = tid; k < n; k += BQG_BUILD_T) {
-        const int cx = cell_of(xyz[(size_t)k * 3 + 0], H.minx, H.inv_h, H.gx);
-        const int cy = cell_of(xyz[(size_t)k * 3 + 1], H.miny, H.inv_h, H.gy);
-        const int cz = cell_of(xyz[(size_t)k * 3 + 2], H.minz, H.inv_h, H.gz);
-        atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+    // ---- histogram.  Nearest-neighbour mode (radius == 0: the cell size is free): a cell budget of n/2 assumes the
+    // points fill their bounding box; a flat scene (LiDAR: a few metres of height over 70 x 80 m) leaves most cells
+    // empty and packs the rest, and every box scan of the query pays for it.  While the occupied cells hold more than
+    // two points on average and a grid of half the cell volume still fits the LDS histogram, refine and count again.
+    for (int pass = 0;; ++pass) {
+        for (int c = tid; c < H.ncells; c += BQG_BUILD_T) hist[c] = 0;
+        if (tid == 0) s_nonempty = 0;
+        __syncthreads();
+        for (int k = tid; k < n; k += BQG_BUILD_T) {
+            const int cx = cell_of(xyz[(size_t)k * 3 + 0], H.minx, H.inv_h, H.gx);
+            const int cy = cell_of(xyz[(size_t)k * 3 + 1], H.miny, H.inv_h, H.gy);
+            const int cz = cell_of(xyz[(size_t)k * 3 + 2], H.minz, H.inv_h, H.gz);
+            atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+        }
+        __syncthreads();
+        if (radius != 0.0f || pass >= 8) break;      // kernel argument: uniform
+        int ne = 0;
+        for (int c = tid; c < H.ncells; c += BQG_BUILD_T) ne += hist[c] > 0 ? 1 : 0;
+        for (int off = 32; off >= 1; off >>= 1) ne += __shfl_xor(ne, off, 64);
+        if (lane == 0 && ne) atomicAdd(&s_nonempty, ne);
+        __syncthreads();
+        if (tid == 0) {
+            s_again = 0;
+            if ((long long)s_nonempty * 2 < n) {
+                const float h = s_h * 0.79370052598f;   // 2^(-1/3): half the cell volume
+                int g[3];
+                long long total = 1;
+                for (int a = 0; a < 3; ++a) {
+                    const float q = s_ext[a] / h;
+                    g[a] = q < 1023.0f ? (int)q + 1 : 1024;
+                    if (!(q == q)) g[a] = 1;
+                    total *= g[a];
+                }
+                if (total <= BQG_CAP && h > 1e-30f) {
+                    s_h = h;
+                    sh.inv_h = 1.0f / h;
+                    sh.gx = g[0]; sh.gy = g[1]; sh.gz = g[2];
+                    sh.ncells = g[0] * g[1] * g[2];
+                    s_again = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (!s_again) break;
+        H = sh;
+        __syncthreads();
     }
-    __syncthreads();
+    if (tid == 0) {
+        float *hp = hdr_all + (size_t)b * BQG_HDR;
+        hp[0] = H.minx; hp[1] = H.miny; hp[2] = H.minz; hp[3] = H.inv_h;
+        reinterpret_cast<int *>(hp)[4] = H.gx; reinterpret_cast<int *>(hp)[5] = H.gy;
+        reinterpret_cast<int *>(hp)[6] = H.gz; reinterpret_cast<int *>(hp)[7] = H.ncells;
+    }
 
     // ---- exclusive scan of hist[0..ncells) -> hist (running cursor) and cell_start (global)
     const int per = (H.ncells + BQG_BUILD_T - 1) / BQG_BUILD_T;
