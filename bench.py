@@ -451,7 +451,10 @@ def main():
     flop_summary = {"reference_form_GFLOP_per_step": round(sa_gf + fp_gf, 2),
                     "executed_GFLOP_per_step": round(sum(executed.values()) / 1e9, 2),
                     "mlp_kernels_ms_per_step": round(sum(o["ms_per_step"] for o in mlp_ops), 4),
-                    "note": "first-layer hoisting: W1 [f_nb ; dx] = (W1f f)[nb] + W1x dx (SA), W1 interp(f) = interp(W1 f) (FP)"}
+                    "note": "SA kernels run over compacted neighbour lists (ball_query's padding copies of the first hit are "
+                            "not computed: max-pool over a multiset = over the set; bit-identical; uniform clouds hold one point "
+                            "per ball, lidar-like ones 1.2-5.6); first-layer hoisting where it pays: W1 [f_nb ; dx] = (W1f f)[nb] "
+                            "+ W1x dx (SA, chosen per level by autotune_hoisting), W1 interp(f) = interp(W1 f) (FP)"}
     # dominant roofline-bounded kernel of the step: the fused SA kernel (fp32 MFMA), all its launches (both entry
     # points).  FPS takes longer but is a latency-bound dependency chain (one workgroup per cloud) with no
     # bandwidth or matrix roofline; it is listed under "ops" with its iteration rate.
@@ -512,7 +515,7 @@ def main():
                                "(pdm_ssd_amd/pipeline.py)" if args.pipeline_depth == 1 else
                                f"level-1 FPS cut into {args.pipeline_depth - 1} resumable segments: one launch per step runs "
                                f"segment s of batch i+{args.pipeline_depth}-s side by side, the rest of batch i+1's coordinate "
-                               "chain on the neck's stream, under the feature half of batch i; every step does one full "
+                               "chain on a third stream, under the feature half of batch i; every step does one full "
                                "batch of every kind of work (pdm_ssd_amd/pipeline.py)" if args.pipeline_depth >= 3 else
                                "sampling two batches deep: level-1 FPS of batch i+2 and levels 2-4 of batch i+1 on side "
                                "streams under the feature half of batch i; every step does one full batch of every "
