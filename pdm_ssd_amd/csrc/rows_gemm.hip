@@ -50,7 +50,20 @@ __global__ __launch_bounds__(512) void rows_gemm_kernel(RowsGemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos = lane & 15, g = lane >> 4;
     const int wp = wave >> 2, wc = wave & 3;
-    const long long r0 = (long long)blockIdx.x * RG_ROWS;
+    // FP_PRE: every row gathers three z rows of ITS cloud's known set (m x z_stride floats: 2 MB for FP1 of PointNet2MSG).
+    // Workgroups go to the 8 XCDs round-robin by linear id, so with the plain tile order each XCD's 4 MB L2 sees the
+    // z rows of every cloud (64 MB at bs=32) and keeps none.  When the tiles divide evenly, XCD x works through clouds
+    // x, x+8, x+16, ... instead: its L2 then holds the one or two known sets in flight (PMC, FP1 at bs=32: HBM reads
+    // 442 -> 140 MB per launch; the launch itself stays at 0.26 ms, it was not waiting for HBM).
+    int tile = blockIdx.x;
+    if constexpr (FP_PRE) {
+        const int tpc = a.n / RG_ROWS, nb = a.rows / a.n;          // tiles per cloud, clouds
+        if (gridDim.y == 1 && tpc * RG_ROWS == a.n && (nb & 7) == 0) {
+            const int xcd = tile & 7, slot = tile >> 3;
+            tile = ((slot / tpc) * 8 + xcd) * tpc + slot % tpc;
+        }
+    }
+    const long long r0 = (long long)tile * RG_ROWS;
     const int mb0 = blockIdx.y * RG_BLKS;
 
     // staging roles: this thread loads float4 `lane` of weight block mb0 + wave, and channels [4 part, +4) of row hrow
