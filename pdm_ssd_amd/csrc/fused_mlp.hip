@@ -763,8 +763,17 @@ __global__ __launch_bounds__(64 * W * PSW) void fp_mlp_fused_kernel(MlpDesc d, F
     const int tps = (a.n + 15) >> 4;  // tiles per sample
     const long long ntiles = (long long)a.b * tps;
     const long long niter = (ntiles + NT - 1) / NT;
+    // hoisted form: every fine point gathers z rows of ITS cloud's known set.  Workgroups go to the 8 XCDs round-robin
+    // by linear id; when the iterations divide evenly, XCD x works through clouds x, x+8, ... so that its L2 holds the
+    // known sets in flight instead of seeing every cloud's (same permutation as rows_gemm.hip)
+    const int ipc = tps / NT;   // iterations per cloud
+    const bool xcd_order = PRE && PSW == 1 && ipc * NT == tps && (a.b & 7) == 0 && (gridDim.x & 7) == 0 && a.b >= 8;
     for (long long base = (long long)blockIdx.x * PSW; base < niter; base += (long long)gridDim.x * PSW) {
-        const long long it = base + grp;
+        long long it = base + grp;
+        if (xcd_order && it < niter) {
+            const long long slot = it >> 3;
+            it = ((slot / ipc) * 8 + (it & 7)) * ipc + slot % ipc;
+        }
         Tiles<FpIn<PRE>, NT> in;
         Tiles<RowOut, NT> out;
 #pragma unroll
