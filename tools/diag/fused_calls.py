@@ -20,7 +20,7 @@ def measure(reps=3):
             for _ in range(reps):
                 run()
             torch.cuda.synchronize()
-            recs = [(n, e0.elapsed_time(e1)) for n, ints, e0, e1 in t.records if "mlp_fused" in n]
+            recs = [(n, e0.elapsed_time(e1)) for n, ints, e0, e1 in t.records if "mlp_fused" in n or "mlp_gemm" in n or "mlp_packed" in n]
     per = len(recs) // reps
     out = []
     for i in range(per):
