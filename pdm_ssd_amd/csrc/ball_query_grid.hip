@@ -210,8 +210,6 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
     const float radius2 = radius * radius;  // ball_query_gpu.cu:29
     const float absr = fabsf(radius);
 
-    __shared__ int s_pre[BQG_QWAVES][65];
-    __shared__ int s_beg[BQG_QWAVES][64];
     // a wave walks centres j, j + stride, ...: the bitmap is cleared once per wave and left clean by every centre
     for (int j = blockIdx.x * BQG_QWAVES + wave; j < m; j += gridDim.x * BQG_QWAVES) {
         const float *c3 = new_xyz + ((size_t)b * m + j) * 3;
@@ -243,20 +241,24 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
             }
             const int total = __shfl(incl, 63, 64);
             if (total == 0) continue;  // wave-uniform
-            s_pre[wave][lane + 1] = incl;
-            s_beg[wave][lane] = beg;
-            if (lane == 0) s_pre[wave][0] = 0;
-            __builtin_amdgcn_wave_barrier();
             const int rows_here = min(64, nrows - r0);
+            const int start = incl - cntr;   // exclusive prefix: first candidate number of this lane's row
             const bool single = nrows <= 64 && total <= 64;  // every candidate of this centre sits in one lane
             for (int t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count
                 const int t = t0 + lane;
                 bool hit = false;
                 int k = 0x7FFFFFFF;
+                // candidate t lives in the LAST row whose first candidate number is <= t (empty rows share their
+                // successor's number and lose to it): a uniform walk over the rows with scalar broadcasts, no LDS
+                int rbeg = 0, rstart = 0;
+                for (int r = 0; r < rows_here; ++r) {
+                    const int st = __builtin_amdgcn_readlane(start, r), bg = __builtin_amdgcn_readlane(beg, r);
+                    const bool ge = t >= st;
+                    rbeg = ge ? bg : rbeg;
+                    rstart = ge ? st : rstart;
+                }
                 if (t < total) {
-                    int row = 0;
-                    while (row + 1 < rows_here && t >= s_pre[wave][row + 1]) ++row;
-                    const float4 q = sorted[s_beg[wave][row] + (t - s_pre[wave][row])];
+                    const float4 q = sorted[rbeg + (t - rstart)];
                     const float d2 = sqdist(cx - q.x, cy - q.y, cz - q.z);
                     hit = d2 < radius2;
                     if (hit) k = __float_as_int(q.w);
@@ -281,7 +283,6 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
                     used_bitmap = true;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
         if (!used_bitmap || hits == 0) continue;  // empty ball: row stays as the caller zero-filled it (pointnet2_utils.py:218)
         __builtin_amdgcn_wave_barrier();
