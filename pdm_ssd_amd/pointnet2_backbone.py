@@ -86,30 +86,36 @@ class PointNet2MSG(nn.Module):
         return out
 
     @torch.no_grad()
-    def autotune_hoisting(self, points, batch_size, margin=1.5):
+    def autotune_hoisting(self, points, batch_size, reps=3):
         """Pick, per SA layer, between the hoisted first layer (W1[:, features] applied once to every SOURCE point,
         fused.cached_pre_packs) and the plain form (applied to the compacted neighbour rows): with sparse
         neighbourhoods the compacted lists hold fewer rows than the source set and hoisting is the more expensive
-        form.  Decided from the first-layer MAC counts of one representative batch (`points` as for forward());
-        sets `sa.use_pre` and returns the decisions.  One host sync per scale: call it at set-up time."""
+        form.  Both forms of every level are run on one representative batch (`points` as for forward()) and timed
+        with events; sets `sa.use_pre` to the faster one and returns the measurements.  Call it at set-up time."""
         xyz = points[:, 1:4].contiguous().view(batch_size, -1, 3)
+        feats = points[:, 4:].contiguous().view(batch_size, -1, points.shape[1] - 4).permute(0, 2, 1).contiguous()
         decisions = []
-        src = xyz
-        cin = points.shape[1] - 4
         for sa in self.SA_modules:
-            new_xyz = sa.sample(src)
-            n_src = src.shape[0] * src.shape[1]
-            c1 = [mlp[0].out_channels for mlp in sa.mlps]
-            hoisted = n_src * cin * sum(c1)
-            plain = 0
-            for q, width in zip(sa.query(src, new_xyz), c1):
-                rows = int(q[1][6].item()) if isinstance(q, tuple) else q.shape[0] * q.shape[1] * q.shape[2]
-                plain += rows * (cin + 3) * width
-            use_pre = cin >= pointnet2_modules.PRE_MIN_CIN and plain * margin >= hoisted
-            sa.use_pre = bool(use_pre)
-            decisions.append({'hoisted_macs': int(hoisted), 'plain_macs': int(plain), 'use_pre': bool(use_pre)})
-            cin = sum(mlp[-3].out_channels for mlp in sa.mlps)
-            src = new_xyz
+            new_xyz = sa.sample(xyz)
+            idx_list = sa.query(xyz, new_xyz)
+            cin = feats.shape[1]
+            timing = {}
+            for form in ((True, False) if cin >= pointnet2_modules.PRE_MIN_CIN else (False,)):
+                sa.use_pre = form
+                out = sa(xyz, feats, new_xyz=new_xyz, idx_list=idx_list)[1]   # also builds the weight packs
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    out = sa(xyz, feats, new_xyz=new_xyz, idx_list=idx_list)[1]
+                e1.record()
+                torch.cuda.synchronize()
+                timing[form] = e0.elapsed_time(e1) / reps
+            sa.use_pre = min(timing, key=timing.get)
+            decisions.append({'use_pre': bool(sa.use_pre), 'ms_hoisted': timing.get(True), 'ms_plain': timing.get(False)})
+            if not sa.use_pre and True in timing:
+                out = sa(xyz, feats, new_xyz=new_xyz, idx_list=idx_list)[1]
+            xyz, feats = new_xyz, out.contiguous()
         return decisions
 
     @torch.no_grad()
