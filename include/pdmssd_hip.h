@@ -271,6 +271,11 @@ int pdm_tune_fused_gemm(int on);        /* LDS-tiled GEMM for single-layer rows 
 /* count device-to-device copies dst[k] <- src[k] (bytes[k] each; host arrays) in one launch per 48 buffers.
  * Plumbing for the stream pipeline's hand-over buffers, not a reference operator. */
 int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes);
+/* The same with device-side lengths: where dyn_count[k] != NULL only the first *dyn_count[k] * dyn_unit[k] bytes of buffer
+ * k are copied (the count is read when the kernel runs): worst-case-sized buffers with a device-computed number of
+ * live rows, e.g. the row lists of pdm_sa_pack (count = &meta[6], unit = 8). */
+int pdm_copy_many_dyn(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes,
+                      const int *const *dyn_count, const unsigned *dyn_unit);
 
 /* ---- PDM neck (build-defined spec, DESIGN.md "PDM spec"; no reference source exists) ------- */
 

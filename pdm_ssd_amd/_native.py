@@ -39,6 +39,7 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
+    "pdm_copy_many_dyn": [_i, _vp, _vp, _vp, _vp, _vp],
     "pdm_mark_time": [_vp],
     "pdm_boxes_overlap_bev": [_i, _vp, _i, _vp, _vp],
     "pdm_boxes_iou_bev": [_i, _vp, _i, _vp, _vp],
@@ -129,12 +130,26 @@ def call(name, stream, *args):
         raise NativeLibraryError(f"{name} failed with code {rc}: {msg}")
 
 
-def copy_many(dst, src):
-    """dst[k].copy_(src[k]) for lists of same-shaped contiguous CUDA tensors, in one kernel launch."""
+def copy_many(dst, src, live=None):
+    """dst[k].copy_(src[k]) for lists of same-shaped contiguous CUDA tensors, in one kernel launch.
+    live[k] = None | (count, unit): `count` a 1-element int32 CUDA tensor (view) read ON THE DEVICE when the copy runs —
+    only the first count * unit bytes of buffer k are live and copied (worst-case-sized buffers, fused.sa_pack)."""
     import torch
     n = len(dst)
     assert n == len(src)
     if n == 0:
+        return
+    if live is not None and any(x is not None for x in live):
+        assert len(live) == n
+        for d, s_ in zip(dst, src):
+            assert d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.shape == s_.shape, (d.shape, s_.shape)
+        P = ctypes.c_void_p * n
+        call("pdm_copy_many_dyn", torch.cuda.current_stream(dst[0].device).cuda_stream, n,
+             ctypes.cast(P(*[d.data_ptr() for d in dst]), ctypes.c_void_p),
+             ctypes.cast(P(*[s_.data_ptr() for s_ in src]), ctypes.c_void_p),
+             ctypes.cast((ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d in dst]), ctypes.c_void_p),
+             ctypes.cast(P(*[None if x is None else x[0].data_ptr() for x in live]), ctypes.c_void_p),
+             ctypes.cast((ctypes.c_uint * n)(*[0 if x is None else int(x[1]) for x in live]), ctypes.c_void_p))
         return
     for d, s_ in zip(dst, src):
         assert d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.shape == s_.shape, (d.shape, s_.shape)

@@ -31,11 +31,17 @@ struct CopyTable {
     void *dst[COPY_MAX];
     const void *src[COPY_MAX];
     unsigned long long bytes[COPY_MAX];
+    const int *dyn[COPY_MAX];     // optional: only the first *dyn[k] * unit[k] bytes are live (device-side count)
+    unsigned unit[COPY_MAX];
 };
 
 __global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
     const int k = blockIdx.y;
-    const unsigned long long n = t.bytes[k];
+    unsigned long long n = t.bytes[k];
+    if (t.dyn[k]) {
+        const unsigned long long live = (unsigned long long)max(*t.dyn[k], 0) * t.unit[k];
+        n = live < n ? live : n;
+    }
     char *__restrict__ d = static_cast<char *>(t.dst[k]);
     const char *__restrict__ s = static_cast<const char *>(t.src[k]);
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -52,7 +58,24 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
 
 }  // namespace pdm
 
+static int copy_many_impl(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes,
+                          const int *const *dyn_count, const unsigned *dyn_unit);
+
 extern "C" int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes) {
+    return copy_many_impl(stream, count, dst, src, bytes, nullptr, nullptr);
+}
+
+// The same with device-side lengths: where dyn_count[k] is not null only the first *dyn_count[k] * dyn_unit[k] bytes of
+// buffer k are copied (read when the kernel runs) — buffers sized for a worst case that hold a device-computed number of
+// live rows (the compacted neighbour lists of pdm_sa_pack: count = &meta[6], unit = 8).
+extern "C" int pdm_copy_many_dyn(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes,
+                                 const int *const *dyn_count, const unsigned *dyn_unit) {
+    PDM_REQUIRE(count == 0 || (dyn_count && dyn_unit), PDM_E_BADARG, "copy_many_dyn: null table");
+    return copy_many_impl(stream, count, dst, src, bytes, dyn_count, dyn_unit);
+}
+
+static int copy_many_impl(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes,
+                          const int *const *dyn_count, const unsigned *dyn_unit) {
     using namespace pdm;
     PDM_REQUIRE(count >= 0, PDM_E_BADARG, "copy_many: count=%d", count);
     PDM_REQUIRE(count == 0 || (dst && src && bytes), PDM_E_BADARG, "copy_many: null table");
@@ -64,6 +87,8 @@ extern "C" int pdm_copy_many(void *stream, int count, void *const *dst, const vo
             if (bytes[k] == 0) continue;
             PDM_REQUIRE(dst[k] && src[k], PDM_E_BADARG, "copy_many: null buffer %d", k);
             t.dst[n] = dst[k]; t.src[n] = src[k]; t.bytes[n] = bytes[k];
+            t.dyn[n] = dyn_count ? dyn_count[k] : nullptr;
+            t.unit[n] = dyn_count ? dyn_unit[k] : 0u;
             largest = bytes[k] > largest ? bytes[k] : largest;
             ++n;
         }

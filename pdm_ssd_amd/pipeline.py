@@ -45,6 +45,17 @@ def _flat(d):
     return out
 
 
+def _live(d):
+    """Per tensor of _flat(d): None, or (device-side row count, bytes per row) for the compacted neighbour lists — their
+    buffers are sized for the worst case (every slot distinct) and mostly empty on sparse clouds."""
+    out = [None] * len(d['sampled_xyz'])
+    for lvl in d['ball_idx']:
+        for q in lvl:
+            out.extend([(q[1][6:7], 8), None] if isinstance(q, tuple) else [None])
+    out.extend([None] * (2 * len(d['fp_interp'])))
+    return out
+
+
 def _merge(a, b):
     return {k: list(a[k]) + list(b[k]) for k in ('sampled_xyz', 'ball_idx', 'fp_interp')}
 
@@ -122,7 +133,7 @@ class PipelinedHotPath:
         bd = self._features(points_cur, batch_size, extra)
         main.wait_stream(self.side3)
         main.wait_stream(self.side)
-        _native.copy_many(_flat(self.cur), _flat(nxt))
+        _native.copy_many(_flat(self.cur), _flat(nxt), _live(nxt))
         # shift the segment states one stage on, last stage first (each launch's sources are the next one's targets)
         _native.copy_many([self.l1idx], [self.seg[S - 1][1]])
         for s in range(S - 1, 1, -1):
@@ -160,7 +171,7 @@ class PipelinedHotPath:
     def part_handover(self):
         S = self.nseg
         nxt, fresh = self._pending
-        _native.copy_many(_flat(self.cur), _flat(nxt))
+        _native.copy_many(_flat(self.cur), _flat(nxt), _live(nxt))
         _native.copy_many([self.l1idx], [self.seg[S - 1][1]])
         for s in range(S - 1, 1, -1):
             _native.copy_many(list(self.seg[s]), list(self.seg[s - 1]))
@@ -231,7 +242,7 @@ class PipelinedHotPath:
         if self.depth == 2:
             main.wait_stream(self.side2)
         # hand-over into the static buffers (addresses must not change under hipGraph replay): one multi-tensor copy
-        _native.copy_many(_flat(self.cur), _flat(nxt))
+        _native.copy_many(_flat(self.cur), _flat(nxt), _live(nxt))
         if self.depth == 2:   # a second launch: self.half is a SOURCE of the first one (level 1 of `nxt`)
             _native.copy_many(_flat(self.half), _flat(nxt_half))
         return bd
