@@ -472,3 +472,31 @@ def test_fps_resumable_segments_match_one_call(dev, n, m, cuts):
     from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as hipops
     hipops.farthest_point_sampling_wrapper(3, n, m, cl_a, ref_temp, ref_idx)
     assert torch.equal(st["a"][0], ref_temp)
+
+
+def test_copy_many_device_side_lengths(dev):
+    """pdm_copy_many_dyn: buffers with a live-row count on the device are copied up to that count only; the others
+    whole; counts beyond the buffer or below zero are clamped."""
+    from pdm_ssd_amd import _native
+    src = [torch.arange(1000, dtype=torch.int32, device=dev).view(500, 2) + 1, torch.rand(77, device=dev),
+           torch.arange(64, dtype=torch.int32, device=dev).view(32, 2) + 5, torch.rand(9, 3, device=dev)]
+    dst = [torch.zeros_like(t) for t in src]
+    counts = torch.tensor([0, 0, 0, 0, 0, 0, 123, 0, 10 ** 6, -4], dtype=torch.int32, device=dev)
+    live = [(counts[6:7], 8), None, (counts[8:9], 8), (counts[9:10], 12)]
+    _native.copy_many(dst, src, live)
+    assert torch.equal(dst[0][:123], src[0][:123]) and (dst[0][123:] == 0).all()
+    assert torch.equal(dst[1], src[1])
+    assert torch.equal(dst[2], src[2])            # count larger than the buffer: all of it
+    assert (dst[3] == 0).all()                    # negative count: nothing
+
+
+def test_mark_time_orders_stream_work(dev):
+    from pdm_ssd_amd import _native
+    marks = torch.zeros(2, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    _native.call("pdm_mark_time", s, marks.data_ptr())
+    torch.cuda._sleep(200000)
+    _native.call("pdm_mark_time", s, marks.data_ptr() + 8)
+    torch.cuda.synchronize()
+    t0, t1 = marks.cpu().tolist()
+    assert t1 > t0 > 0
