@@ -56,6 +56,13 @@ int pdm_group_points(void *stream, int b, int c, int n, int npoints, int nsample
 int pdm_group_points_grad(void *stream, int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx, float *grad_points);
 
+/* The same backward with a caller-provided workspace (pdm_group_points_grad_ws_bytes bytes): scatter inverted into CSR lists,
+ * accumulated without atomics (as pdm_three_interpolate_grad_ws).  Forwards to the plain entry point when a grad_out row
+ * (npoints * nsample floats) exceeds 128 KB or n > 16384. */
+size_t pdm_group_points_grad_ws_bytes(int b, int npoints, int nsample, int n);
+int pdm_group_points_grad_ws(void *stream, int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                             const int *idx, float *grad_points, void *workspace, size_t workspace_bytes);
+
 /* replaces gather_points_wrapper_fast         sampling.cpp:14-22 -> sampling_gpu.cu:15-51
  * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
 int pdm_gather_points(void *stream, int b, int c, int n, int npoints, const float *points,
@@ -103,6 +110,13 @@ int pdm_three_interpolate(void *stream, int b, int c, int m, int n, const float 
  * grad_out (B,C,N) -> grad_points (B,C,M), caller-zeroed, accumulated. */
 int pdm_three_interpolate_grad(void *stream, int b, int c, int n, int m, const float *grad_out,
                                const int *idx, const float *weight, float *grad_points);
+
+/* The same backward with a caller-provided workspace (pdm_three_interpolate_grad_ws_bytes(b, n, m) bytes): the scatter is
+ * first inverted into per-cloud CSR lists (known point <- its contributions), the accumulation then needs no atomics.
+ * Same sums in a different fp32 order; m <= 16384 and n <= 32768, otherwise it forwards to the plain entry point. */
+size_t pdm_three_interpolate_grad_ws_bytes(int b, int n, int m);
+int pdm_three_interpolate_grad_ws(void *stream, int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points, void *workspace, size_t workspace_bytes);
 
 /* ---- fused forms of the same path (additions; same arithmetic, fewer passes over HBM) ------ */
 

@@ -13,6 +13,12 @@ namespace pdm {
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 
+// Scatter-add backward through an inverted (CSR) index, shared by three_interpolate and group_points (interpolate.hip)
+size_t csr_workspace_bytes(int b, long long ne, int m);
+bool csr_form_applies(int b, int row_len, long long ne, int m);
+int csr_scatter_grad_launch(void *stream, const char *who, int b, int c, int row_len, int per, int m, const float *grad_out,
+                            const int *idx, const float *weight, float *grad_points, void *workspace);
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int divup(long long a, long long b) { return (int)((a + b - 1) / b); }

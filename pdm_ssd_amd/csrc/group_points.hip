@@ -247,6 +247,27 @@ extern "C" int pdm_group_points_grad(void *stream, int b, int c, int n, int npoi
     return check_launch("group_points_grad");
 }
 
+extern "C" size_t pdm_group_points_grad_ws_bytes(int b, int npoints, int nsample, int n) {
+    return csr_workspace_bytes(b, (long long)npoints * nsample, n);
+}
+
+// pdm_group_points_grad with a caller-provided workspace (pdm_group_points_grad_ws_bytes bytes): the scatter onto the n
+// source points is inverted into per-cloud CSR lists, then accumulated without atomics (interpolate.hip).  Applies when a
+// grad_out row (npoints * nsample floats) fits 128 KB of LDS and n <= 16384; otherwise the plain entry point is used.
+extern "C" int pdm_group_points_grad_ws(void *stream, int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                        const int *idx, float *grad_points, void *workspace, size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, PDM_E_BADARG, "group_points_grad_ws: negative size");
+    const long long L = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || L == 0) return 0;
+    PDM_REQUIRE(grad_out && idx && grad_points, PDM_E_BADARG, "group_points_grad_ws: null pointer");
+    if (L > 32768 || !csr_form_applies(b, (int)L, L, n))
+        return pdm_group_points_grad(stream, b, c, n, npoints, nsample, grad_out, idx, grad_points);
+    PDM_REQUIRE(workspace && workspace_bytes >= pdm_group_points_grad_ws_bytes(b, npoints, nsample, n), PDM_E_BADARG,
+                "group_points_grad_ws: workspace of %zu bytes, need %zu", workspace_bytes,
+                pdm_group_points_grad_ws_bytes(b, npoints, nsample, n));
+    return csr_scatter_grad_launch(stream, "group_points_grad_ws", b, c, (int)L, 1, n, grad_out, idx, nullptr, grad_points, workspace);
+}
+
 extern "C" int pdm_group_concat(void *stream, int b, int n, int m, int c, int nsample,
                                 const float *xyz, const float *new_xyz, const float *features,
                                 const int *idx, float *out) {

@@ -158,9 +158,173 @@ __global__ __launch_bounds__(TIL_THREADS) void three_interpolate_grad_lds_kernel
     }
 }
 
+// ---- backward of three_interpolate without atomics in the inner loop -------------------------------------------------
+// LDS float atomics turned out to be the limit of the kernel above: ~270 GB/s of grad_out for every shape, i.e. one
+// ds_add_f32 lane every three cycles per CU.  The scatter is inverted once per (idx, weight) pair instead: per cloud a CSR
+// table "known point k <- its (unknown point j, weight) contributions" (counting sort, one workgroup per cloud), then
+//   grad_points[b, c, k] += sum_{(j, w) in list(k)} w * grad_out[b, c, j]
+// with the grad_out rows of a few channels staged in LDS (coalesced global reads, random LDS READS) and one thread per
+// known point.  Needs m <= 16384 (LDS histogram) and n <= 65535 (16-bit j).
+constexpr int TIC_THREADS = 1024;
+
+// ne = contributions per cloud, `per` of them per source row (three_interpolate: 3 per unknown point, with weights;
+// group_points: 1 per grouped slot, weight 1)
+__global__ __launch_bounds__(TIC_THREADS) void interp_csr_build_kernel(int ne, int per, int m, const int *__restrict__ idx,
+                                                                       const float *__restrict__ weight,
+                                                                       int *__restrict__ start_all,
+                                                                       unsigned short *__restrict__ ej_all,
+                                                                       float *__restrict__ ew_all) {
+    extern __shared__ int s_cnt[];   // m counters, then running cursors
+    __shared__ int s_wave[TIC_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *__restrict__ id = idx + (size_t)b * ne;
+    const float *__restrict__ w = weight ? weight + (size_t)b * ne : nullptr;
+    int *__restrict__ start = start_all + (size_t)b * (m + 1);
+    unsigned short *__restrict__ ej = ej_all + (size_t)b * ne;
+    float *__restrict__ ew = ew_all + (size_t)b * ne;
+    for (int k = tid; k < m; k += TIC_THREADS) s_cnt[k] = 0;
+    __syncthreads();
+    for (int e = tid; e < ne; e += TIC_THREADS) {
+        const int k = id[e];
+        if (k >= 0 && k < m) atomicAdd(&s_cnt[k], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the m counters: contiguous chunk per thread, wave scan, wave offsets
+    const int chunk = (m + TIC_THREADS - 1) / TIC_THREADS;
+    const int k0 = tid * chunk, k1 = min(k0 + chunk, m);
+    int local = 0;
+    for (int k = k0; k < k1; ++k) local += s_cnt[k];
+    int incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < wave; ++q) base += s_wave[q];
+    int run = base + incl - local;
+    for (int k = k0; k < k1; ++k) {
+        const int cnt = s_cnt[k];
+        start[k] = run;
+        s_cnt[k] = run;      // becomes the fill cursor
+        run += cnt;
+    }
+    if (tid == TIC_THREADS - 1) start[m] = run;
+    __syncthreads();
+    for (int e = tid; e < ne; e += TIC_THREADS) {
+        const int k = id[e];
+        if (k < 0 || k >= m) continue;
+        const int pos = atomicAdd(&s_cnt[k], 1);
+        ej[pos] = (unsigned short)(e / per);
+        ew[pos] = w ? w[e] : 1.0f;
+    }
+}
+
+template <int TC>
+__global__ __launch_bounds__(TIC_THREADS) void interp_grad_csr_kernel(int c, int n, int ne, int m,
+                                                                      const float *__restrict__ grad_out,
+                                                                      const int *__restrict__ start_all,
+                                                                      const unsigned short *__restrict__ ej_all,
+                                                                      const float *__restrict__ ew_all,
+                                                                      float *__restrict__ grad_points) {
+    extern __shared__ float s_g[];   // TC x n
+    const int b = blockIdx.y, c0 = blockIdx.x * TC, tid = threadIdx.x;
+    const int nc = min(TC, c - c0);
+    const float *__restrict__ g = grad_out + ((size_t)b * c + c0) * n;
+    for (int e = tid; e < nc * n; e += TIC_THREADS) s_g[e] = g[e];   // nc consecutive rows are one contiguous block
+    __syncthreads();
+    const int *__restrict__ start = start_all + (size_t)b * (m + 1);
+    const unsigned short *__restrict__ ej = ej_all + (size_t)b * ne;
+    const float *__restrict__ ew = ew_all + (size_t)b * ne;
+    for (int k = tid; k < m; k += TIC_THREADS) {
+        const int s = start[k], e = start[k + 1];
+        float acc[TC];
+#pragma unroll
+        for (int ci = 0; ci < TC; ++ci) acc[ci] = 0.0f;
+        for (int p = s; p < e; ++p) {
+            const int j = ej[p];
+            const float w = ew[p];
+#pragma unroll
+            for (int ci = 0; ci < TC; ++ci)
+                if (ci < nc) acc[ci] += s_g[ci * n + j] * w;
+        }
+#pragma unroll
+        for (int ci = 0; ci < TC; ++ci)
+            if (ci < nc) grad_points[((size_t)b * c + c0 + ci) * m + k] += acc[ci];   // rows are exclusive to this workgroup
+    }
+}
+
 }  // namespace pdm
 
 using namespace pdm;
+
+// Shared by three_interpolate and group_points: rows of `row_len` floats per (cloud, channel) in grad_out, ne = per * rows'
+// contributions per cloud scattered onto m targets.  Workspace: csr_workspace_bytes(b, ne, m).
+namespace pdm {
+size_t csr_workspace_bytes(int b, long long ne, int m) {
+    if (b <= 0 || ne <= 0 || m <= 0) return 0;
+    return ((size_t)b * (m + 1) * sizeof(int) + 15) / 16 * 16 + ((size_t)b * ne * sizeof(unsigned short) + 15) / 16 * 16 +
+           (size_t)b * ne * sizeof(float) + 64;
+}
+bool csr_form_applies(int b, int row_len, long long ne, int m) {
+    return m >= 1 && m <= 16384 && row_len >= 1 && row_len <= 32768 && ne <= 0x7fffffffll / 4 && b <= 65535;
+}
+int csr_scatter_grad_launch(void *stream, const char *who, int b, int c, int row_len, int per, int m, const float *grad_out,
+                            const int *idx, const float *weight, float *grad_points, void *workspace) {
+    const int ne = row_len * per;
+    uintptr_t p = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+    int *start = reinterpret_cast<int *>(p);
+    p += ((size_t)b * (m + 1) * sizeof(int) + 15) / 16 * 16;
+    unsigned short *ej = reinterpret_cast<unsigned short *>(p);
+    p += ((size_t)b * ne * sizeof(unsigned short) + 15) / 16 * 16;
+    float *ew = reinterpret_cast<float *>(p);
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(TIC_THREADS), (size_t)m * sizeof(int), as_stream(stream), ne, per, m,
+                       idx, weight, start, ej, ew);
+    int rc = check_launch(who);
+    if (rc) return rc;
+    // channel rows staged per workgroup: as many as fit 128 KB of LDS, at most 8
+    const int tc = row_len <= 4096 ? 8 : row_len <= 8192 ? 4 : row_len <= 16384 ? 2 : 1;
+    static bool granted[4] = {false, false, false, false};
+#define PDM_TIC_LAUNCH(TCV, SLOT)                                                                                      \
+    do {                                                                                                               \
+        const size_t lds = (size_t)TCV * row_len * sizeof(float);                                                      \
+        if (lds > 64 * 1024 && !granted[SLOT]) {                                                                       \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_grad_csr_kernel<TCV>),     \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
+            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "%s: cannot obtain %zu bytes of LDS", who, lds);              \
+            granted[SLOT] = true;                                                                                      \
+        }                                                                                                              \
+        hipLaunchKernelGGL(interp_grad_csr_kernel<TCV>, dim3(divup(c, TCV), b), dim3(TIC_THREADS), lds, as_stream(stream), \
+                           c, row_len, ne, m, grad_out, start, ej, ew, grad_points);                                   \
+    } while (0)
+    if (tc == 8) PDM_TIC_LAUNCH(8, 0);
+    else if (tc == 4) PDM_TIC_LAUNCH(4, 1);
+    else if (tc == 2) PDM_TIC_LAUNCH(2, 2);
+    else PDM_TIC_LAUNCH(1, 3);
+#undef PDM_TIC_LAUNCH
+    return check_launch(who);
+}
+}  // namespace pdm
+
+extern "C" size_t pdm_three_interpolate_grad_ws_bytes(int b, int n, int m) { return csr_workspace_bytes(b, 3ll * n, m); }
+
+// pdm_three_interpolate_grad with a caller-provided workspace (pdm_three_interpolate_grad_ws_bytes(b, n, m) bytes): the
+// scatter is inverted into per-cloud CSR lists first, the accumulation then runs without atomics (same sums, different
+// fp32 summation order).  m <= 16384 and n <= 32768 (16-bit row numbers, rows staged in LDS), otherwise the plain entry point.
+extern "C" int pdm_three_interpolate_grad_ws(void *stream, int b, int c, int n, int m, const float *grad_out,
+                                             const int *idx, const float *weight, float *grad_points, void *workspace,
+                                             size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0, PDM_E_BADARG, "three_interpolate_grad_ws: negative size");
+    if (b == 0 || c == 0 || n == 0) return 0;
+    PDM_REQUIRE(grad_out && idx && weight && grad_points, PDM_E_BADARG, "three_interpolate_grad_ws: null pointer");
+    if (!csr_form_applies(b, n, 3ll * n, m))
+        return pdm_three_interpolate_grad(stream, b, c, n, m, grad_out, idx, weight, grad_points);
+    PDM_REQUIRE(workspace && workspace_bytes >= pdm_three_interpolate_grad_ws_bytes(b, n, m), PDM_E_BADARG,
+                "three_interpolate_grad_ws: workspace of %zu bytes, need %zu", workspace_bytes,
+                pdm_three_interpolate_grad_ws_bytes(b, n, m));
+    return csr_scatter_grad_launch(stream, "three_interpolate_grad_ws", b, c, n, 3, m, grad_out, idx, weight, grad_points, workspace);
+}
 
 extern "C" int pdm_three_nn_weights(void *stream, long long rows, const float *dist2, float *dist, float *weight) {
     PDM_REQUIRE(rows >= 0, PDM_E_BADARG, "three_nn_weights: negative size");

@@ -74,8 +74,10 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     _check("grad_points", grad_points, torch.float32)
     _numel_at_least("grad_out", grad_out, b * c * npoints * nsample)
     _numel_at_least("idx", idx, b * npoints * nsample); _numel_at_least("grad_points", grad_points, b * c * n)
-    _run("pdm_group_points_grad", grad_out, b, c, n, npoints, nsample, grad_out.data_ptr(), idx.data_ptr(),
-         grad_points.data_ptr())
+    nbytes = _native.lib().pdm_group_points_grad_ws_bytes(b, npoints, nsample, n)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=grad_out.device)   # CSR lists of the inverted scatter
+    _run("pdm_group_points_grad_ws", grad_out, b, c, n, npoints, nsample, grad_out.data_ptr(), idx.data_ptr(),
+         grad_points.data_ptr(), ws.data_ptr(), nbytes)
     return 1
 
 
@@ -148,8 +150,10 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     _check("weight", weight, torch.float32); _check("grad_points", grad_points, torch.float32)
     _numel_at_least("grad_out", grad_out, b * c * n); _numel_at_least("idx", idx, b * n * 3)
     _numel_at_least("weight", weight, b * n * 3); _numel_at_least("grad_points", grad_points, b * c * m)
-    _run("pdm_three_interpolate_grad", grad_out, b, c, n, m, grad_out.data_ptr(), idx.data_ptr(),
-         weight.data_ptr(), grad_points.data_ptr())
+    nbytes = _native.lib().pdm_three_interpolate_grad_ws_bytes(b, n, m)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=grad_out.device)   # CSR lists of the inverted scatter
+    _run("pdm_three_interpolate_grad_ws", grad_out, b, c, n, m, grad_out.data_ptr(), idx.data_ptr(),
+         weight.data_ptr(), grad_points.data_ptr(), ws.data_ptr(), nbytes)
 
 
 # ---- fused addition (not in the reference's table) -------------------------------------------

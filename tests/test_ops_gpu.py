@@ -500,3 +500,38 @@ def test_mark_time_orders_stream_work(dev):
     torch.cuda.synchronize()
     t0, t1 = marks.cpu().tolist()
     assert t1 > t0 > 0
+
+
+@pytest.mark.parametrize("c,n,m", [(5, 16384, 4096), (19, 5000, 1300), (8, 4096, 1024), (3, 300, 7), (33, 64, 64)])
+def test_three_interpolate_grad_csr_form(oracle, dev, c, n, m):
+    """The backward through the inverted (CSR) scatter — what three_interpolate_grad_wrapper runs — against the oracle,
+    including the reference's accumulate-into-grad_points behaviour (the caller zero-fills, interpolate_gpu.cu:127-149)."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as hipops
+    rng = np.random.default_rng(c * n + m)
+    B = 3
+    go = rng.standard_normal((B, c, n)).astype(np.float32)
+    idx = rng.integers(0, m, size=(B, n, 3)).astype(np.int32)
+    idx[0, : n // 2] = 0                                   # a heavily shared known point (long CSR list)
+    w = rng.random((B, n, 3)).astype(np.float32)
+    want = oracle.three_interpolate_grad(go, idx, w, m)
+    gp = torch.full((B, c, m), 0.5, device=dev)
+    hipops.three_interpolate_grad_wrapper(B, c, n, m, T(go, dev), T(idx, dev), T(w, dev), gp)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(gp.cpu().numpy() - 0.5, want, rtol=1e-4, atol=1e-5 * max(scale, 1.0) + 1e-4)
+
+
+@pytest.mark.parametrize("c,n,m,ns", [(7, 4096, 1024, 32), (96, 2000, 1024, 16), (3, 16384, 512, 16), (5, 300, 64, 32), (4, 16384, 4096, 16)])
+def test_group_points_grad_csr_form(oracle, dev, c, n, m, ns):
+    """group_points backward through the inverted (CSR) scatter (rows of m*ns <= 32768 floats) and through the plain
+    entry point beyond that (last case), against the oracle; grad_points is accumulated into, as the reference does."""
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as hipops
+    rng = np.random.default_rng(c + n + m)
+    B = 2
+    go = rng.standard_normal((B, c, m, ns)).astype(np.float32)
+    idx = rng.integers(0, n, size=(B, m, ns)).astype(np.int32)
+    idx[1, :, : ns // 2] = 3                                # one source point in half of all slots
+    want = oracle.grouping_operation_grad(go, idx, n)
+    gp = torch.full((B, c, n), -1.0, device=dev)
+    hipops.group_points_grad_wrapper(B, c, n, m, ns, T(go, dev), T(idx, dev), gp)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(gp.cpu().numpy() + 1.0, want, rtol=1e-4, atol=1e-5 * max(scale, 1.0) + 1e-4)
