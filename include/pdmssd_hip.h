@@ -56,6 +56,18 @@ int pdm_group_points(void *stream, int b, int c, int n, int npoints, int nsample
 int pdm_group_points_grad(void *stream, int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx, float *grad_points);
 
+/* QueryAndGroup's concat (pointnet2_utils.py:249-257) in channels-last memory for the training path: out (B, M, nsample,
+ * 3+C) = an NHWC view of the reference's (B, 3+C, M, nsample) tensor, fp32 or (out_bf16 = 1) bf16 rounded to nearest even
+ * from the fp32 value; feat_pm (B, N, C) point-major; idx (B, M, nsample) from pdm_ball_query. */
+int pdm_group_concat_cl(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                        const float *feat_pm, const int *idx, void *out, int out_bf16);
+/* Its backward: grad (B, M, nsample, 3+C) fp32 or bf16 -> grad_feat_pm (B, N, C) fp32, fully written (the xyz channels carry
+ * no gradient, as in the reference graph).  Scatter inverted into CSR lists in `workspace`
+ * (pdm_group_concat_cl_grad_ws_bytes bytes), then one wave per source point adds its rows up: no atomics.  n <= 16384. */
+size_t pdm_group_concat_cl_grad_ws_bytes(int b, int n, int m, int nsample);
+int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16,
+                             const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes);
+
 /* The same backward with a caller-provided workspace (pdm_group_points_grad_ws_bytes bytes): scatter inverted into CSR lists,
  * accumulated without atomics (as pdm_three_interpolate_grad_ws).  Forwards to the plain entry point when a grad_out row
  * (npoints * nsample floats) exceeds 128 KB or n > 16384. */

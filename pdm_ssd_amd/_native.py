@@ -38,6 +38,8 @@ _SIGNATURES = {
     "pdm_three_interpolate_grad_ws": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_query_and_group": [_i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_group_concat": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_group_concat_cl": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i],
+    "pdm_group_concat_cl_grad": [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
@@ -80,7 +82,7 @@ EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_b
            "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes",
            "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
            "pdm_sa_pack_rows", "pdm_three_interpolate_grad_ws_bytes",
-           "pdm_group_points_grad_ws_bytes"] + list(_SIGNATURES)
+           "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -110,6 +112,8 @@ def lib():
         l.pdm_nms_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_sa_pack_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_sa_pack_workspace_bytes.argtypes = [_i, _i]
+        l.pdm_group_concat_cl_grad_ws_bytes.restype = ctypes.c_size_t
+        l.pdm_group_concat_cl_grad_ws_bytes.argtypes = [_i, _i, _i, _i]
         l.pdm_group_points_grad_ws_bytes.restype = ctypes.c_size_t
         l.pdm_group_points_grad_ws_bytes.argtypes = [_i, _i, _i, _i]
         l.pdm_three_interpolate_grad_ws_bytes.restype = ctypes.c_size_t

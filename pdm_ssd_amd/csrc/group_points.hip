@@ -310,3 +310,169 @@ extern "C" int pdm_query_and_group(void *stream, int b, int n, int m, int c, flo
     if (rc != 0) return rc;
     return pdm_group_concat(stream, b, n, m, c, nsample, xyz, new_xyz, features, idx, out);
 }
+
+// ---- channels-last QueryAndGroup for the training path -----------------------------------------------------------------
+// The autograd path feeds torch/MIOpen convolutions that want NHWC tensors, bf16 under autocast.  pdm_group_concat writes
+// the reference's (B, 3+C, M, ns) fp32 layout, which then costs a layout copy and a dtype copy over the largest tensor of
+// the step.  This form writes out[b][m][s][3+C] (= a channels-last view of the same logical tensor) in fp32 or bf16
+// directly: element e of the output is one thread, rows of the point-major feature table are read contiguously.
+// bf16 = round-to-nearest-even of the fp32 value, i.e. exactly what the cast would have produced.
+namespace pdm {
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);   // NaN stays NaN (quiet)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void group_concat_cl_kernel(long long total, int n, int m, int c, int ns,
+                                                              const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                              const float *__restrict__ feat_pm, const int *__restrict__ idx,
+                                                              void *__restrict__ out) {
+    const int w = 3 + c;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / w;                 // (b, centre, slot)
+        const int ch = (int)(e - row * w);
+        const long long bm = row / ns;               // b * m + centre
+        const int b = (int)(bm / m);
+        const int src = idx[row];
+        float v;
+        if (ch < 3) v = xyz[((size_t)b * n + src) * 3 + ch] - new_xyz[bm * 3 + ch];   // pointnet2_utils.py:252
+        else v = feat_pm[((size_t)b * n + src) * c + (ch - 3)];
+        if constexpr (BF16) static_cast<unsigned short *>(out)[e] = f32_to_bf16_rne(v);
+        else static_cast<float *>(out)[e] = v;
+    }
+}
+
+}  // namespace pdm
+
+// out (B, M, ns, 3+C) fp32 (out_bf16 = 0) or bf16 (1); feat_pm (B, N, C) point-major, may be null when c == 0; idx (B, M, ns).
+extern "C" int pdm_group_concat_cl(void *stream, int b, int n, int m, int c, int nsample, const float *xyz,
+                                   const float *new_xyz, const float *feat_pm, const int *idx, void *out, int out_bf16) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0, PDM_E_BADARG, "group_concat_cl: negative size");
+    const long long total = (long long)b * m * nsample * (3 + c);
+    if (total == 0) return 0;
+    PDM_REQUIRE(xyz && new_xyz && idx && out && (c == 0 || feat_pm), PDM_E_BADARG, "group_concat_cl: null pointer");
+    const long long want = (total + 255) / 256;
+    const int blocks = (int)(want < 256 * 64 ? want : 256 * 64);
+    if (out_bf16)
+        hipLaunchKernelGGL(pdm::group_concat_cl_kernel<true>, dim3(blocks), dim3(256), 0, pdm::as_stream(stream), total, n, m, c,
+                           nsample, xyz, new_xyz, feat_pm, idx, out);
+    else
+        hipLaunchKernelGGL(pdm::group_concat_cl_kernel<false>, dim3(blocks), dim3(256), 0, pdm::as_stream(stream), total, n, m, c,
+                           nsample, xyz, new_xyz, feat_pm, idx, out);
+    return pdm::check_launch("group_concat_cl");
+}
+
+// Backward of the channels-last form: grad (B, M, ns, 3+C) fp32 or bf16 -> grad_feat_pm (B, N, C) fp32, every element
+// written (zero where a point is in no group).  The scatter is inverted per cloud into CSR lists "source point <- grouped
+// slots" (counting sort in LDS, one workgroup per cloud); then one wave per source point adds up its slots' rows, lanes over
+// channels: every row is read once, contiguously, nothing is atomic.
+namespace pdm {
+
+constexpr int GCL_THREADS = 1024;
+
+__global__ __launch_bounds__(GCL_THREADS) void gcl_csr_build_kernel(int ne, int n, const int *__restrict__ idx,
+                                                                   int *__restrict__ start_all, int *__restrict__ el_all) {
+    extern __shared__ int s_cnt[];   // n counters, then fill cursors
+    __shared__ int s_wave[GCL_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *__restrict__ id = idx + (size_t)b * ne;
+    int *__restrict__ start = start_all + (size_t)b * (n + 1);
+    int *__restrict__ el = el_all + (size_t)b * ne;
+    for (int k = tid; k < n; k += GCL_THREADS) s_cnt[k] = 0;
+    __syncthreads();
+    for (int e = tid; e < ne; e += GCL_THREADS) {
+        const int k = id[e];
+        if (k >= 0 && k < n) atomicAdd(&s_cnt[k], 1);
+    }
+    __syncthreads();
+    const int chunk = (n + GCL_THREADS - 1) / GCL_THREADS;
+    const int k0 = tid * chunk, k1 = min(k0 + chunk, n);
+    int local = 0;
+    for (int k = k0; k < k1; ++k) local += s_cnt[k];
+    int incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < wave; ++q) base += s_wave[q];
+    int run = base + incl - local;
+    for (int k = k0; k < k1; ++k) {
+        const int cnt = s_cnt[k];
+        start[k] = run;
+        s_cnt[k] = run;
+        run += cnt;
+    }
+    if (tid == GCL_THREADS - 1) start[n] = run;
+    __syncthreads();
+    for (int e = tid; e < ne; e += GCL_THREADS) {
+        const int k = id[e];
+        if (k < 0 || k >= n) continue;
+        el[atomicAdd(&s_cnt[k], 1)] = e;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void gcl_grad_kernel(int n, int c, int ne, const void *__restrict__ grad,
+                                                       const int *__restrict__ start_all, const int *__restrict__ el_all,
+                                                       float *__restrict__ out_pm) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per source point
+    if (k >= n) return;
+    const int *__restrict__ start = start_all + (size_t)b * (n + 1);
+    const int *__restrict__ el = el_all + (size_t)b * ne;
+    const int s = start[k], e = start[k + 1];
+    const int w = 3 + c;
+    for (int c0 = 0; c0 < c; c0 += 64) {
+        const int ch = c0 + lane;
+        float acc = 0.0f;
+        if (ch < c) {
+            for (int p = s; p < e; ++p) {
+                const size_t off = ((size_t)b * ne + el[p]) * w + 3 + ch;
+                if constexpr (BF16) acc += __uint_as_float((unsigned)static_cast<const unsigned short *>(grad)[off] << 16);
+                else acc += static_cast<const float *>(grad)[off];
+            }
+            out_pm[((size_t)b * n + k) * c + ch] = acc;
+        }
+    }
+}
+
+}  // namespace pdm
+
+extern "C" size_t pdm_group_concat_cl_grad_ws_bytes(int b, int n, int m, int nsample) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return 0;
+    return (size_t)b * ((size_t)(n + 1) + (size_t)m * nsample) * sizeof(int) + 64;
+}
+
+// grad (B, M, ns, 3+C) fp32 / bf16 (grad_bf16) -> grad_feat_pm (B, N, C) fp32, fully written.  n <= 16384.
+extern "C" int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16,
+                                        const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0, PDM_E_BADARG, "group_concat_cl_grad: negative size");
+    if (b == 0 || n == 0 || c == 0) return 0;
+    PDM_REQUIRE(n <= 16384 && b <= 65535 && (long long)m * nsample < (1ll << 30), PDM_E_TOOLARGE,
+                "group_concat_cl_grad: n=%d (<= 16384), b=%d", n, b);
+    PDM_REQUIRE(grad_feat_pm && (m * nsample == 0 || (grad && idx)) && workspace, PDM_E_BADARG, "group_concat_cl_grad: null pointer");
+    PDM_REQUIRE(workspace_bytes >= pdm_group_concat_cl_grad_ws_bytes(b, n, m, nsample), PDM_E_BADARG,
+                "group_concat_cl_grad: workspace of %zu bytes, need %zu", workspace_bytes,
+                pdm_group_concat_cl_grad_ws_bytes(b, n, m, nsample));
+    const int ne = m * nsample;
+    uintptr_t p = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+    int *start = reinterpret_cast<int *>(p);
+    int *el = start + (size_t)b * (n + 1);
+    hipLaunchKernelGGL(pdm::gcl_csr_build_kernel, dim3(b), dim3(pdm::GCL_THREADS), (size_t)n * sizeof(int), pdm::as_stream(stream), ne,
+                       n, idx, start, el);
+    int rc = pdm::check_launch("group_concat_cl_grad(csr)");
+    if (rc) return rc;
+    const dim3 grid((unsigned)((n + 3) / 4), (unsigned)b);
+    if (grad_bf16)
+        hipLaunchKernelGGL(pdm::gcl_grad_kernel<true>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, grad, start, el, grad_feat_pm);
+    else
+        hipLaunchKernelGGL(pdm::gcl_grad_kernel<false>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, grad, start, el, grad_feat_pm);
+    return pdm::check_launch("group_concat_cl_grad");
+}

@@ -136,6 +136,8 @@ class _PointnetSAModuleBase(nn.Module):
             features = features.contiguous()
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            if CHANNELS_LAST_TRAINING and isinstance(grouper, pointnet2_utils.QueryAndGroup):
+                grouper.channels_last = True   # the grouped tensor is born NHWC (bf16 under autocast): no copies
             x = grouper(xyz, new_xyz, features)
             if CHANNELS_LAST_TRAINING:
                 x = x.contiguous(memory_format=torch.channels_last)

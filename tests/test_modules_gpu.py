@@ -236,3 +236,32 @@ def test_full_size_paths_agree(dev):
             sa.use_pack = False
         bd = neck(backbone({'batch_size': B, 'points': batches[1]}))
         assert torch.equal(bd['point_features'], ref[1][0]) and torch.equal(bd['spatial_features'], ref[1][1])
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_query_and_group_channels_last(dev, bf16):
+    """The training path's grouped tensor born in channels-last memory (bf16 under autocast) equals the reference-layout
+    tensor (cast to bf16 by round-to-nearest-even) bit for bit, and its gradient equals the reference-layout gradient."""
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    cl = synthetic.lidar_like_clouds(2, 2048, 3)
+    xyz = torch.from_numpy(np.ascontiguousarray(cl[:, :, :3])).to(dev)
+    new_xyz = xyz[:, :300].contiguous()
+    feats = torch.randn(2, 37, 2048, device=dev)
+    f1 = feats.clone().requires_grad_(True)
+    f2 = feats.clone().requires_grad_(True)
+    ref_mod = pu.QueryAndGroup(0.9, 16)
+    cl_mod = pu.QueryAndGroup(0.9, 16)
+    cl_mod.channels_last = True
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16):
+        want = ref_mod(xyz, new_xyz, f1)
+        got = cl_mod(xyz, new_xyz, f2)
+    assert got.shape == want.shape == (2, 40, 300, 16)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert got.dtype == (torch.bfloat16 if bf16 else torch.float32)
+    assert torch.equal(got.float(), want.to(got.dtype).float())
+    go = torch.randn_like(want)
+    want.backward(go)
+    got.backward(go.to(got.dtype).contiguous(memory_format=torch.channels_last))
+    tol = 2e-2 if bf16 else 1e-5
+    torch.testing.assert_close(f2.grad, f1.grad, rtol=tol, atol=tol)
