@@ -228,7 +228,10 @@ def train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, dev
             if sampled is not None:
                 bd['sampled_xyz'] = sampled
             bd = self.m["neck"](self.m["backbone"](bd))
-            return bd['point_features'].float().square().mean() + bd['spatial_features'].float().square().mean()
+            sf = bd['spatial_features']
+            if not sf.is_contiguous() and sf.permute(0, 2, 3, 1).is_contiguous():
+                sf = sf.permute(0, 2, 3, 1)   # the neck's grid is channels-last storage: same mean, contiguous kernels
+            return bd['point_features'].float().square().mean() + sf.float().square().mean()
 
     stepper = Step(model)
     if world > 1:
