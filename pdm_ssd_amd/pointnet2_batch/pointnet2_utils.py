@@ -331,6 +331,7 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.fused = fused
+        self.channels_last = False   # True: the result is stored (B, M, ns, 3+C), bf16 under autocast (training path)
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
         """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) -> (B, 3+C, npoint, nsample)."""
@@ -338,7 +339,7 @@ class QueryAndGroup(nn.Module):
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         if self.fused and self.use_xyz and xyz.is_contiguous() and new_xyz.is_contiguous() and (
                 features is None or features.is_contiguous()):
-            if getattr(self, 'channels_last', False):   # set by the SA module on its training path
+            if self.channels_last:   # set by the SA module on its training path
                 bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
                 return _FusedQueryAndGroupCL.apply(self.radius, self.nsample, xyz, new_xyz, features, bf16)
             return _FusedQueryAndGroup.apply(self.radius, self.nsample, xyz, new_xyz, features)
