@@ -11,7 +11,11 @@ configuration BASELINE.json's metric is quoted on: bs = 32 clouds of 16384 point
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU = pure data parallel over whole clouds (weak scaling, 32 clouds per rank, no data-path
-collective; only the timing barriers).  Rank 0 prints ONE JSON line.
+collective; only the timing barriers).  Rank 0 prints ONE JSON line.  Started as plain `python bench.py
+--gpus N` (no WORLD_SIZE in the environment) the process only acts as launcher: it starts N fresh child
+processes, one rank per GPU, before anything touches the GPU (launch_ranks below), relays rank 0's line and
+exits with the worst child code — the reference's equivalent is torch.distributed.launch feeding
+tools/train.py:74-76 / pcdet/utils/common_utils.py:189-204.
 """
 import argparse
 import json
@@ -294,6 +298,62 @@ def train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, dev
         dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------- launcher
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N child processes of this same script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (one process per GPU, rendezvous on 127.0.0.1),
+    wait for them and return the worst exit code.  The parent never initialises the GPU and never execs: the
+    children are ordinary fresh processes.  Rank 0's stdout is inherited, so its JSON line is this command's line;
+    the other ranks' stdout goes to stderr.  If a rank dies, the others are terminated (by pid)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                print(f"[bench] rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def rendezvous_only(args):
+    """--rendezvous-only: the launch + timing protocol of the benchmark without a kernel (gloo when there is no GPU):
+    process group from the environment, barrier, MAX-over-ranks, ONE line from rank 0.  Used by tests/test_dp_gloo.py
+    to drive `python bench.py --gpus 2` on a CPU-only box, and as a launch diagnostic on a GPU node."""
+    rank, world, local_rank = dist_utils.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus N` or torchrun"
+    dist_utils.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    dist_utils.barrier()
+    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "rendezvous only (no kernels)", "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "backend": dist.get_backend() if dist.is_initialized() else None}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------- main
 
 def main():
@@ -317,10 +377,23 @@ def main():
                          "DistributedDataParallel gradient all-reduce over RCCL when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch + barrier + max-over-ranks protocol only, no kernels (launch diagnostic / CPU test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher BEFORE any torch.cuda / HIP call in this process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.rendezvous_only:
+        return rendezvous_only(args)
+
+    if not torch.cuda.is_available():
+        sys.exit(f"[bench] rank {os.environ.get('RANK', '0')}: no GPU visible (torch.cuda.is_available() is False); "
+                 "the hot path has no CPU fallback")
     rank, world, local_rank = dist_utils.init_from_env(backend="nccl")  # 'nccl' is RCCL on ROCm
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus {args.gpus}` "
+                 f"(self-launching) or torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _native.lib()  # fail loudly now if the HIP library is missing

@@ -62,3 +62,38 @@ def test_two_rank_gloo_data_parallel():
     mean_grad = (res[0][5] + res[1][5]) / 2
     for r in res:
         np.testing.assert_allclose(r[6], mean_grad, rtol=1e-6)
+
+
+def _run_bench(*argv, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_self_launches_ranks_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two ranks itself (one process per GPU, as
+    tools/train.py:74-76 / common_utils.py:189-204 expect them), they rendezvous on 127.0.0.1, run the barrier +
+    MAX-over-ranks protocol and rank 0 prints exactly one JSON line."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "3", "--rendezvous-only")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["backend"] == "gloo"
+    # rank r sleeps (r + 1) ms per step: the MAX over ranks is the slower rank's time
+    assert line["ms_per_step"] >= 2.0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour of the launcher")
+def test_bench_launcher_relays_failure_without_gpu():
+    """Without a GPU every child stops at the 'no GPU' check (the hot path has no CPU fallback); the launcher must
+    come back with a non-zero code instead of an AssertionError or a hang."""
+    r = _run_bench("--gpus", "2", "--steps", "1")
+    assert r.returncode != 0
+    assert "no GPU visible" in r.stderr and "Traceback" not in r.stderr
+    r1 = _run_bench("--steps", "1")
+    assert r1.returncode != 0 and "no GPU visible" in r1.stderr
