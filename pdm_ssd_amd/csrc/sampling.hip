@@ -376,7 +376,25 @@ struct FpsSeg {
 };
 #define FPS_SEG_PICK(F, q) ((q) == 0 ? seg.F[0] : (q) == 1 ? seg.F[1] : (q) == 2 ? seg.F[2] : seg.F[3])
 
-template <int BLOCK, int PPT, bool MULTI>
+#if defined(FPS_DIAG) && FPS_DIAG == 4
+// Phase-timing build (tools/diag/fps_phase.py): s_memtime stamps of workgroup 0 around the phases of an iteration,
+// summed separately for waves that ran a distance pass in that iteration (row 1) and waves that skipped (row 0).
+// [row][0..6] = bound+ballot, passes, record write, barrier wait, record read (LDS), decode, whole iteration;
+// [row][7] = count.  Results stay exact; the stamps cost ~10 % (each waits for outstanding LDS/scalar loads).
+__device__ unsigned long long g_fps_phase[2][8];
+#define FPS_STAMP(t) const unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f)
+#else
+#define FPS_STAMP(t)
+#endif
+
+// SUB > 1: a lane's PPT points are SUB separate groups of GP = PPT / SUB points; group s of wave w is run
+// (s * NW + w) * 64 * GP .. of the sorted order, so a wave owns SUB compact boxes that are NOT neighbours, each with
+// its own cached (max, arg-max) record; the skip test runs per group (lane s tests group s, all in one pass of
+// instructions) and a sample near one box costs a pass over GP points per lane instead of PPT.  What an iteration
+// costs is, per SIMD, (waves on it) x (record decode + skip test + record write, ~55 instructions whatever the
+// wave holds) + the passes that do run; fewer, fatter waves with finer groups cut both terms
+// (profiles/r02_fps_phase_table.md).
+template <int BLOCK, int PPT, int SUB, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, int G,
                                                           const float *__restrict__ xyz_arg,
                                                           float *__restrict__ temp_arg,
@@ -394,8 +412,11 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     const int jb0 = segd ? FPS_SEG_PICK(j0, job) : 1;
     const int jb1 = segd ? FPS_SEG_PICK(j1, job) : m;
     constexpr int NW = BLOCK / 64, HPT = 4096 / BLOCK;  // waves, histogram bins per thread
+    constexpr int GP = PPT / SUB, NG = NW * SUB;         // points per lane and group, groups per workgroup
+    static_assert(GP >= 2 && GP * SUB == PPT && (GP & (GP - 1)) == 0 && NG <= 64, "fps_pruned_kernel: group shape");
     using vec = float __attribute__((ext_vector_type(PPT)));
-    __shared__ FpsRecR rec[2][16];
+    __shared__ float4 recA[2][NG];   // {max, x, y, z} of a group's arg-max
+    __shared__ int2 recB[2][NG];     // {iteration it was written in, handle}
     __shared__ int hist[4096];
     __shared__ unsigned short order[BLOCK * PPT];  // sorted point indices, then (slot, thread) -> index
     __shared__ float red[6][NW];
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     int kk[PPT], rk[PPT];
 #pragma unroll
     for (int v = 0; v < PPT; ++v) {
-        const int sp = (wave * 64 + lane) * PPT + v;
+        const int sp = (((v / GP) * NW + wave) * 64 + lane) * GP + (v % GP);
         if (sp < n) {
             const int k = order[sp];
             kk[v] = k;
@@ -536,14 +557,14 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
         }
     }
 #pragma unroll
-    for (int k2 = 2; k2 <= PPT; k2 <<= 1)
+    for (int k2 = 2; k2 <= GP; k2 <<= 1)   // rank order inside each group of GP slots
 #pragma unroll
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1)
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 const int l = i ^ j2;
                 if (l > i) {
-                    const bool up = (i & k2) == 0;
+                    const bool up = ((i & (GP - 1)) & k2) == 0;
                     const bool sw = (rk[i] > rk[l]) == up;
                     const int tr = rk[i], tk = kk[i];
                     const float tx = px[i], ty = py[i], tz = pz[i], tt = tmp[i];
@@ -559,27 +580,30 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
 #pragma unroll
     for (int v = 0; v < PPT; ++v) order[v * BLOCK + p] = (unsigned short)kk[v];
 
-    // ---- box of this wave's points (wave-uniform)
-    float blo[3], bhi[3];
-    {
+    // ---- boxes of the groups: lane g < NG of the OWNING wave keeps the box of group g = s * NW + wave
+    float bl0 = 0.0f, bl1 = 0.0f, bl2 = 0.0f, bh0 = 0.0f, bh1 = 0.0f, bh2 = 0.0f;
+#pragma unroll
+    for (int s_ = 0; s_ < SUB; ++s_) {
         float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int v = 0; v < PPT; ++v)
+        for (int v = s_ * GP; v < (s_ + 1) * GP; ++v)
             if (kk[v] != 0xFFFF) {
                 l[0] = fminf(l[0], px[v]); h[0] = fmaxf(h[0], px[v]);
                 l[1] = fminf(l[1], py[v]); h[1] = fmaxf(h[1], py[v]);
                 l[2] = fminf(l[2], pz[v]); h[2] = fmaxf(h[2], pz[v]);
             }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3; ++a)
             for (int off = 32; off >= 1; off >>= 1) {
                 l[a] = fminf(l[a], __shfl_xor(l[a], off, 64));
                 h[a] = fmaxf(h[a], __shfl_xor(h[a], off, 64));
             }
-            blo[a] = readlane_f(l[a], 0);
-            bhi[a] = readlane_f(h[a], 0);
-        }
+        if (lane == s_ * NW + wave) { bl0 = l[0]; bl1 = l[1]; bl2 = l[2]; bh0 = h[0]; bh1 = h[1]; bh2 = h[2]; }
     }
+    // group records: written by the lane that holds a group's new arg-max in the iteration the group was passed over,
+    // tagged with that iteration; every wave keeps a register copy of all NG records (lane g <-> group g) and takes a
+    // record from LDS only when its tag is the current iteration, so unchanged groups cost nothing to republish
+    if (p < 2 * NG) reinterpret_cast<int2 *>(recB)[p] = make_int2(-1, 0);
     __syncthreads();
 
     // ---- iterations
@@ -588,87 +612,141 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     cur.x = xyz0[(size_t)cur.k * 3]; cur.y = xyz0[(size_t)cur.k * 3 + 1]; cur.z = xyz0[(size_t)cur.k * 3 + 2];
     if (p == 0 && grp == 0 && jb0 <= 1) idxs[0] = 0;
     __shared__ float fin[8];
-    // cached wave result (uniform)
-    bool have = false;
-    float wmax = -1.0f;
-    FpsPick mine;
-    mine.k = 0; mine.x = mine.y = mine.z = 0.0f;
-    int mrank = 0x7FFFFFFF;
+    const bool own = lane < NG && (lane % NW) == wave;   // this lane stands for one of this wave's groups
+    const unsigned long long ownmask = __ballot(own);
+    bool first = true;
+    float rv = -3.0f, rx = 0.0f, ry = 0.0f, rz = 0.0f;   // register copy of record `lane` (lanes >= NG never win)
+    int rh = 0;                                           // its handle: index into order[] (slot * BLOCK + thread)
+    int pend_j = -1, pend_k = 0;                          // sample whose index is still to be stored
     for (int j = jb0; j < jb1; ++j) {
-        // lower bound of every computed distance between cur and a point of this wave's box
-        const float gx = fmaxf(0.0f, fmaxf(blo[0] - cur.x, cur.x - bhi[0]));
-        const float gy = fmaxf(0.0f, fmaxf(blo[1] - cur.y, cur.y - bhi[1]));
-        const float gz = fmaxf(0.0f, fmaxf(blo[2] - cur.z, cur.z - bhi[2]));
+        FPS_STAMP(t0);
+        // lower bound of every computed distance between cur and a point of the group's box (lane g: group g)
+        const float gx = fmaxf(0.0f, fmaxf(bl0 - cur.x, cur.x - bh0));
+        const float gy = fmaxf(0.0f, fmaxf(bl1 - cur.y, cur.y - bh1));
+        const float gz = fmaxf(0.0f, fmaxf(bl2 - cur.z, cur.z - bh2));
         const float lb = (gx * gx + gy * gy + gz * gz) * 0.99999618530273438f;  // 1 - 2^-18
 #if defined(FPS_DIAG) && FPS_DIAG == 2
-        if (!have) {  // timing-only build: distance pass in the first iteration only (results are wrong)
+        const unsigned long long need = first ? ownmask : 0ull;  // timing-only build: passes in the first iteration only
 #else
-        if (!have || !(lb >= wmax)) {  // wave-uniform; also taken when anything is NaN
+        // a group is passed over unless the bound says nothing in it can change; also when anything is NaN
+        const unsigned long long need = first ? ownmask : __ballot(own && !(lb >= rv));
 #endif
-            have = true;
-#if defined(FPS_DIAG) && FPS_DIAG == 3
-            if (lane == 0 && b == 0) atomicAdd(&temp_all[(size_t)gridDim.x * n - 1 - (j >> 8)], 1.0f);  // diag only
-#endif
-            float best = -1.0f;
-            int bestv = 0;
-            const v2f x1 = {cur.x, cur.x}, y1 = {cur.y, cur.y}, z1 = {cur.z, cur.z};
-#pragma unroll
-            for (int v = 0; v < PPT; v += 2) {
-                const v2f dx = v2f{px[v], px[v + 1]} - x1;
-                const v2f dy = v2f{py[v], py[v + 1]} - y1;
-                const v2f dz = v2f{pz[v], pz[v + 1]} - z1;
-                v2f d = dx * dx;
-                d = __builtin_elementwise_fma(dy, dy, d);
-                d = __builtin_elementwise_fma(dz, dz, d);
-                const float d0 = vmin(d.x, tmp[v]);
-                const float d1 = vmin(d.y, tmp[v + 1]);
-                tmp[v] = d0;
-                tmp[v + 1] = d1;
-                bestv = d0 > best ? v : bestv;
-                best = vmax(best, d0);
-                bestv = d1 > best ? v + 1 : bestv;
-                best = vmax(best, d1);
-            }
-            wmax = wave_max(best);
-            const unsigned long long cand = __ballot(best == wmax);
-            int wl = __ffsll((long long)cand) - 1;
-            if (__popcll(cand) > 1) {  // equal maxima in several lanes: the reference order decides
-                const int myk = order[bestv * BLOCK + p];
-                const int r = best == wmax ? rank_of(myk) : 0x7FFFFFFF;
-                const int rmin = wave_min_i(r);
-                wl = __ffsll((long long)__ballot(r == rmin)) - 1;
-            }
-            const int slot = __builtin_amdgcn_readlane(bestv, wl);
-            mine.k = order[slot * BLOCK + wave * 64 + wl];
-            mrank = rank_of(mine.k);
-            mine.x = readlane_f(px[slot], wl);
-            mine.y = readlane_f(py[slot], wl);
-            mine.z = readlane_f(pz[slot], wl);
-        }
-        // exchange: one record per wave, max value then min rank
+        first = false;
         const int buf = j & 1;
-        if (lane == 0) {
-            FpsRecR r;
-            r.v = wmax; r.k = mine.k; r.x = mine.x; r.y = mine.y; r.z = mine.z; r.rank = mrank;
-            rec[buf][wave] = r;
+        FPS_STAMP(t1);
+        const unsigned long long mine = need >> wave;   // bit s * NW <-> this wave's group s
+        if (mine != 0ull) {
+#pragma unroll
+        for (int s_ = 0; s_ < SUB; ++s_) {
+            if ((mine >> (s_ * NW)) & 1ull) {  // wave-uniform
+#if defined(FPS_DIAG) && FPS_DIAG == 3
+                if (lane == 0 && b == 0) atomicAdd(&temp_all[(size_t)gridDim.x * n - 1 - (j >> 8)], 1.0f);  // diag only
+#endif
+                // NC independent (max, first arg-max) chains over contiguous runs of the group's slots, merged with
+                // strict '>' in slot order: the chain of one compare + select + max per point is the latency of a pass
+                constexpr int NC = GP >= 4 ? 2 : 1, CL = GP / NC;
+                float cb[NC];
+                int cv[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { cb[c] = -1.0f; cv[c] = s_ * GP + c * CL; }
+                const v2f x1 = {cur.x, cur.x}, y1 = {cur.y, cur.y}, z1 = {cur.z, cur.z};
+#pragma unroll
+                for (int i = 0; i < CL; i += 2) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const int v = s_ * GP + c * CL + i;
+                        const v2f dx = v2f{px[v], px[v + 1]} - x1;
+                        const v2f dy = v2f{py[v], py[v + 1]} - y1;
+                        const v2f dz = v2f{pz[v], pz[v + 1]} - z1;
+                        v2f d = dx * dx;
+                        d = __builtin_elementwise_fma(dy, dy, d);
+                        d = __builtin_elementwise_fma(dz, dz, d);
+                        const float d0 = vmin(d.x, tmp[v]);
+                        const float d1 = vmin(d.y, tmp[v + 1]);
+                        tmp[v] = d0;
+                        tmp[v + 1] = d1;
+                        cv[c] = d0 > cb[c] ? v : cv[c];
+                        cb[c] = vmax(cb[c], d0);
+                        cv[c] = d1 > cb[c] ? v + 1 : cv[c];
+                        cb[c] = vmax(cb[c], d1);
+                    }
+                }
+                float best = cb[0];
+                int bestv = cv[0];
+#pragma unroll
+                for (int c = 1; c < NC; ++c) {
+                    bestv = cb[c] > best ? cv[c] : bestv;
+                    best = vmax(best, cb[c]);
+                }
+                const float wmax = wave_max(best);
+                const unsigned long long cand = __ballot(best == wmax);
+                int wl = __ffsll((long long)cand) - 1;
+                if (__popcll(cand) > 1) {  // equal maxima in several lanes: the reference order decides
+                    const int myk = order[bestv * BLOCK + p];
+                    const int r = best == wmax ? rank_of(myk) : 0x7FFFFFFF;
+                    const int rmin = wave_min_i(r);
+                    wl = __ffsll((long long)__ballot(r == rmin)) - 1;
+                }
+                const int slot = __builtin_amdgcn_readlane(bestv, wl);
+                const float fx = px[slot], fy = py[slot], fz = pz[slot];   // wave-uniform register index
+                if (lane == wl) {
+                    recA[buf][s_ * NW + wave] = make_float4(best, fx, fy, fz);
+                    recB[buf][s_ * NW + wave] = make_int2(j, slot * BLOCK + p);
+                }
+            }
         }
+        }
+        FPS_STAMP(t2);
+        FPS_STAMP(t3);
         __syncthreads();
-        FpsRecR r = rec[buf][lane & 15];
-        if ((lane & 15) >= NW) r.v = -3.0f;  // fewer than 16 waves: unused record slots never win
-        const float gmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(row_max16(__builtin_bit_cast(int, r.v)), 0));
-        unsigned long long c2 = __ballot(r.v == gmax) & 0xFFFFull;
-        int w = __ffsll((long long)c2) - 1;
-        if (__popcll(c2) > 1) {
-            const int rr = r.v == gmax ? r.rank : 0x7FFFFFFF;
-            const int rmin = __builtin_amdgcn_readlane(row_min16_i(rr), 0);
-            w = __ffsll((long long)(__ballot(rr == rmin) & 0xFFFFull)) - 1;
+        FPS_STAMP(t4);
+        {
+            const float4 na = recA[buf][lane < NG ? lane : 0];
+            const int2 nb = recB[buf][lane < NG ? lane : 0];
+#if defined(FPS_DIAG) && FPS_DIAG == 4
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            if (lane < NG && nb.x == j) { rv = na.x; rx = na.y; ry = na.z; rz = na.w; rh = nb.y; }
         }
-        cur.k = __builtin_amdgcn_readlane(r.k, w) + k0;  // global index
-        cur.x = readlane_f(r.x, w);
-        cur.y = readlane_f(r.y, w);
-        cur.z = readlane_f(r.z, w);
+        FPS_STAMP(t5);
+        // the sample before this one: its index was requested from LDS an iteration ago
+        if (!MULTI && p == 0 && pend_j >= 0) idxs[pend_j] = pend_k;
+        float gmax;
+        unsigned long long c2;
+        int w;
+        if constexpr (NG <= 16) {   // (every row of 16 lanes would do; lanes >= NG hold -3)
+            gmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(row_max16(__builtin_bit_cast(int, rv)), 0));
+            c2 = __ballot(rv == gmax) & 0xFFFFull;
+        } else {
+            gmax = wave_max(rv);
+            c2 = __ballot(rv == gmax);
+        }
+        w = __ffsll((long long)c2) - 1;
+        if (__popcll(c2) > 1) {   // equal maxima in several groups: the reference order decides
+            const int rr = rv == gmax ? rank_of(order[rh]) : 0x7FFFFFFF;
+            const int rmin = wave_min_i(rr);
+            w = __ffsll((long long)__ballot(rr == rmin)) - 1;
+        }
+        cur.x = readlane_f(rx, w);
+        cur.y = readlane_f(ry, w);
+        cur.z = readlane_f(rz, w);
+        const int wh = __builtin_amdgcn_readlane(rh, w);
+        const int wk = order[wh];           // local index of the sample (LDS, uniform address)
+        if (!MULTI) { pend_j = j; pend_k = wk + k0; }
+        else cur.k = wk + k0;               // global index
+#if defined(FPS_DIAG) && FPS_DIAG == 4
+        {
+            FPS_STAMP(t6);
+            if (blockIdx.x == 0 && lane == 0 && j > jb0 + 8) {
+                unsigned long long *row = g_fps_phase[need ? 1 : 0];
+                atomicAdd(row + 0, t1 - t0); atomicAdd(row + 1, t2 - t1); atomicAdd(row + 2, t3 - t2);
+                atomicAdd(row + 3, t4 - t3); atomicAdd(row + 4, t5 - t4); atomicAdd(row + 5, t6 - t5);
+                atomicAdd(row + 6, t6 - t0); atomicAdd(row + 7, 1ull);
+            }
+        }
+#endif
         if (MULTI) {
-            const int crank = __builtin_amdgcn_readlane(r.rank, w);
+            const int crank = rank_of(wk);
             unsigned long long *slot = xch_all + ((size_t)b * 2 + (j & 1)) * (size_t)G * 6;
             if (wave == 0) {
                 if (lane < 6) {
@@ -708,8 +786,9 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
             cur.x = fin[1]; cur.y = fin[2]; cur.z = fin[3];
             __syncthreads();  // fin is rewritten next iteration
         }
-        if (p == 0 && grp == 0) idxs[j] = cur.k;
+        if (MULTI && p == 0 && grp == 0) idxs[j] = cur.k;
     }
+    if (!MULTI && p == 0 && pend_j >= 0) idxs[pend_j] = pend_k;
 
 #pragma unroll
     for (int v = 0; v < PPT; ++v) {
@@ -752,16 +831,34 @@ static int ref_block_threads(int n, int *logS) {
 
 using namespace pdm;
 
-// Tuning knob (not part of the reference-facing ABI) for 8192 < n <= 16384: 0 = pruned kernel, 1024 threads
-// x 16 points (default, fastest measured), 3 = pruned, 512 x 32; 1 = 512 x 32 and 2 = 1024 x 16 without pruning.
-// For 1024 < n <= 8192: 8 = one physical thread per reference thread (1024 x per) instead of the default 256 / 512
-// threads.  All give identical indices.
+// Tuning knob (not part of the reference-facing ABI).  8192 < n <= 16384: 0 = default (FPS_L1_DEFAULT below);
+// 1 = 512 x 32 and 2 = 1024 x 16 without pruning; pruned forms (threads x points per lane / groups per lane):
+// 3 = 512x32/1, 4 = 1024x16/1 (round 1's shape), 5 = 1024x16/2, 6 = 512x32/2, 7 = 512x32/4, 9 = 512x32/8, 10 = 1024x16/4.
+// 1024 <= n <= 8192: 8 = one physical thread per reference thread without pruning, 16 = round 1's register kernels
+// (256 / 512 threads, no pruning), 17 / 18 / 19 = pruned with 1 / 2 / 4 groups per lane.  All give identical indices.
 static int g_fps_variant = 0;
+#if defined(FPS_DIAG) && FPS_DIAG == 4
+extern "C" int pdm_fps_phase_read(unsigned long long *out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(pdm::g_fps_phase), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(pdm::g_fps_phase), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 extern "C" int pdm_tune_fps_variant(int v) { const int old = g_fps_variant; g_fps_variant = v; return old; }
 
 #define FPS_LAUNCH(BLOCK, PPT)                                                                  \
     hipLaunchKernelGGL((fps_reg_kernel<BLOCK, PPT>), dim3(b), dim3(BLOCK), 0, as_stream(stream), \
                        n, m, S, logS, points, temp, idx, rg)
+#define FPS_PRUNED(BLOCK, PPT, SUB)                                                                                  \
+    hipLaunchKernelGGL((fps_pruned_kernel<BLOCK, PPT, SUB, false>), dim3(b), dim3(BLOCK), 0, as_stream(stream), n, m, 1, \
+                       points, temp, idx, (unsigned long long *)nullptr, FpsSeg{})
+// the shape the 16384-point chunk runs in (single call, resumable jobs and cooperating workgroups alike)
+#define FPS_L1_BLOCK 1024
+#define FPS_L1_PPT 16
+#define FPS_L1_SUB 4
 
 extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, const float *points,
                                            float *temp, int *idx) {
@@ -773,6 +870,7 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     const int S = ref_block_threads(n, &logS);
     const int per = (n + S - 1) / S;  // points per reference thread
     const FpsRagged rg{nullptr, nullptr};
+    const int small = g_fps_variant >= 16 ? g_fps_variant - 16 : -1;   // 1024 <= n <= 8192 forms
     if (S <= 64) {
         FPS_LAUNCH(64, 2);
     } else if (S <= 256) {
@@ -782,18 +880,40 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
     } else if (per <= 1) {
         // (S = 1024 reference threads played by 256 physical ones: measured 12-15 % faster than 1024 x per for these
         //  sizes, and a quarter of the CU's registers instead of all of them; variant 8 = the 1024-thread form)
-        if (g_fps_variant == 8) FPS_LAUNCH(1024, 1); else FPS_LAUNCH(256, 4);
+        if (g_fps_variant == 8) FPS_LAUNCH(1024, 1);
+        else if (small == 1) FPS_PRUNED(256, 4, 1);
+        else if (small == 2) FPS_PRUNED(256, 4, 2);
+        else FPS_LAUNCH(256, 4);
     } else if (per <= 2) {
-        if (g_fps_variant == 8) FPS_LAUNCH(1024, 2); else FPS_LAUNCH(256, 8);
+        if (g_fps_variant == 8) FPS_LAUNCH(1024, 2);
+        else if (small == 1) FPS_PRUNED(256, 8, 1);
+        else if (small == 2) FPS_PRUNED(256, 8, 2);
+        else if (small == 3) FPS_PRUNED(256, 8, 4);
+        else FPS_LAUNCH(256, 8);
     } else if (per <= 4) {
-        if (g_fps_variant == 8) FPS_LAUNCH(1024, 4); else FPS_LAUNCH(256, 16);
+        if (g_fps_variant == 8) FPS_LAUNCH(1024, 4);
+        else if (small == 1) FPS_PRUNED(256, 16, 1);
+        else if (small == 2) FPS_PRUNED(256, 16, 2);
+        else if (small == 3) FPS_PRUNED(256, 16, 4);
+        else FPS_LAUNCH(256, 16);
     } else if (per <= 8) {
-        if (g_fps_variant == 8) FPS_LAUNCH(1024, 8); else FPS_LAUNCH(512, 16);   // 8192 -> 2048: 2.19 -> 1.73 ms
+        if (g_fps_variant == 8) FPS_LAUNCH(1024, 8);
+        else if (small == 1) FPS_PRUNED(512, 16, 1);
+        else if (small == 2) FPS_PRUNED(512, 16, 2);
+        else if (small == 3) FPS_PRUNED(512, 16, 4);
+        else if (small == 0) FPS_LAUNCH(512, 16);   // 8192 -> 2048: 2.19 -> 1.73 ms
+        else FPS_PRUNED(512, 16, 4);                // 1.73 -> 1.40 ms (lidar-like clouds 1.52)
     } else if (per <= 16) {
         if (g_fps_variant == 1) FPS_LAUNCH(512, 32);
         else if (g_fps_variant == 2) FPS_LAUNCH(1024, 16);
-        else if (g_fps_variant == 3) hipLaunchKernelGGL((fps_pruned_kernel<512, 32, false>), dim3(b), dim3(512), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr, FpsSeg{});
-        else hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, as_stream(stream), n, m, 1, points, temp, idx, (unsigned long long *)nullptr, FpsSeg{});
+        else if (g_fps_variant == 3) FPS_PRUNED(512, 32, 1);
+        else if (g_fps_variant == 4) FPS_PRUNED(1024, 16, 1);
+        else if (g_fps_variant == 5) FPS_PRUNED(1024, 16, 2);
+        else if (g_fps_variant == 6) FPS_PRUNED(512, 32, 2);
+        else if (g_fps_variant == 7) FPS_PRUNED(512, 32, 4);
+        else if (g_fps_variant == 9) FPS_PRUNED(512, 32, 8);
+        else if (g_fps_variant == 10) FPS_PRUNED(1024, 16, 4);
+        else FPS_PRUNED(FPS_L1_BLOCK, FPS_L1_PPT, FPS_L1_SUB);
     } else {
         hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, as_stream(stream), n,
                            m, S, logS, points, temp, idx, rg);
@@ -849,10 +969,10 @@ extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, 
         }
     }
     if (G == 1)
-        hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, false>), dim3(b * njobs), dim3(1024), 0, as_stream(stream), n, m, 1,
+        hipLaunchKernelGGL((fps_pruned_kernel<FPS_L1_BLOCK, FPS_L1_PPT, FPS_L1_SUB, false>), dim3(b * njobs), dim3(FPS_L1_BLOCK), 0, as_stream(stream), n, m, 1,
                            (const float *)nullptr, (float *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, seg);
     else
-        hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, true>), dim3(b * njobs * G), dim3(1024), 0, as_stream(stream), n, m, G,
+        hipLaunchKernelGGL((fps_pruned_kernel<FPS_L1_BLOCK, FPS_L1_PPT, FPS_L1_SUB, true>), dim3(b * njobs * G), dim3(FPS_L1_BLOCK), 0, as_stream(stream), n, m, G,
                            (const float *)nullptr, (float *)nullptr, (int *)nullptr, (unsigned long long *)nullptr, seg);
     return check_launch("furthest_point_sampling_jobs");
 }
@@ -909,7 +1029,7 @@ extern "C" int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m,
     const int chunk = 256 / G;
     for (int b0 = 0; b0 < b; b0 += chunk) {
         const int nb = b - b0 < chunk ? b - b0 : chunk;
-        hipLaunchKernelGGL((fps_pruned_kernel<1024, 16, true>), dim3(nb * G), dim3(1024), 0, as_stream(stream), n, m, G,
+        hipLaunchKernelGGL((fps_pruned_kernel<FPS_L1_BLOCK, FPS_L1_PPT, FPS_L1_SUB, true>), dim3(nb * G), dim3(FPS_L1_BLOCK), 0, as_stream(stream), n, m, G,
                            points + (size_t)b0 * n * 3, temp + (size_t)b0 * n, idx + (size_t)b0 * m,
                            reinterpret_cast<unsigned long long *>(workspace) + (size_t)b0 * 2 * G * 6, FpsSeg{});
         int rc = check_launch("furthest_point_sampling_ws");
