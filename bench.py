@@ -411,7 +411,8 @@ def main():
         return bd['spatial_features'], bd['point_features']
 
     fps_wgs = (args.pipeline_depth - 1) * B * ((N + 16383) // 16384)
-    if args.pipeline_depth >= 3 and not (1024 < N <= 131072 and (N <= 16384 or fps_wgs <= 256)):
+    if args.pipeline_depth >= 3 and not (1024 < N <= 131072 and
+                                         (N <= 16384 or fps_wgs <= _native.lib().pdm_fps_max_coresident_workgroups())):
         print(f"[bench] resumable FPS segments need 1024 < points <= 131072 and co-resident workgroups; "
               f"{N} points x {B} clouds -> --pipeline-depth 2", file=sys.stderr)
         args.pipeline_depth = 2
@@ -472,6 +473,8 @@ def main():
         elapsed = time.perf_counter() - t0
 
         elapsed = dist_utils.max_over_ranks(elapsed, device)
+        if not args.serial:
+            pipe.check_sampling()   # N > 16384: no cooperating FPS workgroup gave up waiting for a peer
 
         # per-kernel pass (eager, instrumented with HIP events on the launch stream); rank 0 only
         ops = []

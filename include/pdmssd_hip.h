@@ -93,17 +93,25 @@ int pdm_furthest_point_sampling(void *stream, int b, int n, int m, const float *
 
 /* Same operator for large clouds (n > 16384): the cloud is split over ceil(n/16384) cooperating workgroups
  * that keep their points in registers and exchange one record per iteration through `workspace`
- * (pdm_furthest_point_sampling_ws_bytes(b, n) bytes, 8-byte aligned, contents irrelevant).  Identical idx/temp. */
+ * (pdm_furthest_point_sampling_ws_bytes(b, n) bytes, 8-byte aligned, contents irrelevant).  Identical idx/temp.
+ * The workgroups of a cloud wait for each other, so a launch holds at most pdm_fps_max_coresident_workgroups()
+ * of them (compute units x resident workgroups per unit of the CURRENT device, from the runtime); the call cuts the
+ * batch accordingly and takes the single-workgroup kernel where not even one cloud fits.  Every wait is bounded: a
+ * workgroup that gives up raises a status word in the workspace, read back (with a stream synchronisation) by
+ * pdm_furthest_point_sampling_status: *flag = 1 means the indices of that call must not be used. */
 size_t pdm_furthest_point_sampling_ws_bytes(int b, int n);
+int pdm_fps_max_coresident_workgroups(void);
 int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m, const float *points, float *temp,
                                    int *idx, void *workspace, size_t workspace_bytes);
+int pdm_furthest_point_sampling_status(void *stream, int b, int n, const void *workspace, int *flag);
 
 /* The same operator as resumable segments (no reference counterpart; same indices): job q computes samples
  * [j0[q], j1[q]) of its own batch of b clouds, continuing from the state an earlier segment left in temp[q] (running
  * min-distances, 1e10 everywhere before the first segment) and idx[q] (samples [0, j0)).  The 1..4 jobs of a call
  * belong to different batches and run side by side in one launch; host arrays of device pointers.  1024 < n <= 16384,
  * or 16384 < n <= 131072 with workspace[q] = pdm_furthest_point_sampling_ws_bytes(b, n) bytes per job (8-byte aligned;
- * the cooperating workgroups must all be resident: njobs * b * ceil(n/16384) <= 256); workspace may be null otherwise. */
+ * the cooperating workgroups must all be resident: njobs * b * ceil(n/16384) <= pdm_fps_max_coresident_workgroups();
+ * status per job workspace as above); workspace may be null otherwise. */
 int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, int n, int m, const float *const *points,
                                      float *const *temp, int *const *idx, const int *j0, const int *j1,
                                      void *const *workspace, size_t workspace_bytes);

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "pdm_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp],
     "pdm_furthest_point_sampling_ws": [_i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_furthest_point_sampling_status": [_i, _i, _vp, _vp],
     "pdm_furthest_point_sampling_jobs": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_topk_sampling": [_i, _i, _i, _vp, _vp],
     "pdm_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp],
@@ -80,6 +81,7 @@ _SIGNATURES = {
 }
 EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_bytes",
            "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes",
+           "pdm_fps_max_coresident_workgroups",
            "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
            "pdm_sa_pack_rows", "pdm_three_interpolate_grad_ws_bytes",
            "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes"] + list(_SIGNATURES)
@@ -105,6 +107,8 @@ def lib():
         l.pdm_ball_query_grid_workspace_bytes.argtypes = [_i, _i]
         l.pdm_furthest_point_sampling_ws_bytes.restype = ctypes.c_size_t
         l.pdm_furthest_point_sampling_ws_bytes.argtypes = [_i, _i]
+        l.pdm_fps_max_coresident_workgroups.restype = _i
+        l.pdm_fps_max_coresident_workgroups.argtypes = []
         l.pdm_gather_bev_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_gather_bev_workspace_bytes.argtypes = [_i] * 6
         l.pdm_three_nn_grid_workspace_bytes.restype = ctypes.c_size_t
@@ -139,6 +143,48 @@ def call(name, stream, *args):
     if rc != 0:
         msg = l.pdm_last_error().decode("utf-8", "replace")
         raise NativeLibraryError(f"{name} failed with code {rc}: {msg}")
+
+
+# Cooperating-workgroup FPS calls (n > 16384) whose status word has not been read yet: (workspace, b, n, event).
+# The word is read without stalling the caller: when a later call finds the event complete, or in fps_check().
+_fps_pending = []
+
+
+def fps_watch(ws, b, n):
+    """Remember a cooperating-workgroup FPS call for a deferred status check (not during graph capture: a captured
+    launch is checked by whoever replays the graph, with fps_check_workspace)."""
+    import torch
+    if torch.cuda.is_current_stream_capturing():
+        return
+    fps_check(wait=False)
+    ev = torch.cuda.Event()
+    ev.record()
+    _fps_pending.append((ws, b, n, ev))
+
+
+def fps_check_workspace(ws, b, n):
+    """Synchronise and raise if the cooperating-workgroup FPS that used `ws` gave up waiting for a peer workgroup."""
+    import torch
+    flag = ctypes.c_int(0)
+    call("pdm_furthest_point_sampling_status", torch.cuda.current_stream(ws.device).cuda_stream, b, n, ws.data_ptr(),
+         ctypes.cast(ctypes.pointer(flag), ctypes.c_void_p))
+    if flag.value:
+        raise NativeLibraryError(
+            f"furthest_point_sampling ({b} clouds x {n} points): a workgroup gave up waiting for its peers — they were "
+            "not co-resident (device shared, partitioned or CU-masked); the sample indices of that call are invalid")
+
+
+def fps_check(wait=True):
+    """Check the status words of earlier cooperating-workgroup FPS calls: all of them (synchronising) or, with
+    wait=False, those that have finished."""
+    keep = []
+    for item in _fps_pending:
+        ws, b, n, ev = item
+        if wait or ev.query():
+            fps_check_workspace(ws, b, n)
+        else:
+            keep.append(item)
+    _fps_pending[:] = keep
 
 
 def copy_many(dst, src, live=None):

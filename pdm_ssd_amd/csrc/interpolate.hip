@@ -279,6 +279,16 @@ int csr_scatter_grad_launch(void *stream, const char *who, int b, int c, int row
     unsigned short *ej = reinterpret_cast<unsigned short *>(p);
     p += ((size_t)b * ne * sizeof(unsigned short) + 15) / 16 * 16;
     float *ew = reinterpret_cast<float *>(p);
+    if ((size_t)m * sizeof(int) + 1024 > 64 * 1024) {   // dynamic + static LDS above the default 64 KB (m near 16384)
+        static bool granted_build = false;
+        if (!granted_build) {
+            // (the kernel also holds a small static block: dynamic + static must stay within the 160 KB of a CU)
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_csr_build_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "%s: cannot obtain %zu bytes of LDS", who, (size_t)m * sizeof(int));
+            granted_build = true;
+        }
+    }
     hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(TIC_THREADS), (size_t)m * sizeof(int), as_stream(stream), ne, per, m,
                        idx, weight, start, ej, ew);
     int rc = check_launch(who);

@@ -186,6 +186,26 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int n, int col_blocks, con
     if (lane == 0) *num_out = kept;
 }
 
+// more than 16384 boxes: the same walk with the `removed` words in LDS (col_blocks <= 16384 words = 128 KB)
+__global__ __launch_bounds__(64) void nms_scan_lds_kernel(int n, int col_blocks, const unsigned long long *__restrict__ mask,
+                                                          long long *__restrict__ keep, int *__restrict__ num_out) {
+    extern __shared__ unsigned long long removed[];
+    const int lane = threadIdx.x;
+    for (int cb = lane; cb < col_blocks; cb += 64) removed[cb] = 0ull;
+    __syncthreads();
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nblock = i >> 6, inblock = i & 63;
+        if ((removed[nblock] >> inblock) & 1ull) continue;   // wave-uniform (same address in every lane)
+        if (lane == 0) keep[kept] = i;
+        ++kept;
+        const unsigned long long *row = mask + (size_t)i * col_blocks;
+        for (int cb = nblock + lane; cb < col_blocks; cb += 64) removed[cb] |= row[cb];
+        __syncthreads();   // one wave: orders the LDS writes before the next box's read
+    }
+    if (lane == 0) *num_out = kept;
+}
+
 }  // namespace pdm
 
 using namespace pdm;
@@ -222,10 +242,11 @@ extern "C" size_t pdm_nms_workspace_bytes(int n) {
 }
 
 // boxes (n, 7) sorted by descending score; keep (n) int64 receives the kept positions in order, *num_out (device int)
-// their count.  normal != 0: axis-aligned footprints (nms_normal_gpu).  n <= 16384.
+// their count.  normal != 0: axis-aligned footprints (nms_normal_gpu).  Any n the n x n/64 mask workspace allows
+// (n <= 1048576; beyond 16384 boxes the suppression walk keeps its bitmap in LDS instead of registers).
 extern "C" int pdm_nms(void *stream, int n, const float *boxes, float thresh, int normal, void *workspace,
                        size_t workspace_bytes, long long *keep, int *num_out) {
-    PDM_REQUIRE(n >= 0 && n <= 16384, PDM_E_TOOLARGE, "nms: n=%d (at most 16384 boxes)", n);
+    PDM_REQUIRE(n >= 0 && n <= 16384 * 64, PDM_E_TOOLARGE, "nms: n=%d (at most 1048576 boxes)", n);
     PDM_REQUIRE(num_out, PDM_E_BADARG, "nms: null pointer");
     if (n == 0) {
         const hipError_t e = hipMemsetAsync(num_out, 0, sizeof(int), as_stream(stream));
@@ -239,7 +260,19 @@ extern "C" int pdm_nms(void *stream, int n, const float *boxes, float thresh, in
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, as_stream(stream), n, thresh, normal, boxes, mask);
     int rc = check_launch("nms(mask)");
     if (rc) return rc;
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, as_stream(stream), n, cb, mask, keep, num_out);
+    if (n <= 16384) {
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, as_stream(stream), n, cb, mask, keep, num_out);
+    } else {
+        const size_t lds = (size_t)cb * sizeof(unsigned long long);
+        static bool granted = false;
+        if (lds > 64 * 1024 - 256 && !granted) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_scan_lds_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "nms: cannot obtain %zu bytes of LDS", lds);
+            granted = true;
+        }
+        hipLaunchKernelGGL(nms_scan_lds_kernel, dim3(1), dim3(64), lds, as_stream(stream), n, cb, mask, keep, num_out);
+    }
     return check_launch("nms(scan)");
 }
 

