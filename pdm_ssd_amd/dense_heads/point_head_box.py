@@ -1,0 +1,115 @@
+"""Point-wise box head: the point half of PDM-SSD's hybrid head.
+
+Host-side restatement of /root/reference/pcdet/models/dense_heads/point_head_box.py:7-115 (PointHeadBox): same
+constructor (num_class, input_channels, model_cfg, predict_boxes_when_training), config keys (CLS_FC, REG_FC,
+TARGET_CONFIG.{GT_EXTRA_WIDTH, BOX_CODER, BOX_CODER_CONFIG}, LOSS_CONFIG), batch_dict keys in and out, state_dict keys
+(`cls_layers.*`, `box_layers.*`).  In eval mode without autograd the two MLPs run as per-row fp32 MFMA kernels
+(pdm_rows_mlp_fused, BatchNorm folded) on the point-major features the backbone hands over; training uses the torch
+layers.
+"""
+import torch
+
+from .. import fused
+from ..utils import box_coder_utils, box_utils
+from .point_head_template import PointHeadTemplate, _get
+
+
+class _AsConv:
+    """nn.Linear seen as the 1x1 convolution fused.PackedMLP folds and packs."""
+
+    def __init__(self, linear):
+        self.weight, self.bias = linear.weight, linear.bias
+        self.out_channels, self.in_channels = linear.out_features, linear.in_features
+
+
+def _fc_layers(seq):
+    """make_fc_layers' Sequential -> [(linear, bn | None)] (the last Linear has no BatchNorm / ReLU behind it)."""
+    mods, out, i = list(seq), [], 0
+    while i < len(mods):
+        lin = mods[i]
+        assert isinstance(lin, torch.nn.Linear)
+        if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.BatchNorm1d):
+            out.append((_AsConv(lin), mods[i + 1]))
+            i += 3
+        else:
+            out.append((_AsConv(lin), None))
+            i += 1
+    return out
+
+
+class PointHeadBox(PointHeadTemplate):
+    def __init__(self, num_class, input_channels, model_cfg, predict_boxes_when_training=False, **kwargs):
+        super().__init__(model_cfg=model_cfg, num_class=num_class)
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.cls_layers = self.make_fc_layers(fc_cfg=_get(self.model_cfg, 'CLS_FC'), input_channels=input_channels,
+                                              output_channels=num_class)
+        target_cfg = _get(self.model_cfg, 'TARGET_CONFIG')
+        self.box_coder = getattr(box_coder_utils, _get(target_cfg, 'BOX_CODER'))(**_get(target_cfg, 'BOX_CODER_CONFIG'))
+        self.box_layers = self.make_fc_layers(fc_cfg=_get(self.model_cfg, 'REG_FC'), input_channels=input_channels,
+                                              output_channels=self.box_coder.code_size)
+
+    def assign_targets(self, input_dict):
+        """point_coords (N1 + N2 + ..., 4) [bs_idx, x, y, z], gt_boxes (B, M, 8) -> point_cls_labels (0 background,
+        -1 ignored: inside the box enlarged by GT_EXTRA_WIDTH but not the box), point_box_labels (ref :31-59)."""
+        point_coords = input_dict['point_coords']
+        gt_boxes = input_dict['gt_boxes']
+        assert gt_boxes.dim() == 3, 'gt_boxes.shape=%s' % str(gt_boxes.shape)
+        assert point_coords.dim() == 2, 'points.shape=%s' % str(point_coords.shape)
+        batch_size = gt_boxes.shape[0]
+        extend_gt_boxes = box_utils.enlarge_box3d(
+            gt_boxes.view(-1, gt_boxes.shape[-1]), extra_width=_get(_get(self.model_cfg, 'TARGET_CONFIG'), 'GT_EXTRA_WIDTH')
+        ).view(batch_size, -1, gt_boxes.shape[-1])
+        return self.assign_stack_targets(points=point_coords, gt_boxes=gt_boxes, extend_gt_boxes=extend_gt_boxes,
+                                         set_ignore_flag=True, use_ball_constraint=False,
+                                         ret_part_labels=False, ret_box_labels=True)
+
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        point_loss_cls, tb_dict_1 = self.get_cls_layer_loss()
+        point_loss_box, tb_dict_2 = self.get_box_layer_loss()
+        tb_dict.update(tb_dict_1)
+        tb_dict.update(tb_dict_2)
+        return point_loss_cls + point_loss_box, tb_dict
+
+    def _layers(self, point_features):
+        """The two MLPs.  Inference: per-row fused kernels (BatchNorm folded) when the features are fp32 rows on the
+        GPU; otherwise the torch layers."""
+        infer = (not self.training and not torch.is_grad_enabled() and point_features.is_cuda
+                 and point_features.dtype == torch.float32 and point_features.dim() == 2
+                 and getattr(self, 'use_fused', True))
+        if infer:
+            pc = fused.cached_layers(self, 'cls', self.cls_layers, lambda: _fc_layers(self.cls_layers), point_features.device)
+            pb = fused.cached_layers(self, 'box', self.box_layers, lambda: _fc_layers(self.box_layers), point_features.device)
+            if pc is not None and pb is not None:
+                rows = point_features.contiguous().unsqueeze(0)
+                cls = torch.empty((1, rows.shape[1], self.num_class), dtype=torch.float32, device=rows.device)
+                box = torch.empty((1, rows.shape[1], self.box_coder.code_size), dtype=torch.float32, device=rows.device)
+                fused.rows_forward(pc, rows, cls, relu_last=False)
+                fused.rows_forward(pb, rows, box, relu_last=False)
+                return cls[0], box[0]
+        return self.cls_layers(point_features), self.box_layers(point_features)
+
+    def forward(self, batch_dict):
+        """point_features (N1 + N2 + ..., C), point_coords (.., 4) [, gt_boxes (B, M, 8)] -> point_cls_scores and, in
+        eval mode (or predict_boxes_when_training), batch_cls_preds / batch_box_preds / batch_index (ref :71-115)."""
+        if _get(self.model_cfg, 'USE_POINT_FEATURES_BEFORE_FUSION', False):
+            point_features = batch_dict['point_features_before_fusion']
+        else:
+            point_features = batch_dict['point_features']
+        point_cls_preds, point_box_preds = self._layers(point_features)
+        point_cls_preds_max, _ = point_cls_preds.max(dim=-1)
+        batch_dict['point_cls_scores'] = torch.sigmoid(point_cls_preds_max)
+        ret_dict = {'point_cls_preds': point_cls_preds, 'point_box_preds': point_box_preds}
+        if self.training:
+            targets_dict = self.assign_targets(batch_dict)
+            ret_dict['point_cls_labels'] = targets_dict['point_cls_labels']
+            ret_dict['point_box_labels'] = targets_dict['point_box_labels']
+        if not self.training or self.predict_boxes_when_training:
+            point_cls_preds, point_box_preds = self.generate_predicted_boxes(
+                points=batch_dict['point_coords'][:, 1:4], point_cls_preds=point_cls_preds, point_box_preds=point_box_preds)
+            batch_dict['batch_cls_preds'] = point_cls_preds
+            batch_dict['batch_box_preds'] = point_box_preds
+            batch_dict['batch_index'] = batch_dict['point_coords'][:, 0]
+            batch_dict['cls_preds_normalized'] = False
+        self.forward_ret_dict = ret_dict
+        return batch_dict
