@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of PDM-SSD's point-cloud hot path on MI355X.
 
-One "step" = one forward pass of the hot path over one batch of synthetic KITTI-range clouds that are
-already resident in HBM: PointNet2MSG backbone (4 SA-MSG + 4 FP layers: FPS, ball query, grouping,
-shared MLPs, three-NN interpolation) followed by the PDM neck (dilation, SH x Gaussian filling,
-scatter-add to the BEV grid, normalise, height compression).  fp32, inference (BN in eval mode), the
-configuration BASELINE.json's metric is quoted on: bs = 32 clouds of 16384 points per GPU.
+One "step" = one full PDM-SSD forward over one batch of synthetic KITTI-range clouds that are already
+resident in HBM: PointNet2MSG backbone (4 SA-MSG + 4 FP layers: FPS, ball query, grouping, shared MLPs,
+three-NN interpolation), the PDM neck (dilation, SH x Gaussian filling, scatter-add to the BEV grid,
+normalise, height compression) and the hybrid head (BEV heat-map head on the neck's grid + point box head
+on the backbone's point features, boxes decoded; NMS post-processing is not part of the step).  fp32,
+inference (BN in eval mode), the configuration BASELINE.json's metric is quoted on (configs[2]): bs = 32
+clouds of 16384 points per GPU.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -32,25 +34,28 @@ import torch
 import torch.distributed as dist
 
 from pdm_ssd_amd import _native, dist_utils, synthetic
-from pdm_ssd_amd.pdm_neck import PDMNeck
+from pdm_ssd_amd.detector_config import PDM_SSD_CFG, build_pdm_ssd
 from pdm_ssd_amd.pipeline import PipelinedHotPath
-from pdm_ssd_amd.pointnet2_backbone import POINTRCNN_MSG_CFG, PointNet2MSG
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
-VOXEL = [0.05, 0.05, 0.1]
-NECK_CFG = {'SOURCE_LAYER': 2, 'FEATURE_DIM': 128, 'DILATION': [7, 7, 1], 'SH_DEGREE': 2, 'BEV_STRIDE': 8,
-            'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 256, 'NORMALIZE': True}
+VALU_F32_PEAK_TFLOPS = 157.3  # same figure for the packed-fp32 vector pipe (256 CUs x 256 flop/clk x 2.4 GHz)
+NECK_CFG = PDM_SSD_CFG['MAP_TO_BEV']
+
+
+def build_detector(device, seed=0):
+    """PDM-SSD (pdm_ssd_amd/detector_config.py): PointNet2MSG -> PDM neck -> heat-map head + point box head."""
+    torch.manual_seed(seed)
+    model = build_pdm_ssd()
+    with torch.no_grad():  # non-degenerate SH / scale head so the neck's arithmetic is fully exercised
+        model.map_to_bev_module.coef.weight.normal_(0.0, 0.02)
+    return model.to(device).eval()
 
 
 def build_models(device, seed=0):
-    torch.manual_seed(seed)
-    backbone = PointNet2MSG(POINTRCNN_MSG_CFG, input_channels=4)
-    neck = PDMNeck(NECK_CFG, grid_size=[1408, 1600, 40], voxel_size=VOXEL,
-                   point_cloud_range=list(synthetic.KITTI_RANGE))
-    with torch.no_grad():  # non-degenerate SH / scale head so the neck's arithmetic is fully exercised
-        neck.coef.weight.normal_(0.0, 0.02)
-    return backbone.to(device).eval(), neck.to(device).eval()
+    """(backbone, neck) of the detector: the part of the step tests/test_modules_gpu.py checks at full size."""
+    model = build_detector(device, seed)
+    return model.backbone_3d, model.map_to_bev_module
 
 
 def make_batch(B, N, kind, seed0, device):
@@ -86,10 +91,15 @@ def algorithmic_bytes(name, a):
     if name == "pdm_three_interpolate":
         b, c, m, n = a[:4]
         return b * (24 * n + 4 * c * m + 4 * c * n)
-    if name == "pdm_scatter_bev":
+    if name in ("pdm_scatter_bev", "pdm_gather_bev"):
+        # SURVEY D4 "PDM scatter": point inputs + the grid written once (the atomic read-modify-write traffic
+        # 4*C*P*K of the scatter form is reported separately, see pdm_atomics_section)
         B, P, C, deg = a[:4]
         W, H, D = a[17:20]
         return B * (12 * P + 4 * C * P + 4 * (deg + 1) ** 2 * P + 4 * P) + 4 * B * C * D * H * W
+    if name == "pdm_bev_depthwise3x3":
+        B, H, W, C = a[:4]
+        return 8 * B * H * W * C
     if name == "pdm_bev_normalize":
         B, C, W, H, D = a[:5]
         return B * H * W * D * (8 * C + 4)
@@ -185,42 +195,83 @@ def reference_op_section(backbone, points, B, iters=5):
     ms = sum(o["ms_per_step"] for o in ops)
     mb = sum(o["alg_MB_per_step"] for o in ops)
     gp = [o for o in ops if o["op"] == "pdm_group_points"][0]
+    # ball query is not bandwidth-bound as the reference states it: N * M distance evaluations of 8 flop per call
+    # (SURVEY D3); the grid form visits only the cells a ball can reach, so its rate is quoted in reference-form
+    # evaluations per second ("effective") next to the exhaustive scan's real rate
+    evals = {"pdm_ball_query": 0.0, "pdm_ball_query_grid": 0.0}
+    for radius, ns, x, nx, f, xt in plan:
+        n, m = x.shape[1], nx.shape[1]
+        evals["pdm_ball_query_grid" if 2048 <= n <= 131072 else "pdm_ball_query"] += float(B) * n * m
+    bq = {}
+    for o in ops:
+        if o["op"] in evals and o["ms_per_step"] > 0:
+            rate = evals[o["op"]] / (o["ms_per_step"] * 1e-3)
+            bq[o["op"]] = {"reference_form_evals_per_step": evals[o["op"]], "Gevals_per_s": round(rate / 1e9, 1),
+                           "frac_of_valu_peak_at_8_flop_per_eval": round(rate * 8 / 1e12 / VALU_F32_PEAK_TFLOPS, 4),
+                           "kind": "effective (grid-pruned, same indices)" if o["op"].endswith("grid") else "executed (exhaustive scan)"}
     return {"ops": ops, "ms_per_step": round(ms, 4), "alg_MB_per_step": round(mb, 2),
             "GBps": round(mb / ms, 1), "frac_of_hbm_peak": round(mb / ms / HBM_PEAK_GBS, 4),
+            "ball_query_distance_evals": bq,
             "note": "8 ball_query + 16 group_points launches at bs=%d; target >= 0.60" % B}, gp
 
 
 # ----------------------------------------------------------------------------- CPU baseline
 
-def cpu_baseline(backbone, neck, N, kind, frames=2):
-    """Times the CPU statement of the same step (oracle operators + torch-CPU MLPs) on `frames` clouds."""
+def cpu_baseline(model, N, kind, frames=2, threads=None):
+    """Times the CPU statement of the same step on `frames` clouds: oracle C operators (OpenMP) for the backbone and
+    neck (oracle/cpu_backbone.py), the detector's own torch layers on the CPU for the hybrid head."""
     import copy
 
     from oracle import cpu_backbone, cpu_oracle
     cpu_oracle.build()
-    bb = copy.deepcopy(backbone).cpu().eval()
-    nk = copy.deepcopy(neck).cpu().eval()
+    m = copy.deepcopy(model).cpu().eval()
     gen = synthetic.uniform_clouds if kind == "uniform" else synthetic.lidar_like_clouds
     clouds = gen(frames, N, 4321)
-    threads = cpu_oracle.max_threads()
+    all_threads = cpu_oracle.max_threads()
+    threads = all_threads if threads is None else threads
+    cpu_oracle.set_threads(threads)
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
-    out = cpu_backbone.backbone_forward(bb, clouds)
-    cpu_backbone.neck_forward(nk, out['sa_xyz'], out['sa_features'])
+    with torch.no_grad():
+        out = cpu_backbone.backbone_forward(m.backbone_3d, clouds)
+        sf = cpu_backbone.neck_forward(m.map_to_bev_module, out['sa_xyz'], out['sa_features'])
+        m.dense_head({'spatial_features': torch.from_numpy(sf)})
+        coords = torch.from_numpy(synthetic.to_batch_points(clouds)[:, :4])
+        m.point_head({'batch_size': frames, 'point_features': torch.from_numpy(out['point_features']), 'point_coords': coords})
     dt = time.perf_counter() - t0
+    cpu_oracle.set_threads(all_threads)
+    torch.set_num_threads(all_threads)
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} clouds x {N} pts, same step (oracle C operators with OpenMP + torch-CPU MLPs), "
+            "sample": f"{frames} cloud(s) x {N} pts, same step (oracle C operators with OpenMP + torch-CPU layers), "
                       f"{dt:.1f} s wall; the reference itself has no CPU path for these operators"}
 
 
-def train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, device):
-    """Training step (BASELINE config 4): the autograd graph over the HIP operators (fused QueryAndGroup forward,
-    atomic scatter backward kernels), torch modules for the MLPs under bf16 autocast, coordinates and indices in
-    fp32; one gradient all-reduce per step (DDP, single bucket) when world > 1.  The loss is a stand-in (mean
-    square of both outputs): the reference's hybrid head is not part of the hot path."""
-    model = torch.nn.ModuleDict({"backbone": backbone, "neck": neck}).train()
+# ----------------------------------------------------------------------------- training step (configs[3])
+
+def synthetic_gt_boxes(B, M, seed, device):
+    """(B, M, 8) [x, y, z, dx, dy, dz, heading, class] KITTI-like boxes for the head's target assignment."""
+    rng = np.random.default_rng(seed)
+    sizes = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], dtype=np.float32)
+    cls = rng.integers(1, 4, (B, M))
+    gt = np.zeros((B, M, 8), dtype=np.float32)
+    gt[..., 0] = rng.uniform(5, 65, (B, M)); gt[..., 1] = rng.uniform(-35, 35, (B, M)); gt[..., 2] = rng.uniform(-1.6, -0.8, (B, M))
+    gt[..., 3:6] = sizes[cls - 1] * rng.uniform(0.9, 1.1, (B, M, 3))
+    gt[..., 6] = rng.uniform(-np.pi, np.pi, (B, M))
+    gt[..., 7] = cls
+    return torch.from_numpy(gt).to(device)
+
+
+def train_bench(args, model, points, B, N, rank, world, local_rank, device):
+    """Training step (BASELINE configs[3]): the detector in train mode — autograd graph over the HIP operators (fused
+    QueryAndGroup forward, inverted-index backward kernels, PDM scatter + its gather-form backward), torch modules
+    for the MLPs under bf16 autocast, coordinates and indices in fp32, the hybrid head's losses (point focal +
+    smooth-L1 over points_in_boxes targets, heat-map focal) — AdamW, one gradient all-reduce per step (DDP, single
+    bucket) when world > 1."""
+    model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-3)
+    gt_boxes = synthetic_gt_boxes(B, 12, 99 + rank, device)
+    backbone = model.backbone_3d
 
     class Step(torch.nn.Module):
         def __init__(self, m):
@@ -228,21 +279,18 @@ def train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, dev
             self.m = m
 
         def forward(self, pts, sampled=None):
-            bd = {'batch_size': B, 'points': pts, 'points_per_sample_checked': True}
+            bd = {'batch_size': B, 'points': pts, 'points_per_sample_checked': True, 'gt_boxes': gt_boxes}
             if sampled is not None:
                 bd['sampled_xyz'] = sampled
-            bd = self.m["neck"](self.m["backbone"](bd))
-            sf = bd['spatial_features']
-            if not sf.is_contiguous() and sf.permute(0, 2, 3, 1).is_contiguous():
-                sf = sf.permute(0, 2, 3, 1)   # the neck's grid is channels-last storage: same mean, contiguous kernels
-            return bd['point_features'].float().square().mean() + sf.float().square().mean()
+            ret, tb, disp = self.m(bd)
+            return ret['loss']
 
     stepper = Step(model)
     if world > 1:
         stepper = torch.nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], bucket_cap_mb=64,
                                                             gradient_as_bucket_view=True)
 
-    # The sampling chain (FPS + gather: 4.4 ms, one workgroup per cloud) needs no gradient: the chain of the NEXT batch
+    # The sampling chain (FPS + gather, one workgroup per cloud) needs no gradient: the chain of the NEXT batch
     # runs on a side stream under this batch's forward/backward (same synthetic cloud every step).
     side = torch.cuda.Stream()
     state = {"sampled": None}
@@ -289,8 +337,8 @@ def train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, dev
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
-            "config": {"workload": f"configs[3]: train step of PointNet2MSG + PDM neck, bs={B}/GPU x {N} pts, stand-in loss, "
-                                   "AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
+            "config": {"workload": f"configs[3]: PDM-SSD train step (PointNet2MSG + PDM neck + hybrid head losses), bs={B}/GPU x {N} "
+                                   "pts, 12 synthetic boxes per cloud, AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
                        "overlap": "none" if args.serial else "FPS chain of the next batch on a side stream"},
             "final_loss": float(loss.detach())}))
     if world > 1:
@@ -354,6 +402,165 @@ def rendezvous_only(args):
         dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------- the timed step
+
+class Bench:
+    """One configuration (B clouds of N points, cloud kind) set up for timing: distinct synthetic batches rotated
+    through static input buffers (every pipeline stage sees a DIFFERENT batch every step), the pipelined step
+    captured in a hipGraph."""
+
+    NBATCH = 4
+
+    def __init__(self, model, B, N, kind, depth, device, seed0, serial=False, graph=True, autotune=True):
+        self.model, self.B, self.N, self.kind, self.device = model, B, N, kind, device
+        self.backbone, self.neck = model.backbone_3d, model.map_to_bev_module
+        self.serial, self.mode = serial, "eager"
+        self.batches = [make_batch(B, N, kind, seed0 + 1000 * i, device)[1] for i in range(self.NBATCH)]
+        fps_wgs = (depth - 1) * B * ((N + 16383) // 16384)
+        if depth >= 3 and not (1024 < N <= 131072 and (N <= 16384 or fps_wgs <= _native.lib().pdm_fps_max_coresident_workgroups())):
+            print(f"[bench] resumable FPS segments need 1024 < points <= 131072 and co-resident workgroups; "
+                  f"{N} points x {B} clouds -> --pipeline-depth 2", file=sys.stderr)
+            depth = 2
+        self.depth = depth
+        self.pipe = PipelinedHotPath(self.backbone, self.neck, depth=depth, dense_head=model.dense_head, point_head=model.point_head)
+        self.nstage = depth + 1 if depth >= 3 else 3           # input buffers: current batch + the ones in flight
+        self.inputs = [self.batches[k % self.NBATCH].clone() for k in range(self.nstage)]
+        self.step_no = 0
+        self.hoisting = None
+        with torch.no_grad():
+            counts = torch.bincount(self.batches[0][:, 0].long(), minlength=B)   # the backbone's per-sample point-count
+            assert int(counts.min()) == int(counts.max()) == N                    # check (host sync), once, untimed
+            if autotune:
+                self.hoisting = self.backbone.autotune_hoisting(self.batches[0], B)
+            if not serial:
+                if depth >= 3:
+                    self.pipe.prime_segmented(self.inputs[:depth], B)
+                else:
+                    self.pipe.prime(self.inputs[0], B, points_next=self.inputs[1])
+            self._run = self.step
+            if graph:
+                self._capture()
+
+    def step_serial(self, points=None):
+        bd = {'batch_size': self.B, 'points': self.inputs[0] if points is None else points, 'points_per_sample_checked': True}
+        bd = self.model.point_head(self.model.dense_head(self.neck(self.backbone(bd))))
+        return bd['spatial_features'], bd['point_features'], bd['batch_box_preds'], bd['bev_heatmap']
+
+    def step(self):
+        if self.serial:
+            return self.step_serial()
+        i = self.inputs
+        bd = self.pipe.step(i[0], i[1], self.B, extra={'points_per_sample_checked': True}, points_next2=i[2],
+                            points_ahead=i[1:self.depth + 1] if self.depth >= 3 else None)
+        return bd['spatial_features'], bd['point_features'], bd['batch_box_preds'], bd['bev_heatmap']
+
+    def _advance(self):
+        """The input buffers move one batch on: stage k now holds the batch that was at stage k + 1 (what the pipeline's
+        state expects after a step), the last stage a new one.  One 10 MB device copy per stage, part of the step."""
+        for k, buf in enumerate(self.inputs):
+            buf.copy_(self.batches[(self.step_no + k) % self.NBATCH], non_blocking=True)
+        self.step_no += 1
+
+    def _capture(self):
+        try:
+            for _ in range(2):
+                self._advance()
+                self.step()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._advance()
+                self.step()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):     # recorded, not executed: the pipeline's state does not move
+                self.static_out = self.step()
+            self._run, self.mode = self.graph.replay, "hipGraph"
+            self.run()
+            torch.cuda.synchronize()
+        except Exception as e:  # capture unsupported -> measure eager, say so
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            self._run, self.mode = self.step, "eager"
+            torch.cuda.synchronize()
+
+    def run(self):
+        """One step: rotate the inputs (the pipeline's stages hold batches i, i+1, ...), then the step."""
+        self._advance()
+        self._run()
+
+    def timed(self, steps, warmup, barrier=lambda: torch.cuda.synchronize()):
+        with torch.no_grad():
+            for _ in range(warmup):
+                self.run()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.run()
+            barrier()
+            return time.perf_counter() - t0
+
+    def median_ms(self, iters=50):
+        """Median over `iters` individually timed steps (HIP events on the launch stream), SURVEY D2."""
+        with torch.no_grad():
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            for e0, e1 in ev:
+                e0.record()
+                self.run()
+                e1.record()
+            torch.cuda.synchronize()
+        t = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        return t[len(t) // 2], t[0], t[-1]
+
+
+def measured_copy_bandwidth(device, mib=1024, iters=10):
+    """Device-to-device float4 copy of `mib` MiB through this library's own copy kernel: the HBM figure the box
+    sustains (read + write bytes per second), reported beside the nominal 8 TB/s."""
+    n = mib * 1024 * 1024 // 4
+    src, dst = torch.empty(n, dtype=torch.float32, device=device).normal_(), torch.empty(n, dtype=torch.float32, device=device)
+    _native.copy_many([dst], [src])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        _native.copy_many([dst], [src])
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def pdm_atomics_section(model, bd_source, reps=5):
+    """The PDM neck's scatter form (atomics-on-HBM, pdm_scatter_bev: memset + atomic adds + normalise — what training
+    runs and what north_star names) timed on the sampled set of the current batch, beside the gather form the
+    inference step uses.  Bytes: SURVEY D4's PDM formula, the atomic read-modify-write volume 4*C*P*K separately."""
+    neck = model.map_to_bev_module
+    with torch.no_grad():
+        bd = {'sa_xyz': bd_source['sa_xyz'], 'sa_features': bd_source['sa_features']}
+        out = {}
+        for form in ("gather", "scatter"):
+            neck.use_gather = form == "gather"
+            with OpTimer() as t:
+                for it in range(reps + 1):
+                    if it == 1:
+                        t.records.clear()
+                    neck(dict(bd))
+                ops = [o for o in t.summary(reps) if o["op"].startswith(("pdm_scatter", "pdm_gather", "pdm_bev_norm"))]
+            out[form] = ops
+        neck.use_gather = True
+    xyz = bd_source['sa_xyz'][neck.source_layer]
+    B, P = xyz.shape[0], xyz.shape[1]
+    K = neck.dilation[0] * neck.dilation[1] * neck.dilation[2]
+    rmw = 4.0 * neck.feature_dim * P * K * B
+    sc = [o for o in out["scatter"] if o["op"] == "pdm_scatter_bev"]
+    res = {"gather_form_ops": out["gather"], "scatter_form_ops": out["scatter"],
+           "atomic_rmw_MB_per_step": round(rmw / 1e6, 1)}
+    if sc and sc[0]["ms_per_step"] > 0:
+        res["atomics_kernel"] = {"kernel": "pdm::pdm_scatter_kernel", "ms": sc[0]["ms_per_step"],
+                                 "atomic_add_GBps": round(rmw / 1e9 / (sc[0]["ms_per_step"] * 1e-3), 1),
+                                 "note": "memory-side fp32 atomic adds, 4 bytes of payload each"}
+    return res
+
+
 # ----------------------------------------------------------------------------- main
 
 def main():
@@ -373,10 +580,13 @@ def main():
                          "neighbour density of the batch (PointNet2MSG.autotune_hoisting)")
     ap.add_argument("--serial", action="store_true", help="no cross-batch overlap of the FPS chain")
     ap.add_argument("--train", action="store_true",
-                    help="BASELINE config 4 instead: bf16-autocast forward+backward+AdamW step of backbone+neck, "
+                    help="BASELINE config 4 instead: bf16-autocast forward+backward+AdamW step of the detector, "
                          "DistributedDataParallel gradient all-reduce over RCCL when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra measurements of the default line (lidar-like clouds, configs[4] stress shape, "
+                         "single-thread CPU leg, median over 50 steps)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch + barrier + max-over-ranks protocol only, no kernels (launch diagnostic / CPU test)")
     args = ap.parse_args()
@@ -399,100 +609,20 @@ def main():
     _native.lib()  # fail loudly now if the HIP library is missing
 
     B, N = args.batch, args.points
-    backbone, neck = build_models(device)
-    _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
+    model = build_detector(device)
     if args.train:
-        return train_bench(args, backbone, neck, points, B, N, rank, world, local_rank, device)
+        _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
+        return train_bench(args, model, points, B, N, rank, world, local_rank, device)
+    backbone, neck = model.backbone_3d, model.map_to_bev_module
 
-    def step_serial():
-        bd = {'batch_size': B, 'points': points, 'points_per_sample_checked': True}
-        bd = backbone(bd)
-        bd = neck(bd)
-        return bd['spatial_features'], bd['point_features']
-
-    fps_wgs = (args.pipeline_depth - 1) * B * ((N + 16383) // 16384)
-    if args.pipeline_depth >= 3 and not (1024 < N <= 131072 and
-                                         (N <= 16384 or fps_wgs <= _native.lib().pdm_fps_max_coresident_workgroups())):
-        print(f"[bench] resumable FPS segments need 1024 < points <= 131072 and co-resident workgroups; "
-              f"{N} points x {B} clouds -> --pipeline-depth 2", file=sys.stderr)
-        args.pipeline_depth = 2
-    pipe = PipelinedHotPath(backbone, neck, depth=args.pipeline_depth)
-
-    def step_pipelined():
-        # features of this batch || sampling of the following batch(es) (same synthetic cloud every step)
-        bd = pipe.step(points, points, B, extra={'points_per_sample_checked': True}, points_next2=points,
-                       points_ahead=[points] * args.pipeline_depth)
-        return bd['spatial_features'], bd['point_features']
-
-    step = step_serial if args.serial else step_pipelined
-
-    barrier = dist_utils.barrier
-
-    mode = "eager"
-    with torch.no_grad():
-        # per-sample point-count check of the backbone (host sync) done once, outside the timed region
-        counts = torch.bincount(points[:, 0].long(), minlength=B)
-        assert int(counts.min()) == int(counts.max()) == N
-        if not args.no_autotune:
-            hoisting = backbone.autotune_hoisting(points, B)
-        if args.pipeline_depth >= 3:
-            pipe.prime_segmented([points] * args.pipeline_depth, B)
-        else:
-            pipe.prime(points, B)
-        for _ in range(max(1, args.warmup)):
-            step()
-        torch.cuda.synchronize()
-        run = step
-        graph = None
-        if not args.no_graph:
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    step()
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    static_out = step()
-                run = graph.replay
-                mode = "hipGraph"
-                run()
-                torch.cuda.synchronize()
-            except Exception as e:  # capture unsupported -> measure eager, say so
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-                graph, run, mode = None, step, "eager"
-                torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        barrier()
-        elapsed = time.perf_counter() - t0
-
-        elapsed = dist_utils.max_over_ranks(elapsed, device)
-        if not args.serial:
-            pipe.check_sampling()   # N > 16384: no cooperating FPS workgroup gave up waiting for a peer
-
-        # per-kernel pass (eager, instrumented with HIP events on the launch stream); rank 0 only
-        ops = []
-        if rank == 0:
-            psteps = max(3, min(args.steps, 10))
-            from pdm_ssd_amd import fused as _fused
-            _fused.FLOP_COUNTER = {}
-            with OpTimer() as timer:
-                for _ in range(psteps):
-                    step_serial()
-                ops = timer.summary(psteps)
-            executed = {k: v / psteps for k, v in _fused.FLOP_COUNTER.items()}
-            _fused.FLOP_COUNTER = None
-            t0s = time.perf_counter()
-            for _ in range(psteps):
-                step_serial()
-            torch.cuda.synchronize()
-            serial_ms = (time.perf_counter() - t0s) / psteps * 1e3
+    bench = Bench(model, B, N, args.clouds, args.pipeline_depth, device, seed0=1234 + rank * B, serial=args.serial,
+                  graph=not args.no_graph, autotune=not args.no_autotune)
+    elapsed = bench.timed(args.steps, args.warmup, barrier=dist_utils.barrier)
+    elapsed = dist_utils.max_over_ranks(elapsed, device)
+    LAUNCH_MODE[0] = bench.mode
+    LAUNCH_MODE[1] = None if bench.hoisting is None else [d["use_pre"] for d in bench.hoisting]
+    if not args.serial:
+        bench.pipe.check_sampling()   # N > 16384: no cooperating FPS workgroup gave up waiting for a peer
 
     if rank != 0:
         if world > 1:
@@ -502,13 +632,43 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * B * args.steps / elapsed
+    extras = {}
+    if not args.no_extras:
+        med, lo, hi = bench.median_ms(max(50, args.steps))
+        extras["ms_per_step_median_of_50"] = {"median": round(med, 4), "min": round(lo, 4), "max": round(hi, 4),
+                                              "frames_per_s_at_median": round(B / med * 1e3, 1)}
 
-    # HBM traffic per launch from the committed PMC passes of this same command (profiles/r01c_pmc_traffic.json;
-    # rocprofv3 cannot run inside this process): corrected bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB
-    pmc = {}
+    # per-kernel pass (eager, serial, every C-ABI call bracketed by HIP events on its launch stream)
+    points = bench.batches[0]
+    with torch.no_grad():
+        psteps = max(3, min(args.steps, 10))
+        from pdm_ssd_amd import fused as _fused
+        _fused.FLOP_COUNTER = {}
+        with OpTimer() as timer:
+            for _ in range(psteps):
+                bench.step_serial(points)
+            ops = timer.summary(psteps)
+        executed = {k: v / psteps for k, v in _fused.FLOP_COUNTER.items()}
+        _fused.FLOP_COUNTER = None
+        t0s = time.perf_counter()
+        for _ in range(psteps):
+            bench.step_serial(points)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t0s) / psteps * 1e3
+        bd_src = neck(backbone({'batch_size': B, 'points': points, 'points_per_sample_checked': True}))
+        pdm = pdm_atomics_section(model, bd_src)
+        copy_gbs = measured_copy_bandwidth(device)
+
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process): only a file
+    # recorded for THIS shape is attached (tools/pmc_traffic.py stores batch / points / clouds)
+    pmc, pmc_src = {}, None
     try:
         import glob as _glob
-        pmc = json.load(open(sorted(_glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))["kernels"]
+        for path in sorted(_glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+            doc = json.load(open(path))
+            if doc.get("shape") == {"batch": B, "points": N, "clouds": args.clouds}:
+                pmc, pmc_src = doc["kernels"], os.path.relpath(path, ROOT)
+                break
     except Exception:
         pass
 
@@ -519,99 +679,179 @@ def main():
         return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
 
     # FLOPs: `executed` = what each entry point actually contracts (2 * real cin * cout per position and layer).
-    # The SA / FP kernels run with the wide block of their first layer hoisted onto the source / known points
-    # (pdm_rows_mlp_fused), so the step executes fewer FLOPs than the reference's form of the same network.
     sa_gf, fp_gf = model_flops(backbone, B, N)
+    head_gf = B * N * (mlp_flops_linear(model.point_head.cls_layers) + mlp_flops_linear(model.point_head.box_layers)) / 1e9
     for o in ops:
         if o["op"] in executed:
             o["executed_GFLOP_per_step"] = round(executed[o["op"]] / 1e9, 2)
             o["TFLOPs"] = round(executed[o["op"]] / 1e9 / o["ms_per_step"], 1)
     mlp_ops = [o for o in ops if o["op"] in executed]
-    flop_summary = {"reference_form_GFLOP_per_step": round(sa_gf + fp_gf, 2),
+    flop_summary = {"reference_form_GFLOP_per_step": round(sa_gf + fp_gf + head_gf, 2),
+                    "of_which": {"SA": round(sa_gf, 2), "FP": round(fp_gf, 2), "point_head": round(head_gf, 2)},
                     "executed_GFLOP_per_step": round(sum(executed.values()) / 1e9, 2),
                     "mlp_kernels_ms_per_step": round(sum(o["ms_per_step"] for o in mlp_ops), 4),
                     "note": "SA kernels run over compacted neighbour lists (ball_query's padding copies of the first hit are "
                             "not computed: max-pool over a multiset = over the set; bit-identical; uniform clouds hold one point "
                             "per ball, lidar-like ones 1.2-5.6); first-layer hoisting where it pays: W1 [f_nb ; dx] = (W1f f)[nb] "
                             "+ W1x dx (SA, chosen per level by autotune_hoisting), W1 interp(f) = interp(W1 f) (FP)"}
-    # dominant roofline-bounded kernel of the step: the fused SA kernel (fp32 MFMA), all its launches (both entry
-    # points).  FPS takes longer but is a latency-bound dependency chain (one workgroup per cloud) with no
-    # bandwidth or matrix roofline; it is listed under "ops" with its iteration rate.
-    # (with the neighbour lists compacted the SA kernels only run the distinct neighbours — on sparse clouds a small
-    # part of the step — so the dominant MFMA entry point is picked by measured time, not by name)
     KERNELS_OF = {"pdm_sa_mlp_fused": ("pdm::sa_mlp_fused_kernel", "pdm::sa_reg_mlp_kernel"),
                   "pdm_sa_mlp_fused_pre": ("pdm::sa_mlp_fused_kernel",),
                   "pdm_sa_mlp_packed": ("pdm::sa_packed_fused_kernel", "pdm::sa_reg_packed_kernel"),
                   "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
                   "pdm_fp_mlp_fused_pre": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<true>"),
                   "pdm_rows_mlp_fused": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
-    sa_ops = sorted(mlp_ops, key=lambda o: -o["ms_per_step"])[:1]
-    roofline = None
-    if sa_ops:
-        calls = sum(o["calls_per_step"] for o in sa_ops)
-        per_launch_flop = sum(executed[o["op"]] for o in sa_ops) / calls
-        per_launch_s = sum(o["ms_per_step"] for o in sa_ops) / 1e3 / calls
+
+    def mfma_block(o):
+        calls = o["calls_per_step"]
+        per_launch_flop = executed[o["op"]] / calls
+        per_launch_s = o["ms_per_step"] / 1e3 / calls
         ach = per_launch_flop / per_launch_s / 1e12
-        kernels = KERNELS_OF.get(sa_ops[0]["op"], ())
-        roofline = {"bound": "mfma", "kernel": " + ".join(kernels) + f" (all launches of {sa_ops[0]['op']}, the MFMA entry "
-                                               "point with the most time in the step)",
-                    "achieved": round(ach, 2),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(*kernels) if kernels else None, "traffic_unit": "HBM bytes per launch (PMC)",
-                    "launches_per_step": calls,
-                    "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop),
-                    "flops_counted": "executed (hoisted first layer), unpadded"}
+        kernels = KERNELS_OF.get(o["op"], ())
+        return {"bound": "mfma", "kernel": " + ".join(kernels) + f" (all launches of {o['op']})",
+                "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(*kernels) if kernels else None,
+                "traffic_unit": "HBM bytes per launch (PMC)", "launches_per_step": calls,
+                "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop),
+                "ms_per_step": o["ms_per_step"], "flops_counted": "executed (hoisted first layer), unpadded"}
+
+    def fps_block():
+        """FPS: a dependent chain of m - 1 iterations per cloud, each N distance evaluations of 8 flop; bound by the
+        latency of an iteration (VALU + cross-lane reductions + one barrier), quoted against the fp32 vector peak."""
+        fo = [o for o in ops if o["op"] == "pdm_furthest_point_sampling"]
+        if not fo:
+            return None
+        lv = [(m.npoint, n_in) for m, n_in in zip(backbone.SA_modules, [N] + [m.npoint for m in backbone.SA_modules][:-1])]
+        flop = sum(8.0 * B * (m - 1) * n for m, n in lv)
+        iters = sum(m - 1 for m, _ in lv)
+        ms = fo[0]["ms_per_step"]
+        ach = flop / (ms * 1e-3) / 1e12
+        return {"bound": "valu/latency", "kernel": "pdm::fps_pruned_kernel + pdm::fps_reg_kernel (all launches of "
+                "pdm_furthest_point_sampling: the four levels' chains, whole calls; the pipelined step runs level 1 as "
+                "resumable jobs of the same kernel)",
+                "achieved": round(ach, 3), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / VALU_F32_PEAK_TFLOPS, 4),
+                "traffic": pmc_traffic("pdm::fps_pruned_kernel", "pdm::fps_reg_kernel"), "traffic_unit": "HBM bytes per launch (PMC)",
+                "launches_per_step": fo[0]["calls_per_step"], "avg_launch_us": round(ms * 1e3 / fo[0]["calls_per_step"], 2),
+                "alg_flop_per_launch": int(flop / fo[0]["calls_per_step"]), "ms_per_step": ms,
+                "serial_iterations_per_step": iters, "us_per_iteration": round(ms * 1e3 / iters, 3),
+                "distance_evals_per_s_G": round(flop / 8 / (ms * 1e-3) / 1e9, 1),
+                "flops_counted": "reference form: every point against every new sample (the kernel skips groups whose "
+                                 "bound proves nothing changes — exact — so fewer are executed)"}
+
+    mfma_blocks = {o["op"]: mfma_block(o) for o in mlp_ops}
+    roofline_mfma = max(mfma_blocks.values(), key=lambda b: b["ms_per_step"]) if mfma_blocks else None
+    roofline_fps = fps_block()
+    # `roofline` = the entry point with the most device time in the step
+    cands = [b for b in (roofline_mfma, roofline_fps) if b is not None]
+    roofline = max(cands, key=lambda b: b["ms_per_step"]) if cands else None
+
     with torch.no_grad():
         refops, gp = reference_op_section(backbone, points, B)
     gp_launch_bytes = gp["alg_MB_per_step"] * 1e6 / gp["calls_per_step"]
     gp_launch_s = gp["ms_per_step"] / 1e3 / gp["calls_per_step"]
-    roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_v4_kernel (pdm_group_points, API-exact operator)",
-                    "achieved": round(gp_launch_bytes / gp_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gp_launch_bytes / gp_launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("pdm::group_points_v4_kernel"),
+    gp_gbs = gp_launch_bytes / gp_launch_s / 1e9
+    roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_v4_kernel + pdm::group_points_lds_kernel (all launches of "
+                    "pdm_group_points, the API-exact operator)",
+                    "achieved": round(gp_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gp_gbs / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_copy": round(gp_gbs / copy_gbs, 4),
+                    "traffic": pmc_traffic("pdm::group_points_v4_kernel", "pdm::group_points_lds_kernel"),
                     "launches_per_step": gp["calls_per_step"], "avg_launch_us": round(gp_launch_s * 1e6, 2),
                     "alg_bytes_per_launch": int(gp_launch_bytes)}
-    fps_ops = [o for o in ops if o["op"].startswith("pdm_furthest_point_sampling")]
-    if fps_ops:
-        iters = sum(m.npoint - 1 for m in backbone.SA_modules)
-        fps_ms = sum(o["ms_per_step"] for o in fps_ops)
-        fps_ops[0]["fps_chain"] = {"serial_iterations_per_step": iters, "ms_per_step": round(fps_ms, 4),
-                                   "us_per_iteration": round(fps_ms * 1e3 / iters, 3)}
+    pg = [o for o in ops if o["op"] == "pdm_gather_bev"]
+    roofline_pdm = None
+    if pg:
+        o = pg[0]
+        gbs = o["alg_MB_per_step"] / o["ms_per_step"]
+        roofline_pdm = {"bound": "hbm", "kernel": "pdm::pdm_bin_kernel + pdm::pdm_gather_reg_kernel (pdm_gather_bev, the inference "
+                        "form of the PDM scatter; atomics form under pdm_neck_forms)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_gbs, 4),
+                        "traffic": pmc_traffic("pdm::pdm_gather_reg_kernel", "pdm::pdm_bin_kernel"),
+                        "launches_per_step": o["calls_per_step"], "avg_launch_us": round(o["ms_per_step"] * 1e3 / o["calls_per_step"], 2),
+                        "alg_bytes_per_launch": int(o["alg_MB_per_step"] * 1e6 / o["calls_per_step"])}
+    refops["frac_of_measured_copy"] = round(refops["GBps"] / copy_gbs, 4)
 
-    cpu = None
+    cpu = cpu1 = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline(backbone, neck, N, args.clouds, frames=args.cpu_frames)
+        cpu = cpu_baseline(model, N, args.clouds, frames=args.cpu_frames)
+        if not args.no_extras:
+            cpu1 = cpu_baseline(model, N, args.clouds, frames=1, threads=1)
 
+    if not args.no_extras and not args.serial:
+        del bench
+        torch.cuda.empty_cache()
+        with torch.no_grad():
+            if args.clouds != "lidar":
+                b2 = Bench(model, B, N, "lidar", args.pipeline_depth, device, seed0=4321, graph=not args.no_graph,
+                           autotune=not args.no_autotune)
+                t = b2.timed(max(10, args.steps), 3)
+                n = max(10, args.steps)
+                extras["lidar_like_clouds"] = {"ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(B * n / t, 1),
+                                               "workload": f"same step, bs={B} x {N} pts, lidar-like clouds (ring structure + ground "
+                                                           "plane: 1.2-5.6 distinct neighbours per ball instead of 1)"}
+                del b2
+                torch.cuda.empty_cache()
+            if (B, N) == (32, 16384):
+                b5 = Bench(model, 16, 65536, "lidar", 4, device, seed0=777, graph=not args.no_graph, autotune=not args.no_autotune)
+                n = 10
+                t = b5.timed(n, 2)
+                b5.pipe.check_sampling()
+                bd5 = neck(backbone({'batch_size': 16, 'points': b5.batches[0], 'points_per_sample_checked': True}))
+                extras["config5_dense_stress"] = {
+                    "workload": "configs[4]: 65536 pts/cloud, bs=16, lidar-like, same full forward; level-1 FPS as 3 resumable "
+                                "segments of 4 cooperating workgroups per cloud",
+                    "ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(16 * n / t, 1), "launch": b5.mode,
+                    "pdm_neck_forms": pdm_atomics_section(model, bd5)}
+                del b5, bd5
+                torch.cuda.empty_cache()
+
+    # rebuilt if deleted above: only its attributes are needed for the line
     line = {
-        "metric": "frames/sec (16384-pt clouds, bs=32)", "value": round(frames_per_s, 2), "unit": "frames/s",
+        "metric": f"frames/sec ({N}-pt clouds, bs={B})", "value": round(frames_per_s, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[2]: PointNet2MSG backbone + PDM neck forward, bs={B}/GPU x {N} pts, "
-                               f"{args.clouds} KITTI-range clouds, fp32 inference, inputs resident in HBM",
-                   "launch": mode, "parallelism": f"dp{world}",
+        "config": {"workload": f"configs[2]: full PDM-SSD forward (PointNet2MSG backbone + PDM neck + hybrid head: BEV heat-map "
+                               f"head + point box head with decoded boxes), bs={B}/GPU x {N} pts, {args.clouds} KITTI-range clouds, "
+                               f"fp32 inference, inputs resident in HBM, {Bench.NBATCH} distinct batches in rotation",
+                   "launch": LAUNCH_MODE[0], "parallelism": f"dp{world}",
                    "overlap": "none" if args.serial else
                               ("FPS chain of batch i+1 on a side stream under the feature half of batch i "
                                "(pdm_ssd_amd/pipeline.py)" if args.pipeline_depth == 1 else
                                f"level-1 FPS cut into {args.pipeline_depth - 1} resumable segments: one launch per step runs "
                                f"segment s of batch i+{args.pipeline_depth}-s side by side, the rest of batch i+1's coordinate "
-                               "chain on a third stream, under the feature half of batch i; every step does one full "
-                               "batch of every kind of work (pdm_ssd_amd/pipeline.py)" if args.pipeline_depth >= 3 else
+                               "chain on a third stream, under the feature half of batch i (heat-map head behind the neck on "
+                               "the neck's stream, point head behind the FP layers); every step does one full batch of every "
+                               "kind of work (pdm_ssd_amd/pipeline.py)" if args.pipeline_depth >= 3 else
                                "sampling two batches deep: level-1 FPS of batch i+2 and levels 2-4 of batch i+1 on side "
                                "streams under the feature half of batch i; every step does one full batch of every "
                                "kind of work (pdm_ssd_amd/pipeline.py)"),
                    "ms_per_step_eager_serial": round(serial_ms, 4),
-                   "sa_first_layer_hoisted": None if args.no_autotune else [d["use_pre"] for d in hoisting]},
+                   "sa_first_layer_hoisted": LAUNCH_MODE[1]},
         "roofline": roofline,
+        "roofline_fps": roofline_fps,
+        "roofline_mfma": roofline_mfma,
         "roofline_hbm": roofline_hbm,
+        "roofline_pdm": roofline_pdm,
+        "hbm_copy_measured_GBps": round(copy_gbs, 1),
+        "traffic_source": pmc_src,
         "mlp_flops": flop_summary,
+        "mfma_entry_points": mfma_blocks,
         "ball_query_plus_group": refops,
+        "pdm_neck_forms": pdm,
         "ops": ops,
+        "extras": extras,
         "cpu_baseline": cpu,
+        "cpu_baseline_single_thread": cpu1,
     }
     print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LAUNCH_MODE = [None, None]
+
+
+def mlp_flops_linear(seq):
+    return 2 * sum(m.in_features * m.out_features for m in seq if isinstance(m, torch.nn.Linear))
 
 
 if __name__ == "__main__":

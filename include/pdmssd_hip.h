@@ -264,6 +264,13 @@ int pdm_stack_three_interpolate_grad(void *stream, int N, int C, const float *gr
 int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
                                       const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points);
 
+/* ---- hybrid head (north_star configs[2]: "backbone + PDM neck + hybrid head"; no reference source: SURVEY.md F1) ----
+ * Depthwise 3x3 convolution + folded BatchNorm + ReLU over the neck's channels-last BEV grid, the context stage of
+ * the heat-map head (pdm_ssd_amd/dense_heads/pdm_heatmap_head.py); the point head's MLPs and the heat-map head's 1x1
+ * stack run through pdm_rows_mlp_fused.  in / out (B, H, W, C) fp32, w (9, C) tap-major, shift (C); C % 4 == 0. */
+int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, const float *in, const float *w, const float *shift,
+                         float *out, int relu);
+
 /* ---- rotated-box IoU / NMS ---------------------------------------------
  * One entry per function of the reference's iou3d_nms_cuda extension (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp):
  *   boxes_overlap_bev_gpu / boxes_iou_bev_gpu        iou3d_nms.cpp:55,96     (na, nb) areas / BEV IoUs

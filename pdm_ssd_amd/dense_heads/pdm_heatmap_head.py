@@ -8,7 +8,10 @@ pieces for the same job: the detector's DENSE_HEAD slot and constructor keywords
 (utils/loss_utils.py:266-345, weight `cls_weight` as center_head.py:238-242).  Plain torch convolutions: the BEV map
 is 128 x 200 x 176 — a dense 2-D problem MIOpen handles; nothing on it is a hot kernel of the path.
 
-  spatial_features (B, C, H, W) -> SHARED_CONV x (3x3 conv + BN + ReLU) -> 3x3 conv + ReLU -> 1x1 conv -> logits
+  spatial_features (B, C, H, W) -> NUM_CONTEXT_CONV x context block -> 1x1 conv + ReLU -> 1x1 conv -> logits
+  context block (CONTEXT_CONV): 'separable' (default) = depthwise 3x3 + BN + ReLU, pointwise 1x1 + BN + ReLU — the
+  dilated map is wide (128 channels x 35200 cells x batch) and mostly empty, a full 3x3 convolution over it would cost
+  more FLOPs than the whole point backbone; 'full' = 3x3 conv + BN + ReLU as CenterPoint's shared_conv.
   batch_dict['bev_heatmap'] = sigmoid(logits)  (B, num_class, H, W)
 """
 import numpy as np
@@ -31,11 +34,16 @@ class PDMHeatmapHead(nn.Module):
         self.feature_map_stride = _get(_get(model_cfg, 'TARGET_ASSIGNER_CONFIG', {}), 'FEATURE_MAP_STRIDE', 8)
         width = _get(model_cfg, 'SHARED_CONV_CHANNEL', 64)
         layers, c = [], input_channels
-        for _ in range(_get(model_cfg, 'NUM_CONTEXT_CONV', 2)):   # "context learning" over the dilated, mostly empty map
-            layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
+        kind = _get(model_cfg, 'CONTEXT_CONV', 'separable')
+        for _ in range(_get(model_cfg, 'NUM_CONTEXT_CONV', 1)):   # "context learning" over the dilated, mostly empty map
+            if kind == 'separable':
+                layers += [nn.Conv2d(c, c, 3, padding=1, groups=c, bias=False), nn.BatchNorm2d(c), nn.ReLU(),
+                           nn.Conv2d(c, width, 1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
+            else:
+                layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
             c = width
         self.shared_conv = nn.Sequential(*layers)
-        self.hm = nn.Sequential(nn.Conv2d(c, width, 3, padding=1, bias=True), nn.ReLU(), nn.Conv2d(width, num_class, 1, bias=True))
+        self.hm = nn.Sequential(nn.Conv2d(c, width, 1, bias=True), nn.ReLU(), nn.Conv2d(width, num_class, 1, bias=True))
         self.hm[-1].bias.data.fill_(-2.19)   # CenterPoint's prior: sigmoid(-2.19) = 0.1 (center_head.py:47)
         self.add_module('hm_loss_func', loss_utils.FocalLossCenterNet())
         self.forward_ret_dict = {}
@@ -75,8 +83,45 @@ class PDMHeatmapHead(nn.Module):
         tb_dict['hm_loss'] = hm_loss.detach()
         return hm_loss, tb_dict
 
+    def _fused_logits(self, x):
+        """Inference on the neck's channels-last grid: depthwise 3x3 + BN + ReLU as one HIP kernel
+        (pdm_bev_depthwise3x3), then pointwise 1x1 + BN + ReLU -> 1x1 + ReLU -> 1x1 as ONE per-cell MLP on the MFMA row
+        kernels (pdm_rows_mlp_fused, BatchNorm folded) — the map is read twice and written once instead of ten passes
+        of MIOpen kernels.  None when the module's shape or the tensor's layout does not fit."""
+        from .. import _native, fused
+        mods = list(self.shared_conv)
+        if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or len(mods) != 6
+                or not isinstance(mods[0], nn.Conv2d) or mods[0].groups != mods[0].in_channels
+                or not getattr(self, 'use_fused', True) or x.shape[1] % 16 != 0):
+            return None
+        rows = x.permute(0, 2, 3, 1)                       # (B, H, W, C): the storage itself for the neck's grid
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        B, H, W, C = rows.shape
+        cache = self.__dict__.setdefault('_pdm_fused_cache', {})
+        key = (fused._state_key(self.shared_conv), str(x.device))
+        if cache.get('dw', (None,))[0] != key:
+            dw, bn = mods[0], mods[1]
+            s = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
+            w = (dw.weight.detach().double().reshape(C, 9) * s[:, None]).t().contiguous().float()      # (9, C) tap-major
+            shift = (bn.bias.detach().double() - bn.running_mean.detach().double() * s).float().contiguous()
+            cache['dw'] = (key, w.to(x.device), shift.to(x.device))
+        _, w, shift = cache['dw']
+        pk = fused.cached_layers(self, 'pw', self, lambda: [(mods[3], mods[4]), (self.hm[0], None), (self.hm[2], None)], x.device)
+        mid = torch.empty_like(rows)
+        _native.call("pdm_bev_depthwise3x3", torch.cuda.current_stream(x.device).cuda_stream, B, H, W, C, rows.data_ptr(),
+                     w.data_ptr(), shift.data_ptr(), mid.data_ptr(), 1)
+        out = torch.empty((B, H, W, (self.num_class + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+        fused.rows_forward(pk, mid, out, relu_last=False)
+        return out[..., :self.num_class].permute(0, 3, 1, 2)
+
     def forward(self, data_dict):
         x = data_dict['spatial_features_2d'] if 'spatial_features_2d' in data_dict else data_dict['spatial_features']
+        logits = self._fused_logits(x)
+        if logits is not None:
+            self.forward_ret_dict['hm_logits'] = logits
+            data_dict['bev_heatmap'] = self.sigmoid(logits)
+            return data_dict
         if x.dim() == 4 and not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)   # the neck's grid IS channels-last storage: no copy
         logits = self.hm(self.shared_conv(x))

@@ -82,11 +82,13 @@ class PointHeadBox(PointHeadTemplate):
             pb = fused.cached_layers(self, 'box', self.box_layers, lambda: _fc_layers(self.box_layers), point_features.device)
             if pc is not None and pb is not None:
                 rows = point_features.contiguous().unsqueeze(0)
-                cls = torch.empty((1, rows.shape[1], self.num_class), dtype=torch.float32, device=rows.device)
-                box = torch.empty((1, rows.shape[1], self.box_coder.code_size), dtype=torch.float32, device=rows.device)
+                # (the kernel writes 16-byte groups: row strides padded to a multiple of 4 floats)
+                ncls, nbox = self.num_class, self.box_coder.code_size
+                cls = torch.empty((1, rows.shape[1], (ncls + 3) // 4 * 4), dtype=torch.float32, device=rows.device)
+                box = torch.empty((1, rows.shape[1], (nbox + 3) // 4 * 4), dtype=torch.float32, device=rows.device)
                 fused.rows_forward(pc, rows, cls, relu_last=False)
                 fused.rows_forward(pb, rows, box, relu_last=False)
-                return cls[0], box[0]
+                return cls[0, :, :ncls], box[0, :, :nbox]
         return self.cls_layers(point_features), self.box_layers(point_features)
 
     def forward(self, batch_dict):

@@ -16,7 +16,7 @@ PDM_SSD_CFG = {
     'BACKBONE_3D': dict(POINTRCNN_MSG_CFG),
     'MAP_TO_BEV': {'NAME': 'PDMNeck', 'SOURCE_LAYER': 2, 'FEATURE_DIM': 128, 'DILATION': [7, 7, 1], 'SH_DEGREE': 2,
                    'BEV_STRIDE': 8, 'HEIGHT_BINS': 1, 'INPUT_CHANNELS': 256, 'NORMALIZE': True},
-    'DENSE_HEAD': {'NAME': 'PDMHeatmapHead', 'CLASS_AGNOSTIC': False, 'SHARED_CONV_CHANNEL': 64, 'NUM_CONTEXT_CONV': 2,
+    'DENSE_HEAD': {'NAME': 'PDMHeatmapHead', 'CLASS_AGNOSTIC': False, 'SHARED_CONV_CHANNEL': 64, 'NUM_CONTEXT_CONV': 1, 'CONTEXT_CONV': 'separable',
                    'TARGET_ASSIGNER_CONFIG': {'FEATURE_MAP_STRIDE': 8, 'GAUSSIAN_OVERLAP': 0.1, 'MIN_RADIUS': 2},
                    'LOSS_CONFIG': {'LOSS_WEIGHTS': {'cls_weight': 1.0}}},
     'POINT_HEAD': {'NAME': 'PointHeadBox', 'CLS_FC': [256, 256], 'REG_FC': [256, 256], 'CLASS_AGNOSTIC': False,

@@ -61,10 +61,15 @@ def _merge(a, b):
 
 
 class PipelinedHotPath:
-    def __init__(self, backbone, neck=None, depth=1):
+    def __init__(self, backbone, neck=None, depth=1, dense_head=None, point_head=None):
+        """dense_head / point_head: the two halves of the hybrid head (detector slots DENSE_HEAD / POINT_HEAD).  The
+        heat-map head reads only the neck's grid and runs behind it on the neck's stream; the point head reads the
+        backbone's point features and runs on the main stream after the FP layers."""
         assert depth in (1, 2, 3, 4, 5)
         self.backbone = backbone
         self.neck = neck
+        self.dense_head = dense_head
+        self.point_head = point_head
         self.depth = depth
         self.side = torch.cuda.Stream()
         self.neck_stream = torch.cuda.Stream()
@@ -197,8 +202,12 @@ class PipelinedHotPath:
                 self.neck_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.neck_stream):
                     self.neck(d)
+                    if self.dense_head is not None:
+                        self.dense_head(d)
             bd['after_sa_hook'] = start_neck
         bd = self.backbone(bd)
+        if self.point_head is not None:
+            bd = self.point_head(bd)
         if self.neck is not None:
             torch.cuda.current_stream().wait_stream(self.neck_stream)
         return bd

@@ -18,10 +18,11 @@ class PointResidualCoder(object):
             self.mean_size = torch.from_numpy(np.array(kwargs['mean_size'])).float()
             assert self.mean_size.min() > 0
 
-    def _anchor(self, classes, like):
+    def _anchor(self, classes, like, check=False):
         if self.mean_size.device != like.device:
             self.mean_size = self.mean_size.to(like.device)
-        assert classes.max() <= self.mean_size.shape[0]
+        if check:   # (a host synchronisation: only where the classes come from data, i.e. target encoding)
+            assert classes.max() <= self.mean_size.shape[0]
         size = self.mean_size[classes - 1]
         dxa, dya, dza = torch.split(size, 1, dim=-1)
         return dxa, dya, dza, torch.sqrt(dxa ** 2 + dya ** 2)
@@ -33,7 +34,7 @@ class PointResidualCoder(object):
         xg, yg, zg, dxg, dyg, dzg, rg, *cgs = torch.split(gt_boxes, 1, dim=-1)
         xa, ya, za = torch.split(points, 1, dim=-1)
         if self.use_mean_size:
-            dxa, dya, dza, diagonal = self._anchor(gt_classes, gt_boxes)
+            dxa, dya, dza, diagonal = self._anchor(gt_classes, gt_boxes, check=True)
             xt, yt, zt = (xg - xa) / diagonal, (yg - ya) / diagonal, (zg - za) / dza
             dxt, dyt, dzt = torch.log(dxg / dxa), torch.log(dyg / dya), torch.log(dzg / dza)
         else:
@@ -42,7 +43,9 @@ class PointResidualCoder(object):
         return torch.cat([xt, yt, zt, dxt, dyt, dzt, torch.cos(rg), torch.sin(rg), *cgs], dim=-1)
 
     def decode_torch(self, box_encodings, points, pred_classes=None):
-        """box_encodings (N, 8 + C) [x, y, z, dx, dy, dz, cos, sin, ...], points (N, 3) -> boxes (N, 7 + C)."""
+        """box_encodings (N, 8 + C) [x, y, z, dx, dy, dz, cos, sin, ...], points (N, 3) -> boxes (N, 7 + C).
+        pred_classes in [1, num_classes] (an arg-max + 1 in the head: the reference's range assert, a device->host
+        synchronisation per call, is kept for the encoder only, so decoding can be captured in a hipGraph)."""
         xt, yt, zt, dxt, dyt, dzt, cost, sint, *cts = torch.split(box_encodings, 1, dim=-1)
         xa, ya, za = torch.split(points, 1, dim=-1)
         if self.use_mean_size:

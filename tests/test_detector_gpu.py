@@ -26,6 +26,15 @@ SMALL['BACKBONE_3D'] = {'NAME': 'PointNet2MSG',
 SMALL['MAP_TO_BEV'] = dict(PDM_SSD_CFG['MAP_TO_BEV'], FEATURE_DIM=32, DILATION=[5, 5, 1])
 
 
+HEAD_CFG = {'CLS_FC': [32, 24], 'REG_FC': [24], 'CLASS_AGNOSTIC': False, 'USE_POINT_FEATURES_BEFORE_FUSION': False,
+            'TARGET_CONFIG': {'GT_EXTRA_WIDTH': [0.2, 0.2, 0.2], 'BOX_CODER': 'PointResidualCoder',
+                              'BOX_CODER_CONFIG': {'use_mean_size': True,
+                                                   'mean_size': [[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]]}},
+            'LOSS_CONFIG': {'LOSS_REG': 'WeightedSmoothL1Loss',
+                            'LOSS_WEIGHTS': {'point_cls_weight': 1.0, 'point_box_weight': 2.0,
+                                             'code_weights': [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}}}   # as tests/golden/gen_head_fixtures.py
+
+
 def scene_boxes(B, M, seed):
     rng = np.random.default_rng(seed)
     gt = np.zeros((B, M, 8), dtype=np.float32)
@@ -42,7 +51,6 @@ def scene_boxes(B, M, seed):
 
 def test_point_head_targets_on_gpu_match_reference_fixture(dev):
     """points_in_boxes HIP kernel + batched target assignment == the reference's labels (oracle-backed fixture)."""
-    from tests.test_head import HEAD_CFG
     ref = np.load(os.path.join(G, "ref_head.npz"))
     head = PointHeadBox(num_class=3, input_channels=16, model_cfg=HEAD_CFG)
     head.load_state_dict({k[len("state."):]: torch.from_numpy(ref[k]) for k in ref.files if k.startswith("state.")})
@@ -113,3 +121,25 @@ def test_detector_eval_returns_nms_filtered_predictions(dev):
         iou = iu.boxes_iou_bev(d['pred_boxes'].contiguous(), d['pred_boxes'].contiguous())
         iou.fill_diagonal_(0)
         assert float(iou.max()) <= 0.1 + 1e-4                # survivors do not overlap beyond NMS_THRESH
+
+
+def test_heatmap_head_fused_inference_equals_torch_layers(dev):
+    """pdm_bev_depthwise3x3 + the per-cell MFMA row kernels against the torch convolutions of the same module, on a
+    channels-last grid like the neck's (with empty cells and a border)."""
+    torch.manual_seed(3)
+    head = build_pdm_ssd().dense_head.to(dev).eval()
+    for m in head.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    x = torch.randn(3, 200, 176, 128, device=dev) * (torch.rand(3, 200, 176, 1, device=dev) < 0.3)
+    sf = x.permute(0, 3, 1, 2)                                   # (B, C, H, W) view of channels-last storage
+    with torch.no_grad():
+        a = head({'spatial_features': sf})['bev_heatmap'].clone()
+        la = head.forward_ret_dict['hm_logits'].clone()
+        assert head._pdm_fused_cache['pw'][1] is not None
+        head.use_fused = False
+        b = head({'spatial_features': sf})['bev_heatmap']
+        lb = head.forward_ret_dict['hm_logits']
+    assert tuple(a.shape) == (3, 3, 200, 176)
+    torch.testing.assert_close(la, lb, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)

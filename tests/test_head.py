@@ -162,6 +162,7 @@ def test_detector_registry_and_module_slots():
     assert [type(m).__name__ for m in model.module_list] == ['PointNet2MSG', 'PDMNeck', 'PDMHeatmapHead', 'PointHeadBox']
     assert model.backbone_3d.num_point_features == 128 and model.map_to_bev_module.num_bev_features == 128
     assert model.point_head.cls_layers[0].in_features == 128 and model.dense_head.shared_conv[0].in_channels == 128
+    assert model.dense_head.shared_conv[0].groups == 128 and model.dense_head.shared_conv[3].out_channels == 64   # separable block
     assert model.vfe is None and model.roi_head is None and int(model.global_step) == 0
     keys = set(model.state_dict())
     assert {'backbone_3d.SA_modules.0.mlps.0.0.weight', 'map_to_bev_module.proj.0.weight', 'dense_head.hm.2.bias',

@@ -7,7 +7,8 @@ Collection (separate passes, --kernel-trace only; MI355X_MICROARCH.md "HBM" / "r
         python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --serial
     rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- \
         python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --serial
-    python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write profiles/rNN_pmc_traffic.json [command] [batch points clouds]
+bench.py attaches the file's numbers to a run only when batch / points / clouds match (default 32 16384 uniform).
 
 Correction (gfx950): FETCH_SIZE tallies each 128-byte read request at 64 B, so read bytes = 2 * FETCH_SIZE KiB;
 WRITE_SIZE is exact.  bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of each kernel
@@ -53,7 +54,9 @@ def main():
         kernels[k] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KiB_mean": round(fm, 1), "WRITE_SIZE_KiB_mean": round(wm, 1),
                       "hbm_bytes_per_launch_corrected": int((2 * fm + wm) * 1024),
                       "TCC_EA0_ATOMIC_mean": round(sum(a) / len(a), 1) if a else 0.0}
-    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum (separate passes) -- " + cmd,
+    shape = {"batch": int(sys.argv[5]) if len(sys.argv) > 5 else 32, "points": int(sys.argv[6]) if len(sys.argv) > 6 else 16384,
+             "clouds": sys.argv[7] if len(sys.argv) > 7 else "uniform"}
+    doc = {"shape": shape, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum (separate passes) -- " + cmd,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
            "kernels": kernels}
     with open(out, "w") as fh:
