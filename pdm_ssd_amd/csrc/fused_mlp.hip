@@ -1112,6 +1112,9 @@ __global__ __launch_bounds__(256) void sa_reg_packed_kernel(SaArgs a, const int2
 
 int rows_gemm_launch(void *stream, int rows, int cin, const float *in_pm, int k0, int c1, const float *wpack,
                      const float *bias, int relu_last, float *out_pm, int out_stride, int cout);   // rows_gemm.hip
+int rows_chain_launch(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims, const float *wpack,
+                      const float *bias, int relu_last, float *out_pm, int out_stride, int cout, int *launched);   // rows_chain.hip
+static int g_fused_chain = 1;       // 0: many-row MLPs go through the general chain kernel instead of rows_chain.hip
 int fp_pre_gemm_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
                        const float *skip_pm, const int *idx, const float *weight, int k1, int c2,
                        const float *wpack, const float *bias, float *out_pm, int out_stride, int cout);
@@ -1195,6 +1198,7 @@ static void allow_lds(const void *fn, size_t bytes) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) done.insert(fn);
 }
 extern "C" int pdm_tune_fused_lds_cap(int bytes) { const int old = g_fused_lds_cap; if (bytes >= 16 * 1024 && bytes <= 160 * 1024) g_fused_lds_cap = bytes; return old; }
+extern "C" int pdm_tune_fused_chain(int on) { const int old = g_fused_chain; g_fused_chain = on != 0; return old; }
 extern "C" int pdm_tune_fused_gemm(int on) { const int old = g_fused_gemm; g_fused_gemm = on != 0; return old; }
 extern "C" int pdm_tune_fused_reg(int on) { const int old = g_fused_reg; g_fused_reg = on != 0; return old; }
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
@@ -1418,6 +1422,16 @@ extern "C" int pdm_rows_mlp_fused(void *stream, int rows, int cin, const float *
                                   const int *dims, const float *wpack, const float *bias, int relu_last,
                                   float *out_pm, int out_stride, int cout) {
     PDM_REQUIRE(rows >= 0 && cin >= 1, PDM_E_BADARG, "rows_mlp_fused: rows=%d cin=%d", rows, cin);
+    if (g_fused_chain && dims && in_pm && wpack && bias && out_pm && cout > 0 && nlayers >= 1 && nlayers <= 3 && cout <= dims[nlayers] &&
+        cout <= out_stride && out_stride % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(out_pm) | reinterpret_cast<uintptr_t>(wpack) | reinterpret_cast<uintptr_t>(bias) |
+          reinterpret_cast<uintptr_t>(in_pm)) & 15) == 0) {
+        // many rows, widths that fit the register-resident chain (rows_chain.hip): the hybrid head's MLPs
+        int launched = 0;
+        const int rc = rows_chain_launch(stream, rows, cin, in_pm, nlayers, dims, wpack, bias, relu_last, out_pm, out_stride, cout,
+                                         &launched);
+        if (rc || launched) return rc;
+    }
     if (g_fused_gemm && nlayers == 1 && dims && dims[0] % 16 == 0 && dims[1] % 16 == 0 && dims[0] >= cin && dims[0] >= 32 &&
         dims[1] >= 64 && (long long)((rows + 127) / 128) * ((dims[1] + 127) / 128) >= 256 && in_pm && wpack && bias && out_pm && cout > 0 && cout <= dims[1] && cout <= out_stride &&
         out_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(out_pm) | reinterpret_cast<uintptr_t>(wpack) |
