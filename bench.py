@@ -69,7 +69,7 @@ def make_batch(B, N, kind, seed0, device):
 
 def algorithmic_bytes(name, a):
     """SURVEY.md section 8 D4 formulas; `a` = the integer/float arguments of the C-ABI call."""
-    if name in ("pdm_ball_query", "pdm_ball_query_grid"):
+    if name in ("pdm_ball_query", "pdm_ball_query_grid", "pdm_ball_query_grid_prebuilt"):
         b, n, m, _r, ns = a[:5]
         return b * (12 * n + 12 * m + 4 * m * ns)
     if name == "pdm_group_concat":
@@ -85,7 +85,7 @@ def algorithmic_bytes(name, a):
     if name in ("pdm_furthest_point_sampling", "pdm_furthest_point_sampling_ws"):
         b, n, m = a[:3]
         return b * (12 * n + 4 * m)
-    if name in ("pdm_three_nn", "pdm_three_nn_grid"):
+    if name in ("pdm_three_nn", "pdm_three_nn_grid", "pdm_three_nn_grid_prebuilt"):
         b, n, m = a[:3]
         return b * (12 * n + 12 * m + 24 * n)
     if name == "pdm_three_interpolate":
@@ -183,10 +183,12 @@ def reference_op_section(backbone, points, B, iters=5):
         for g in m.groupers:
             plan.append((g.radius, g.nsample, xyz, new_xyz, f, xyz.transpose(1, 2).contiguous()))
         xyz = new_xyz
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
     with OpTimer() as t:
         for it in range(iters + 1):
             if it == 1:
                 t.records.clear()  # first pass = warm-up
+            ext.GRID_CACHE.entries.clear()   # every pass is a new batch: one grid build per SA level, shared by its two radii
             for radius, ns, x, nx, f, xt in plan:
                 idx = pu.ball_query(radius, ns, x, nx)
                 pu.grouping_operation(xt, idx)
@@ -198,21 +200,23 @@ def reference_op_section(backbone, points, B, iters=5):
     # ball query is not bandwidth-bound as the reference states it: N * M distance evaluations of 8 flop per call
     # (SURVEY D3); the grid form visits only the cells a ball can reach, so its rate is quoted in reference-form
     # evaluations per second ("effective") next to the exhaustive scan's real rate
-    evals = {"pdm_ball_query": 0.0, "pdm_ball_query_grid": 0.0}
+    evals = {"pdm_ball_query": 0.0, "pdm_ball_query_grid_prebuilt": 0.0}
     for radius, ns, x, nx, f, xt in plan:
         n, m = x.shape[1], nx.shape[1]
-        evals["pdm_ball_query_grid" if 2048 <= n <= 131072 else "pdm_ball_query"] += float(B) * n * m
+        evals["pdm_ball_query_grid_prebuilt" if 2048 <= n <= 131072 else "pdm_ball_query"] += float(B) * n * m
     bq = {}
     for o in ops:
         if o["op"] in evals and o["ms_per_step"] > 0:
-            rate = evals[o["op"]] / (o["ms_per_step"] * 1e-3)
+            build_ms = sum(x["ms_per_step"] for x in ops if x["op"] == "pdm_grid_build") if "grid" in o["op"] else 0.0
+            rate = evals[o["op"]] / ((o["ms_per_step"] + build_ms) * 1e-3)
             bq[o["op"]] = {"reference_form_evals_per_step": evals[o["op"]], "Gevals_per_s": round(rate / 1e9, 1),
                            "frac_of_valu_peak_at_8_flop_per_eval": round(rate * 8 / 1e12 / VALU_F32_PEAK_TFLOPS, 4),
-                           "kind": "effective (grid-pruned, same indices)" if o["op"].endswith("grid") else "executed (exhaustive scan)"}
+                           "kind": "effective (grid-pruned incl. its share of pdm_grid_build, same indices)" if "grid" in o["op"] else "executed (exhaustive scan)"}
     return {"ops": ops, "ms_per_step": round(ms, 4), "alg_MB_per_step": round(mb, 2),
             "GBps": round(mb / ms, 1), "frac_of_hbm_peak": round(mb / ms / HBM_PEAK_GBS, 4),
             "ball_query_distance_evals": bq,
-            "note": "8 ball_query + 16 group_points launches at bs=%d; target >= 0.60" % B}, gp
+            "note": "8 ball_query (+ 2 grid builds, one per level that uses the grid) + 16 group_points launches at bs=%d; "
+                    "target >= 0.60" % B}, gp
 
 
 # ----------------------------------------------------------------------------- CPU baseline

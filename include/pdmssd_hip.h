@@ -157,6 +157,16 @@ int pdm_ball_query_grid(void *stream, int b, int n, int m, float radius, int nsa
                         const float *new_xyz, const float *xyz, int *idx, void *workspace,
                         size_t workspace_bytes);
 
+/* The grid half and the query half of the call above as separate entry points, so ONE grid serves every query over the
+ * same point set: both radii of an SA level (pointnet2_modules.py:37 loops its scales over the same xyz) and the
+ * three_nn of the FP module whose known set it is.  Any grid gives exact results; radius_hint only sizes the cells
+ * (0 = about two points per occupied cell, the nearest-neighbour setting).  workspace = pdm_ball_query_grid_workspace_bytes(b, n). */
+int pdm_grid_build(void *stream, int b, int n, float radius_hint, const float *xyz, void *workspace, size_t workspace_bytes);
+int pdm_ball_query_grid_prebuilt(void *stream, int b, int n, int m, float radius, int nsample, const float *new_xyz, int *idx,
+                                 const void *workspace, size_t workspace_bytes);
+int pdm_three_nn_grid_prebuilt(void *stream, int b, int n, int m, const float *unknown, float *dist2, int *idx,
+                               const void *workspace, size_t workspace_bytes);
+
 /* Grid-accelerated form of pdm_three_nn: identical dist2 / idx, bit for bit; needs m >= 1 and a
  * caller-provided workspace of pdm_three_nn_grid_workspace_bytes(b, m) bytes. */
 size_t pdm_three_nn_grid_workspace_bytes(int b, int m);

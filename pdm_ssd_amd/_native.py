@@ -22,6 +22,9 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGNATURES = {
     "pdm_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp],
     "pdm_ball_query_grid": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_grid_build": [_i, _i, _f, _vp, _vp, ctypes.c_size_t],
+    "pdm_ball_query_grid_prebuilt": [_i, _i, _i, _f, _i, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_three_nn_grid_prebuilt": [_i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_three_nn_grid": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdm_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
@@ -73,6 +76,7 @@ _SIGNATURES = {
     "pdm_tune_fused_wg_per_cu": None,
     "pdm_tune_fused_lds_cap": None,
     "pdm_tune_fused_reg": None,
+    "pdm_tune_bq_quad": None,
     "pdm_tune_fused_gemm": None,
     "pdm_tune_fused_chain": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],

@@ -191,6 +191,134 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
 
 constexpr int BQG_QWAVES = 4;
 
+struct BqGrid {
+    float minx, miny, minz, inv_h;
+    int gx, gy, gz;
+    const int *__restrict__ cell_start;
+    const float4 *__restrict__ sorted;
+};
+
+// One centre by a whole wave (any number of candidates): rows of the search box -> candidate numbering -> distance
+// test -> hits ordered by index through registers (<= 64 candidates in <= 64 rows) or the wave's LDS bitmap.
+__device__ __forceinline__ void bq_centre_wave(const BqGrid &G, float cx, float cy, float cz, float radius2, float absr,
+                                               int nsample, int wpl, unsigned int *bm, int *out, int lane) {
+    const float rx = search_halfwidth(cx, absr), ry = search_halfwidth(cy, absr), rz = search_halfwidth(cz, absr);
+    const int x0 = cell_of(cx - rx, G.minx, G.inv_h, G.gx), x1 = cell_of(cx + rx, G.minx, G.inv_h, G.gx);
+    const int y0 = cell_of(cy - ry, G.miny, G.inv_h, G.gy), y1 = cell_of(cy + ry, G.miny, G.inv_h, G.gy);
+    const int z0 = cell_of(cz - rz, G.minz, G.inv_h, G.gz), z1 = cell_of(cz + rz, G.minz, G.inv_h, G.gz);
+    // The (z, y) rows of the search box are x-contiguous runs of the sorted array.  All run bounds are
+    // fetched at once (lane r = row r) and the candidates of all runs are numbered consecutively.
+    const int ny = y1 - y0 + 1;
+    const int nrows = ny * (z1 - z0 + 1);
+    int hits = 0;          // wave-uniform
+    bool used_bitmap = false;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {  // one pass unless the box spans more than 64 rows
+        const int r = r0 + lane;
+        int beg = 0, cntr = 0;
+        if (r < nrows) {
+            const int base = ((z0 + r / ny) * G.gy + (y0 + r % ny)) * G.gx;
+            beg = G.cell_start[base + x0];
+            cntr = G.cell_start[base + x1 + 1] - beg;
+        }
+        int incl = cntr;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;  // wave-uniform
+        const int rows_here = min(64, nrows - r0);
+        const int start = incl - cntr;   // exclusive prefix: first candidate number of this lane's row
+        const bool single = nrows <= 64 && total <= 64;  // every candidate of this centre sits in one lane
+        for (int t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count
+            const int t = t0 + lane;
+            bool hit = false;
+            int k = 0x7FFFFFFF;
+            // candidate t lives in the LAST row whose first candidate number is <= t (empty rows share their
+            // successor's number and lose to it): a uniform walk over the rows with scalar broadcasts, no LDS
+            int rbeg = 0, rstart = 0;
+            for (int r = 0; r < rows_here; ++r) {
+                const int st = __builtin_amdgcn_readlane(start, r), bg = __builtin_amdgcn_readlane(beg, r);
+                const bool ge = t >= st;
+                rbeg = ge ? bg : rbeg;
+                rstart = ge ? st : rstart;
+            }
+            if (t < total) {
+                const float4 q = G.sorted[rbeg + (t - rstart)];
+                const float d2 = sqdist(cx - q.x, cy - q.y, cz - q.z);
+                hit = d2 < radius2;
+                if (hit) k = __float_as_int(q.w);
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (single) {
+                // fast path, registers only: a hit's output slot is the number of hits with a smaller index
+                hits = __popcll(hm);
+                if (hits > 0) {
+                    int pos = 0, kmin = 0x7FFFFFFF;
+                    for (unsigned long long mrest = hm; mrest != 0ull; mrest &= mrest - 1ull) {
+                        const int other = __builtin_amdgcn_readlane(k, __ffsll((long long)mrest) - 1);
+                        pos += other < k ? 1 : 0;
+                        kmin = min(kmin, other);
+                    }
+                    if (hit && pos < nsample) out[pos] = k;
+                    for (int l = hits + lane; l < nsample; l += 64) out[l] = kmin;  // ball_query_gpu.cu:41-45
+                }
+            } else {
+                if (hit) atomicOr(&bm[k >> 5], 1u << (k & 31));
+                hits += __popcll(hm);
+                used_bitmap = true;
+            }
+        }
+    }
+    if (!used_bitmap || hits == 0) return;  // empty ball: row stays as the caller zero-filled it (pointnet2_utils.py:218)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // LDS atomics of this wave are done before it reads them back
+
+    // general path: lane owns bitmap words [lane*wpl, (lane+1)*wpl) = indices ascending with lane
+    unsigned int *mine = bm + lane * wpl;
+    int cnt = 0;
+    for (int w = 0; w < wpl; ++w) cnt += __popc(mine[w]);
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    int pos = incl - cnt;  // hits in lower lanes
+    int first_local = -1;
+    if (cnt > 0) {
+        for (int w = 0; w < wpl; ++w) {
+            unsigned int bits = mine[w];
+            if (bits == 0u) continue;
+            mine[w] = 0u;  // leave the bitmap clean for the next centre
+            if (first_local < 0) first_local = (lane * wpl + w) * 32 + (__ffs(bits) - 1);
+            while (bits != 0u && pos < nsample) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1u;
+                out[pos++] = (lane * wpl + w) * 32 + bit;
+            }
+        }
+    }
+    // slots beyond the hit count hold the first hit (ball_query_gpu.cu:41-45)
+    const unsigned long long have = __ballot(cnt > 0);
+    const int fl = __ffsll((long long)have) - 1;
+    const int first = __shfl(first_local, fl, 64);
+    for (int l = hits + lane; l < nsample; l += 64) out[l] = first;
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ BqGrid bq_grid_of(int b, int n, const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+                                             const float4 *__restrict__ sorted_all) {
+    const float *hp = hdr_all + (size_t)b * BQG_HDR;
+    BqGrid G;
+    G.minx = hp[0]; G.miny = hp[1]; G.minz = hp[2]; G.inv_h = hp[3];
+    G.gx = reinterpret_cast<const int *>(hp)[4]; G.gy = reinterpret_cast<const int *>(hp)[5];
+    G.gz = reinterpret_cast<const int *>(hp)[6];
+    G.cell_start = cell_start_all + (size_t)b * (BQG_CAP + 1);
+    G.sorted = sorted_all + (size_t)b * n;
+    return G;
+}
+
+// One wave per centre (round 1's form; kept as the measured alternative: pdm_tune_bq_quad(0)).
 __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
     int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
     const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
@@ -200,124 +328,116 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int *bm = bitmap_all + (size_t)wave * wpl * 64;
     for (int w = lane; w < wpl * 64; w += 64) bm[w] = 0u;  // once; every centre leaves it clean
-
-    const float *hp = hdr_all + (size_t)b * BQG_HDR;
-    const float minx = hp[0], miny = hp[1], minz = hp[2], inv_h = hp[3];
-    const int gx = reinterpret_cast<const int *>(hp)[4], gy = reinterpret_cast<const int *>(hp)[5],
-              gz = reinterpret_cast<const int *>(hp)[6];
-    const int *__restrict__ cell_start = cell_start_all + (size_t)b * (BQG_CAP + 1);
-    const float4 *__restrict__ sorted = sorted_all + (size_t)b * n;
+    const BqGrid G = bq_grid_of(b, n, hdr_all, cell_start_all, sorted_all);
     const float radius2 = radius * radius;  // ball_query_gpu.cu:29
     const float absr = fabsf(radius);
-
     // a wave walks centres j, j + stride, ...: the bitmap is cleared once per wave and left clean by every centre
     for (int j = blockIdx.x * BQG_QWAVES + wave; j < m; j += gridDim.x * BQG_QWAVES) {
         const float *c3 = new_xyz + ((size_t)b * m + j) * 3;
+        bq_centre_wave(G, c3[0], c3[1], c3[2], radius2, absr, nsample, wpl, bm, idx + ((size_t)b * m + j) * nsample, lane);
+    }
+}
+
+// Four centres per wave: a centre with at most 16 rows in its search box and at most 16 candidates in them (the
+// common case once the cell follows the radius: a handful of candidates per ball) is answered by ONE 16-lane DPP
+// row — run bounds, prefix sum, candidate -> run resolution, distance test and the by-index ranking of the hits
+// are row-local (row_shr / row_newbcast), so one pass of instructions serves four centres; a centre that does not
+// fit takes the whole-wave path above afterwards.  Same indices either way.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query4_kernel(
+    int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
+    const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+    const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
+    extern __shared__ unsigned int bitmap_all[];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    unsigned int *bm = bitmap_all + (size_t)wave * wpl * 64;
+    for (int w = lane; w < wpl * 64; w += 64) bm[w] = 0u;
+    const BqGrid G = bq_grid_of(b, n, hdr_all, cell_start_all, sorted_all);
+    const float radius2 = radius * radius;
+    const float absr = fabsf(radius);
+    const int nquads = (m + 3) / 4;
+    for (int jq = blockIdx.x * BQG_QWAVES + wave; jq < nquads; jq += gridDim.x * BQG_QWAVES) {
+        const int j = jq * 4 + q;
+        const bool live = j < m;
+        const float *c3 = new_xyz + ((size_t)b * m + (live ? j : m - 1)) * 3;
         const float cx = c3[0], cy = c3[1], cz = c3[2];
         const float rx = search_halfwidth(cx, absr), ry = search_halfwidth(cy, absr), rz = search_halfwidth(cz, absr);
-        const int x0 = cell_of(cx - rx, minx, inv_h, gx), x1 = cell_of(cx + rx, minx, inv_h, gx);
-        const int y0 = cell_of(cy - ry, miny, inv_h, gy), y1 = cell_of(cy + ry, miny, inv_h, gy);
-        const int z0 = cell_of(cz - rz, minz, inv_h, gz), z1 = cell_of(cz + rz, minz, inv_h, gz);
-        int *out = idx + ((size_t)b * m + j) * nsample;
-
-        // The (z, y) rows of the search box are x-contiguous runs of the sorted array.  All run bounds are
-        // fetched at once (lane r = row r) and the candidates of all runs are numbered consecutively.
+        const int x0 = cell_of(cx - rx, G.minx, G.inv_h, G.gx), x1 = cell_of(cx + rx, G.minx, G.inv_h, G.gx);
+        const int y0 = cell_of(cy - ry, G.miny, G.inv_h, G.gy), y1 = cell_of(cy + ry, G.miny, G.inv_h, G.gy);
+        const int z0 = cell_of(cz - rz, G.minz, G.inv_h, G.gz), z1 = cell_of(cz + rz, G.minz, G.inv_h, G.gz);
         const int ny = y1 - y0 + 1;
         const int nrows = ny * (z1 - z0 + 1);
-        int hits = 0;          // wave-uniform
-        bool used_bitmap = false;
-        for (int r0 = 0; r0 < nrows; r0 += 64) {  // one pass unless the box spans more than 64 rows
-            const int r = r0 + lane;
-            int beg = 0, cntr = 0;
-            if (r < nrows) {
-                const int base = ((z0 + r / ny) * gy + (y0 + r % ny)) * gx;
-                beg = cell_start[base + x0];
-                cntr = cell_start[base + x1 + 1] - beg;
-            }
-            int incl = cntr;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            const int total = __shfl(incl, 63, 64);
-            if (total == 0) continue;  // wave-uniform
-            const int rows_here = min(64, nrows - r0);
-            const int start = incl - cntr;   // exclusive prefix: first candidate number of this lane's row
-            const bool single = nrows <= 64 && total <= 64;  // every candidate of this centre sits in one lane
-            for (int t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count
-                const int t = t0 + lane;
-                bool hit = false;
-                int k = 0x7FFFFFFF;
-                // candidate t lives in the LAST row whose first candidate number is <= t (empty rows share their
-                // successor's number and lose to it): a uniform walk over the rows with scalar broadcasts, no LDS
-                int rbeg = 0, rstart = 0;
-                for (int r = 0; r < rows_here; ++r) {
-                    const int st = __builtin_amdgcn_readlane(start, r), bg = __builtin_amdgcn_readlane(beg, r);
-                    const bool ge = t >= st;
-                    rbeg = ge ? bg : rbeg;
-                    rstart = ge ? st : rstart;
-                }
-                if (t < total) {
-                    const float4 q = sorted[rbeg + (t - rstart)];
-                    const float d2 = sqdist(cx - q.x, cy - q.y, cz - q.z);
-                    hit = d2 < radius2;
-                    if (hit) k = __float_as_int(q.w);
-                }
-                const unsigned long long hm = __ballot(hit);
-                if (single) {
-                    // fast path, registers only: a hit's output slot is the number of hits with a smaller index
-                    hits = __popcll(hm);
-                    if (hits > 0) {
-                        int pos = 0, kmin = 0x7FFFFFFF;
-                        for (unsigned long long mrest = hm; mrest != 0ull; mrest &= mrest - 1ull) {
-                            const int other = __builtin_amdgcn_readlane(k, __ffsll((long long)mrest) - 1);
-                            pos += other < k ? 1 : 0;
-                            kmin = min(kmin, other);
-                        }
-                        if (hit && pos < nsample) out[pos] = k;
-                        for (int l = hits + lane; l < nsample; l += 64) out[l] = kmin;  // ball_query_gpu.cu:41-45
-                    }
-                } else {
-                    if (hit) atomicOr(&bm[k >> 5], 1u << (k & 31));
-                    hits += __popcll(hm);
-                    used_bitmap = true;
-                }
-            }
+        bool fast = live && nrows <= 16;
+        int beg = 0, cntr = 0;
+        if (fast && li < nrows) {
+            const int base = ((z0 + li / ny) * G.gy + (y0 + li % ny)) * G.gx;
+            beg = G.cell_start[base + x0];
+            cntr = G.cell_start[base + x1 + 1] - beg;
         }
-        if (!used_bitmap || hits == 0) continue;  // empty ball: row stays as the caller zero-filled it (pointnet2_utils.py:218)
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // LDS atomics of this wave are done before it reads them back
-
-        // general path: lane owns bitmap words [lane*wpl, (lane+1)*wpl) = indices ascending with lane
-        unsigned int *mine = bm + lane * wpl;
-        int cnt = 0;
-        for (int w = 0; w < wpl; ++w) cnt += __popc(mine[w]);
-        int incl = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+        // inclusive prefix sum inside the 16-lane row (zeros shift in)
+        int incl = cntr;
+        incl += dpp_i<0x111>(0, incl);   // row_shr:1
+        incl += dpp_i<0x112>(0, incl);   // row_shr:2
+        incl += dpp_i<0x114>(0, incl);   // row_shr:4
+        incl += dpp_i<0x118>(0, incl);   // row_shr:8
+        const int total = dpp_i<0x15F>(0, incl);   // row_newbcast:15
+        fast = fast && total <= 16;
+        const int start = incl - cntr;
+        // candidate li of this centre lives in the last run whose first candidate number is <= li
+        const int maxrows = __builtin_amdgcn_readfirstlane(
+            max(max(__builtin_amdgcn_readlane(fast ? nrows : 0, 0), __builtin_amdgcn_readlane(fast ? nrows : 0, 16)),
+                max(__builtin_amdgcn_readlane(fast ? nrows : 0, 32), __builtin_amdgcn_readlane(fast ? nrows : 0, 48))));
+        int rbeg = 0, rstart = 0;
+#define BQ_RUN(R)                                                                                  \
+        if (R < maxrows) {                                                                         \
+            const int st = dpp_i<0x150 + R>(0, start), bg = dpp_i<0x150 + R>(0, beg);              \
+            const bool ge = li >= st && R < nrows;                                                 \
+            rbeg = ge ? bg : rbeg;                                                                 \
+            rstart = ge ? st : rstart;                                                             \
         }
-        int pos = incl - cnt;  // hits in lower lanes
-        int first_local = -1;
-        if (cnt > 0) {
-            for (int w = 0; w < wpl; ++w) {
-                unsigned int bits = mine[w];
-                if (bits == 0u) continue;
-                mine[w] = 0u;  // leave the bitmap clean for the next centre
-                if (first_local < 0) first_local = (lane * wpl + w) * 32 + (__ffs(bits) - 1);
-                while (bits != 0u && pos < nsample) {
-                    const int bit = __ffs(bits) - 1;
-                    bits &= bits - 1u;
-                    out[pos++] = (lane * wpl + w) * 32 + bit;
-                }
-            }
+        BQ_RUN(0) BQ_RUN(1) BQ_RUN(2) BQ_RUN(3) BQ_RUN(4) BQ_RUN(5) BQ_RUN(6) BQ_RUN(7)
+        BQ_RUN(8) BQ_RUN(9) BQ_RUN(10) BQ_RUN(11) BQ_RUN(12) BQ_RUN(13) BQ_RUN(14) BQ_RUN(15)
+#undef BQ_RUN
+        int k = 0x7FFFFFFF;
+        if (fast && li < total) {
+            const float4 p4 = G.sorted[rbeg + (li - rstart)];
+            const float d2 = sqdist(cx - p4.x, cy - p4.y, cz - p4.z);
+            if (d2 < radius2) k = __float_as_int(p4.w);
         }
-        // slots beyond the hit count hold the first hit (ball_query_gpu.cu:41-45)
-        const unsigned long long have = __ballot(cnt > 0);
-        const int fl = __ffsll((long long)have) - 1;
-        const int first = __shfl(first_local, fl, 64);
-        for (int l = hits + lane; l < nsample; l += 64) out[l] = first;
-        __builtin_amdgcn_wave_barrier();
+        // rank of a hit = number of hits of its centre with a smaller index; kmin = the first hit
+        const int maxtot = __builtin_amdgcn_readfirstlane(
+            max(max(__builtin_amdgcn_readlane(fast ? total : 0, 0), __builtin_amdgcn_readlane(fast ? total : 0, 16)),
+                max(__builtin_amdgcn_readlane(fast ? total : 0, 32), __builtin_amdgcn_readlane(fast ? total : 0, 48))));
+        int pos = 0, kmin = 0x7FFFFFFF, hits = 0;
+#define BQ_RANK(R)                                                \
+        if (R < maxtot) {                                         \
+            const int other = dpp_i<0x150 + R>(0x7FFFFFFF, k);    \
+            pos += other < k ? 1 : 0;                             \
+            hits += other != 0x7FFFFFFF ? 1 : 0;                  \
+            kmin = min(kmin, other);                              \
+        }
+        BQ_RANK(0) BQ_RANK(1) BQ_RANK(2) BQ_RANK(3) BQ_RANK(4) BQ_RANK(5) BQ_RANK(6) BQ_RANK(7)
+        BQ_RANK(8) BQ_RANK(9) BQ_RANK(10) BQ_RANK(11) BQ_RANK(12) BQ_RANK(13) BQ_RANK(14) BQ_RANK(15)
+#undef BQ_RANK
+        if (fast && hits > 0) {
+            int *out = idx + ((size_t)b * m + j) * nsample;
+            if (k != 0x7FFFFFFF && pos < nsample) out[pos] = k;
+            for (int l = hits + li; l < nsample; l += 16) out[l] = kmin;   // ball_query_gpu.cu:41-45
+        }
+        // centres that did not fit a DPP row: whole-wave path, one after the other
+        unsigned long long slow = __ballot(live && !fast) & 0x0001000100010001ull;
+        while (slow != 0ull) {   // wave-uniform
+            const int src = __ffsll((long long)slow) - 1;
+            slow &= slow - 1ull;
+            const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cx), src));
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), src));
+            const float sz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cz), src));
+            bq_centre_wave(G, sx, sy, sz, radius2, absr, nsample, wpl, bm, idx + ((size_t)b * m + jq * 4 + (src >> 4)) * nsample, lane);
+        }
     }
 }
 
@@ -338,6 +458,56 @@ extern "C" size_t pdm_ball_query_grid_workspace_bytes(int b, int n) {
     return grid_workspace_bytes(b, n);
 }
 
+static int g_bq_quad = 1;   // 0: one wave per centre (round 1's query kernel)
+extern "C" int pdm_tune_bq_quad(int on) { const int old = g_bq_quad; g_bq_quad = on != 0; return old; }
+
+// The search grid of a point set, built once and shared by every query over it: both radii of an SA level's ball
+// queries and the three-NN of the FP module whose known set it is.  Any grid gives exact answers (the cell size only
+// decides how many candidates a query visits); radius_hint sizes the cells for ball queries of about that radius,
+// radius_hint == 0 asks for about two points per occupied cell (nearest-neighbour use).
+extern "C" int pdm_grid_build(void *stream, int b, int n, float radius_hint, const float *xyz, void *workspace,
+                              size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0, PDM_E_BADARG, "grid_build: negative size b=%d n=%d", b, n);
+    if (b == 0 || n == 0) return 0;
+    PDM_REQUIRE(xyz && workspace, PDM_E_BADARG, "grid_build: null pointer");
+    PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "grid_build: b=%d exceeds grid", b);
+    PDM_REQUIRE(workspace_bytes >= grid_workspace_bytes(b, n), PDM_E_BADARG, "grid_build: workspace of %zu bytes, need %zu",
+                workspace_bytes, grid_workspace_bytes(b, n));
+    const GridWs ws = grid_carve(workspace, b, n);
+    return launch_grid_build(as_stream(stream), b, n, radius_hint, radius_hint == 0.0f ? (n / 2 > 8 ? n / 2 : 8) : BQG_CAP, xyz, ws);
+}
+
+static int bq_query_launch(void *stream, int b, int n, int m, float radius, int nsample, const float *new_xyz, int *idx,
+                           const GridWs &ws) {
+    const int wpl = (n + 2047) / 2048;  // bitmap words per lane: 64 lanes x wpl words x 32 bits >= n
+    const size_t lds = (size_t)BQG_QWAVES * wpl * 64 * sizeof(unsigned int);
+    PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "ball_query_grid: n=%d needs %zu bytes of LDS bitmap", n, lds);
+    const int units = g_bq_quad ? divup(m, 4) : m;           // work items per sample: quads of centres or centres
+    const int per_sample = divup(units, BQG_QWAVES);
+    const int cap = (256 * 16 + b - 1) / b;  // about 16 four-wave workgroups per CU in total; waves loop beyond that
+    dim3 grid(per_sample < cap ? per_sample : cap, b);
+    if (g_bq_quad)
+        hipLaunchKernelGGL(bq_grid_query4_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius, nsample, wpl,
+                           new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
+    else
+        hipLaunchKernelGGL(bq_grid_query_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius, nsample, wpl,
+                           new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
+    return check_launch("ball_query_grid(query)");
+}
+
+// Ball query against a grid pdm_grid_build left in `workspace` (same b, n): identical indices to pdm_ball_query.
+extern "C" int pdm_ball_query_grid_prebuilt(void *stream, int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                            int *idx, const void *workspace, size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, PDM_E_BADARG,
+                "ball_query_grid: negative size b=%d n=%d m=%d nsample=%d", b, n, m, nsample);
+    if (b == 0 || m == 0 || nsample == 0 || n == 0) return 0;
+    PDM_REQUIRE(new_xyz && idx && workspace, PDM_E_BADARG, "ball_query_grid: null pointer");
+    PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "ball_query_grid: b=%d exceeds grid", b);
+    PDM_REQUIRE(workspace_bytes >= grid_workspace_bytes(b, n), PDM_E_BADARG, "ball_query_grid: workspace of %zu bytes, need %zu",
+                workspace_bytes, grid_workspace_bytes(b, n));
+    return bq_query_launch(stream, b, n, m, radius, nsample, new_xyz, idx, grid_carve(const_cast<void *>(workspace), b, n));
+}
+
 extern "C" int pdm_ball_query_grid(void *stream, int b, int n, int m, float radius, int nsample,
                                    const float *new_xyz, const float *xyz, int *idx, void *workspace,
                                    size_t workspace_bytes) {
@@ -349,16 +519,8 @@ extern "C" int pdm_ball_query_grid(void *stream, int b, int n, int m, float radi
     PDM_REQUIRE(workspace_bytes >= pdm_ball_query_grid_workspace_bytes(b, n), PDM_E_BADARG,
                 "ball_query_grid: workspace of %zu bytes, need %zu", workspace_bytes,
                 pdm_ball_query_grid_workspace_bytes(b, n));
-    const int wpl = (n + 2047) / 2048;  // bitmap words per lane: 64 lanes x wpl words x 32 bits >= n
-    const size_t lds = (size_t)BQG_QWAVES * wpl * 64 * sizeof(unsigned int);
-    PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "ball_query_grid: n=%d needs %zu bytes of LDS bitmap", n, lds);
     const GridWs ws = grid_carve(workspace, b, n);
     int rc = launch_grid_build(as_stream(stream), b, n, radius, BQG_CAP, xyz, ws);
     if (rc) return rc;
-    const int per_sample = divup(m, BQG_QWAVES);
-    const int cap = (256 * 16 + b - 1) / b;  // about 16 four-wave workgroups per CU in total; waves loop beyond that
-    dim3 grid(per_sample < cap ? per_sample : cap, b);
-    hipLaunchKernelGGL(bq_grid_query_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius,
-                       nsample, wpl, new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
-    return check_launch("ball_query_grid(query)");
+    return bq_query_launch(stream, b, n, m, radius, nsample, new_xyz, idx, ws);
 }

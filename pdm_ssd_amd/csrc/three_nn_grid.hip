@@ -109,6 +109,23 @@ using namespace pdm;
 
 extern "C" size_t pdm_three_nn_grid_workspace_bytes(int b, int m) { return grid_workspace_bytes(b, m); }
 
+// three_nn against a grid of the KNOWN set that pdm_grid_build left in `workspace` (same b, m).
+extern "C" int pdm_three_nn_grid_prebuilt(void *stream, int b, int n, int m, const float *unknown, float *dist2, int *idx,
+                                          const void *workspace, size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0, PDM_E_BADARG, "three_nn_grid: negative size");
+    if (b == 0 || n == 0) return 0;
+    PDM_REQUIRE(m >= 1, PDM_E_BADARG, "three_nn_grid: m=%d (use pdm_three_nn for an empty known set)", m);
+    PDM_REQUIRE(unknown && dist2 && idx && workspace, PDM_E_BADARG, "three_nn_grid: null pointer");
+    PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "three_nn_grid: b=%d exceeds grid", b);
+    PDM_REQUIRE(workspace_bytes >= grid_workspace_bytes(b, m), PDM_E_BADARG,
+                "three_nn_grid: workspace of %zu bytes, need %zu", workspace_bytes, grid_workspace_bytes(b, m));
+    const GridWs ws = grid_carve(const_cast<void *>(workspace), b, m);
+    dim3 grid(divup(n, NNG_THREADS), b);
+    hipLaunchKernelGGL(three_nn_grid_kernel, grid, dim3(NNG_THREADS), 0, as_stream(stream), n, m, unknown, ws.hdr,
+                       ws.cell_start, ws.sorted, dist2, idx);
+    return check_launch("three_nn_grid");
+}
+
 extern "C" int pdm_three_nn_grid(void *stream, int b, int n, int m, const float *unknown,
                                  const float *known, float *dist2, int *idx, void *workspace,
                                  size_t workspace_bytes) {

@@ -47,11 +47,45 @@ GRID_MAX_N = 131072
 NN_GRID_MIN_M = 512
 
 
+class _GridCache:
+    """Search grids of recently seen point sets (pdm_grid_build), so the calls that search the same set share one
+    build: the two radii of an SA level's ball queries and the three_nn whose known set it is (SURVEY.md section 7:
+    "both MSG radii in one pass").  An entry belongs to one tensor OBJECT (weak reference) at one version: a new tensor
+    that happens to reuse the address, or an in-place write, misses.  Any grid gives exact results — the cell size
+    only decides how many candidates a query visits — so the first caller's radius sizes it."""
+    SIZE = 6
+
+    def __init__(self):
+        self.entries = []   # (weakref, version, b, n, stream, workspace)
+
+    def get(self, pts, b, n, radius_hint):
+        import weakref
+        stream = torch.cuda.current_stream(pts.device).cuda_stream
+        for e in self.entries:
+            if e[0]() is pts and e[1] == pts._version and e[2] == b and e[3] == n and e[4] == stream:
+                return e[5], e[6]
+        nbytes = _native.lib().pdm_ball_query_grid_workspace_bytes(b, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+        _run("pdm_grid_build", pts, b, n, float(radius_hint), pts.data_ptr(), ws.data_ptr(), nbytes)
+        self.entries.insert(0, (weakref.ref(pts), pts._version, b, n, stream, ws, nbytes))
+        del self.entries[self.SIZE:]
+        return ws, nbytes
+
+
+GRID_CACHE = _GridCache()
+SHARE_GRIDS = True   # False: every call builds its own grid (round 1's behaviour; A/B measurements)
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     _check("new_xyz", new_xyz, torch.float32); _check("xyz", xyz, torch.float32); _check("idx", idx, torch.int32)
     _numel_at_least("new_xyz", new_xyz, b * m * 3); _numel_at_least("xyz", xyz, b * n * 3)
     _numel_at_least("idx", idx, b * m * nsample)
     if GRID_MIN_N <= n <= GRID_MAX_N and b > 0 and m > 0:
+        if SHARE_GRIDS:
+            ws, nbytes = GRID_CACHE.get(xyz, b, n, radius)
+            _run("pdm_ball_query_grid_prebuilt", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), idx.data_ptr(),
+                 ws.data_ptr(), nbytes)
+            return 1
         nbytes = _native.lib().pdm_ball_query_grid_workspace_bytes(b, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
         _run("pdm_ball_query_grid", xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
@@ -120,6 +154,12 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     _numel_at_least("unknown", unknown, b * n * 3); _numel_at_least("known", known, b * m * 3)
     _numel_at_least("dist2", dist2, b * n * 3); _numel_at_least("idx", idx, b * n * 3)
     if NN_GRID_MIN_M <= m and b > 0 and n > 0:
+        if SHARE_GRIDS and GRID_MIN_N <= m <= GRID_MAX_N:
+            # (the same set is the source of the next SA level's ball queries: one grid for all three)
+            ws, nbytes = GRID_CACHE.get(known, b, m, 0.0)
+            _run("pdm_three_nn_grid_prebuilt", unknown, b, n, m, unknown.data_ptr(), dist2.data_ptr(), idx.data_ptr(),
+                 ws.data_ptr(), nbytes)
+            return
         nbytes = _native.lib().pdm_three_nn_grid_workspace_bytes(b, m)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=unknown.device)
         _run("pdm_three_nn_grid", unknown, b, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(),

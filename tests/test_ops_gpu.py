@@ -535,3 +535,64 @@ def test_group_points_grad_csr_form(oracle, dev, c, n, m, ns):
     hipops.group_points_grad_wrapper(B, c, n, m, ns, T(go, dev), T(idx, dev), gp)
     scale = float(np.abs(want).max())
     np.testing.assert_allclose(gp.cpu().numpy() + 1.0, want, rtol=1e-4, atol=1e-5 * max(scale, 1.0) + 1e-4)
+
+
+def test_shared_search_grid_cache_is_safe(oracle, dev):
+    """One grid per point set serves both MSG radii and the three_nn over it (pointnet2_batch_hip.GRID_CACHE); the
+    cache must miss after an in-place write and for a NEW tensor that reuses the freed address."""
+    from pdm_ssd_amd import _native
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
+    xyz_np = clouds("lidar", 2, 4096, seed=201)
+    xyz = T(xyz_np, dev)
+    new_xyz = xyz[:, :512].contiguous()
+    builds = []
+    orig = _native.call
+
+    def counting(name, *a):
+        if name == "pdm_grid_build":
+            builds.append(name)
+        return orig(name, *a)
+    _native.call = counting
+    try:
+        ext.GRID_CACHE.entries.clear()
+        for r, ns in ((0.3, 16), (1.2, 32)):
+            got = pu.ball_query(r, ns, xyz, new_xyz)
+            np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(r, ns, xyz_np, xyz_np[:, :512].copy()))
+        d, i = pu.three_nn(new_xyz, xyz)                      # known set = the same tensor: third user of the grid
+        rd, ri = oracle.three_nn(xyz_np[:, :512].copy(), xyz_np)
+        np.testing.assert_array_equal(i.cpu().numpy(), ri)
+        assert len(builds) == 1
+        xyz.add_(0.25)                                        # in-place write: version changes, the grid is rebuilt
+        moved = xyz_np + np.float32(0.25)
+        got = pu.ball_query(0.3, 16, xyz, new_xyz)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.3, 16, moved, xyz_np[:, :512].copy()))
+        assert len(builds) == 2
+        ptr = xyz.data_ptr()
+        del xyz, got
+        other_np = clouds("uniform", 2, 4096, seed=202)
+        other = T(other_np, dev)                              # usually lands on the address just freed
+        got = pu.ball_query(0.8, 16, other, new_xyz)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.8, 16, other_np, xyz_np[:, :512].copy()))
+        assert len(builds) == 3, (ptr, other.data_ptr())
+    finally:
+        _native.call = orig
+
+
+@pytest.mark.parametrize("quad", [1, 0])
+def test_ball_query_grid_quad_and_wave_kernels_agree_with_oracle(oracle, dev, quad):
+    """Four centres per wave (DPP rows) and one centre per wave: same indices as the oracle on clouds whose balls
+    hold 0 .. far more than 16 candidates (dense lidar near field, duplicated points, a lattice, radius 0 and huge)."""
+    from pdm_ssd_amd import _native
+    old = _native.lib().pdm_tune_bq_quad(quad)
+    try:
+        lid = clouds("lidar", 2, 8192, seed=203)
+        dup = np.concatenate([lid[:, :4096], lid[:, :4096]], axis=1)
+        lattice = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(16), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32) * 0.25
+        for xyz_np, m in ((lid, 2048), (dup, 1000), (lattice, 4096), (clouds("uniform", 3, 5000, seed=204), 1251)):
+            new_np = np.ascontiguousarray(xyz_np[:, :m])
+            xyz, new_xyz = T(xyz_np, dev), T(new_np, dev)
+            for r, ns in ((0.1, 16), (0.5, 32), (2.0, 16), (0.0, 8), (1e4, 32)):
+                got = pu.ball_query(r, ns, xyz, new_xyz)
+                np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(r, ns, xyz_np, new_np), err_msg=f"r={r} ns={ns} m={m}")
+    finally:
+        _native.lib().pdm_tune_bq_quad(old)
