@@ -280,6 +280,9 @@ int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const floa
  * stack run through pdm_rows_mlp_fused.  in / out (B, H, W, C) fp32, w (9, C) tap-major, shift (C); C % 4 == 0. */
 int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, const float *in, const float *w, const float *shift,
                          float *out, int relu);
+/* Weight gradient of that convolution (training): gw (9, C), zeroed by the caller, += sum over cells of gout * in[tap].
+ * The data gradient is pdm_bev_depthwise3x3 on gout with the nine taps mirrored. */
+int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw);
 
 /* ---- rotated-box IoU / NMS ---------------------------------------------
  * One entry per function of the reference's iou3d_nms_cuda extension (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp):

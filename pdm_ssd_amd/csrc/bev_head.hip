@@ -59,3 +59,81 @@ extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, co
                        reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu);
     return check_launch("bev_depthwise3x3");
 }
+
+// Weight gradient of the depthwise 3x3 convolution above:
+//   gw[tap][c] = sum over (b, y, x) of gout[b, y, x, c] * in[b, y + dy, x + dx, c]      (zero padding)
+// A thread owns four channels and walks a strip of cells with 36 running sums; a workgroup's threads with the same
+// channel quad are reduced through LDS and added to gw (9, C) with one float atomic per (tap, channel) per workgroup.
+// (The data gradient is the same convolution with the taps mirrored: pdm_bev_depthwise3x3 on gout.)
+namespace pdm {
+
+__global__ __launch_bounds__(256) void depthwise3x3_cl_wgrad_kernel(int H, int W, int C4, long long cells_total, int cells_per_wg,
+                                                                   const float4 *__restrict__ in, const float4 *__restrict__ gout,
+                                                                   float *__restrict__ gw) {
+    extern __shared__ float red[];   // (256 / C4) rows x 36 x C4 x 4 floats -> reduced over rows
+    const int cq = threadIdx.x % C4, lc = threadIdx.x / C4, rows = 256 / C4;
+    const long long c_begin = (long long)blockIdx.x * cells_per_wg;
+    const long long c_end = c_begin + cells_per_wg < cells_total ? c_begin + cells_per_wg : cells_total;
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lc < rows) {
+        for (long long cell = c_begin + lc; cell < c_end; cell += rows) {
+            const long long b = cell / ((long long)H * W);
+            const int rem = (int)(cell - b * (long long)H * W);
+            const int y = rem / W, x = rem - y * W;
+            const float4 g = gout[cell * C4 + cq];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    const float4 v = in[((b * H + yy) * W + xx) * C4 + cq];
+                    float4 &a = acc[(dy + 1) * 3 + dx + 1];
+                    a.x = fmaf(g.x, v.x, a.x); a.y = fmaf(g.y, v.y, a.y); a.z = fmaf(g.z, v.z, a.z); a.w = fmaf(g.w, v.w, a.w);
+                }
+            }
+        }
+    }
+    // reduce over the rows of the workgroup: red[lc][t][cq] (float4)
+    float4 *r4 = reinterpret_cast<float4 *>(red);
+    if (lc < rows)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) r4[(lc * 9 + t) * C4 + cq] = acc[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * C4 * 4; i += 256) {   // i = (t * C4 + cq) * 4 + comp
+        float s = 0.f;
+        const int tc = i >> 2, comp = i & 3;
+        for (int r = 0; r < rows; ++r) s += red[((r * 9 * C4) + tc) * 4 + comp];
+        atomicAdd(gw + i, s);
+    }
+}
+
+}  // namespace pdm
+
+// in, gout (B, H, W, C) fp32 channels-last; gw (9, C) fp32, ZEROED by the caller, receives the sums (float atomics
+// between workgroups: the order of the last additions is free, compare with a tolerance).
+extern "C" int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw) {
+    using namespace pdm;
+    PDM_REQUIRE(B >= 0 && H >= 0 && W >= 0 && C >= 0, PDM_E_BADARG, "bev_depthwise3x3_wgrad: negative size");
+    if (B == 0 || H == 0 || W == 0 || C == 0) return 0;
+    PDM_REQUIRE(C % 4 == 0 && C <= 1024, PDM_E_BADARG, "bev_depthwise3x3_wgrad: C=%d (multiple of 4, <= 1024)", C);
+    PDM_REQUIRE(in && gout && gw, PDM_E_BADARG, "bev_depthwise3x3_wgrad: null pointer");
+    PDM_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(gw)) & 15) == 0,
+                PDM_E_BADARG, "bev_depthwise3x3_wgrad: buffers must be 16-byte aligned");
+    const int C4 = C / 4;
+    const long long cells = (long long)B * H * W;
+    const int rows = 256 / C4 > 0 ? 256 / C4 : 1;
+    PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "bev_depthwise3x3_wgrad: C=%d", C);
+    int wgs = 2048;
+    if (cells < wgs * (long long)rows) wgs = (int)((cells + rows - 1) / rows);
+    const int per = (int)((cells + wgs - 1) / wgs);
+    const size_t lds = (size_t)rows * 9 * C4 * 4 * sizeof(float);
+    PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "bev_depthwise3x3_wgrad: %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(depthwise3x3_cl_wgrad_kernel, dim3((unsigned)((cells + per - 1) / per)), dim3(256), lds, as_stream(stream), H, W,
+                       C4, cells, per, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(gout), gw);
+    return check_launch("bev_depthwise3x3_wgrad");
+}

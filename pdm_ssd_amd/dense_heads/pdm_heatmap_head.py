@@ -22,6 +22,61 @@ from ..utils import centernet_utils, loss_utils
 from .point_head_template import _get
 
 
+class _Depthwise3x3CL(torch.autograd.Function):
+    """Depthwise 3x3 convolution (padding 1, no bias) on a channels-last fp32 map, forward and backward on the HIP
+    kernels of csrc/bev_head.hip.  MIOpen's depthwise path for this shape (128 channels x 200 x 176 x 32) costs ~170 ms
+    per training step in its weight-gradient kernel alone; these are three memory-bound passes over the map."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight):
+        from .. import _native
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        B, H, W, C = rows.shape
+        w9 = weight.reshape(C, 9).t().contiguous()                 # (9, C) tap-major
+        out = torch.empty_like(rows)
+        zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+        _native.call("pdm_bev_depthwise3x3", torch.cuda.current_stream(x.device).cuda_stream, B, H, W, C, rows.data_ptr(),
+                     w9.data_ptr(), zero.data_ptr(), out.data_ptr(), 0)
+        ctx.save_for_backward(rows, w9)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        from .. import _native
+        rows, w9 = ctx.saved_tensors
+        B, H, W, C = rows.shape
+        gr = g.float().permute(0, 2, 3, 1)
+        if not gr.is_contiguous():
+            gr = gr.contiguous()
+        stream = torch.cuda.current_stream(rows.device).cuda_stream
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx_rows = torch.empty_like(rows)
+            zero = torch.zeros(C, dtype=torch.float32, device=rows.device)
+            _native.call("pdm_bev_depthwise3x3", stream, B, H, W, C, gr.data_ptr(), w9.flip(0).contiguous().data_ptr(),
+                         zero.data_ptr(), gx_rows.data_ptr(), 0)
+            gx = gx_rows.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw9 = torch.zeros((9, C), dtype=torch.float32, device=rows.device)
+            _native.call("pdm_bev_depthwise3x3_wgrad", stream, B, H, W, C, rows.data_ptr(), gr.data_ptr(), gw9.data_ptr())
+            gw = gw9.t().reshape(C, 1, 3, 3)
+        return gx, gw
+
+
+class _DepthwiseConv3x3(nn.Conv2d):
+    """nn.Conv2d(c, c, 3, padding=1, groups=c, bias=False) — same parameters and state_dict — whose CUDA path is the
+    HIP pair above."""
+
+    def forward(self, x):
+        if x.is_cuda and x.shape[1] % 4 == 0:
+            return _Depthwise3x3CL.apply(x, self.weight)
+        return super().forward(x)
+
+
 class PDMHeatmapHead(nn.Module):
     def __init__(self, model_cfg, input_channels, num_class, class_names=None, grid_size=None, point_cloud_range=None,
                  voxel_size=None, predict_boxes_when_training=False, **kwargs):
@@ -37,7 +92,7 @@ class PDMHeatmapHead(nn.Module):
         kind = _get(model_cfg, 'CONTEXT_CONV', 'separable')
         for _ in range(_get(model_cfg, 'NUM_CONTEXT_CONV', 1)):   # "context learning" over the dilated, mostly empty map
             if kind == 'separable':
-                layers += [nn.Conv2d(c, c, 3, padding=1, groups=c, bias=False), nn.BatchNorm2d(c), nn.ReLU(),
+                layers += [_DepthwiseConv3x3(c, c, 3, padding=1, groups=c, bias=False), nn.BatchNorm2d(c), nn.ReLU(),
                            nn.Conv2d(c, width, 1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
             else:
                 layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
