@@ -124,6 +124,8 @@ class OpTimer:
             self._orig(name, stream, *args)
             e1.record(s)
             ints = [x for x in args if isinstance(x, (int, float))]
+            if name == "pdm_rows_mlp_fused":   # one entry point, several kernels: keep its shapes apart (fused.rows_tag)
+                name = f"{name}[{args[3]} layers, {args[1]} in, {args[0]} rows]"
             self.records.append((name, ints, e0, e1))
 
         _native.call = timed
@@ -140,7 +142,7 @@ class OpTimer:
             d = agg.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
             d["calls"] += 1
             d["ms"] += ms
-            d["bytes"] += algorithmic_bytes(name, ints)
+            d["bytes"] += algorithmic_bytes(name.split("[")[0], ints)
         out = []
         for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
             ms_step = d["ms"] / steps
@@ -575,7 +577,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
-    ap.add_argument("--pipeline-depth", type=int, default=3, choices=[1, 2, 3, 4, 5],
+    ap.add_argument("--pipeline-depth", type=int, default=4, choices=[1, 2, 3, 4, 5],
                     help="batches whose sampling chain is in flight beside the feature path; >= 3 also cuts the level-1 "
                          "FPS into depth - 1 resumable segments run side by side (pdm_ssd_amd/pipeline.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
@@ -642,17 +644,36 @@ def main():
         extras["ms_per_step_median_of_50"] = {"median": round(med, 4), "min": round(lo, 4), "max": round(hi, 4),
                                               "frames_per_s_at_median": round(B / med * 1e3, 1)}
 
+    # in-situ pass: the timed (pipelined) step launched eagerly, every C-ABI call bracketed by HIP events on the stream it
+    # is launched on — launch durations as they are inside the step, beside the other branches.  This pass decides which
+    # entry point has the most device time in the step (`roofline`).
+    insitu = []
+    from pdm_ssd_amd import fused as _fused
+    if not args.serial:
+        with torch.no_grad():
+            psteps = max(3, min(args.steps, 10))
+            bench._advance(); bench.step(); torch.cuda.synchronize()
+            with OpTimer() as timer:   # (no flop accounting here: it would put host synchronisations into the step)
+                for _ in range(psteps):
+                    bench._advance()
+                    bench.step()
+                insitu = timer.summary(psteps)
+
     # per-kernel pass (eager, serial, every C-ABI call bracketed by HIP events on its launch stream)
     points = bench.batches[0]
     with torch.no_grad():
         psteps = max(3, min(args.steps, 10))
-        from pdm_ssd_amd import fused as _fused
         _fused.FLOP_COUNTER = {}
         with OpTimer() as timer:
             for _ in range(psteps):
                 bench.step_serial(points)
             ops = timer.summary(psteps)
         executed = {k: v / psteps for k, v in _fused.FLOP_COUNTER.items()}
+        insitu_flops = executed if insitu else {}   # executed flops per step are the serial pass's (same work per step)
+        for o in insitu:
+            if o["op"] in insitu_flops:
+                o["executed_GFLOP_per_step"] = round(insitu_flops[o["op"]] / 1e9, 2)
+                o["TFLOPs"] = round(insitu_flops[o["op"]] / 1e9 / o["ms_per_step"], 1)
         _fused.FLOP_COUNTER = None
         t0s = time.perf_counter()
         for _ in range(psteps):
@@ -703,14 +724,26 @@ def main():
                   "pdm_sa_mlp_packed": ("pdm::sa_packed_fused_kernel", "pdm::sa_reg_packed_kernel"),
                   "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
                   "pdm_fp_mlp_fused_pre": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<true>"),
-                  "pdm_rows_mlp_fused": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
+                  "pdm_rows_mlp_fused": ("pdm::rows_chain_kernel", "pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
+
+    def kernels_of(op):
+        """Kernel names behind an entry point; pdm_rows_mlp_fused picks by shape (fused_mlp.hip::pdm_rows_mlp_fused):
+        3-layer chains over many rows -> rows_chain.hip, one wide layer -> rows_gemm.hip, else the general chain kernel."""
+        base = op.split("[")[0]
+        if base == "pdm_rows_mlp_fused" and "[" in op:
+            layers = int(op.split("[")[1].split(" ")[0])
+            rows = int(op.split(" in, ")[1].split(" ")[0])
+            if layers == 3 and rows >= 8192:
+                return ("pdm::rows_chain_kernel",)
+            return ("pdm::rows_gemm_kernel<false>",) if layers == 1 and rows >= 16384 else ("pdm::fp_mlp_fused_kernel",)
+        return KERNELS_OF.get(base, ())
 
     def mfma_block(o):
         calls = o["calls_per_step"]
         per_launch_flop = executed[o["op"]] / calls
         per_launch_s = o["ms_per_step"] / 1e3 / calls
         ach = per_launch_flop / per_launch_s / 1e12
-        kernels = KERNELS_OF.get(o["op"], ())
+        kernels = kernels_of(o["op"])
         return {"bound": "mfma", "kernel": " + ".join(kernels) + f" (all launches of {o['op']})",
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(*kernels) if kernels else None,
@@ -744,9 +777,30 @@ def main():
     mfma_blocks = {o["op"]: mfma_block(o) for o in mlp_ops}
     roofline_mfma = max(mfma_blocks.values(), key=lambda b: b["ms_per_step"]) if mfma_blocks else None
     roofline_fps = fps_block()
-    # `roofline` = the entry point with the most device time in the step
-    cands = [b for b in (roofline_mfma, roofline_fps) if b is not None]
-    roofline = max(cands, key=lambda b: b["ms_per_step"]) if cands else None
+    # `roofline` = the entry point with the most device time in the TIMED (pipelined) step, from the in-situ pass; its
+    # block is rebuilt with the in-situ launch durations.  (serial run: the serial pass is the timed step)
+    top = max(insitu, key=lambda o: o["ms_per_step"]) if insitu else None
+    roofline = None
+    if top is not None and top["op"] in insitu_flops:
+        saved, executed = executed, insitu_flops
+        roofline = mfma_block(top)
+        executed = saved
+        roofline["measured"] = "in situ: HIP events on the launch stream inside the pipelined step (eager launch of the timed step)"
+    elif top is not None and top["op"].startswith("pdm_furthest_point_sampling"):
+        lv = [(m.npoint, n_in) for m, n_in in zip(backbone.SA_modules, [N] + [m.npoint for m in backbone.SA_modules][:-1])]
+        mine = [o for o in insitu if o["op"] == top["op"]][0]
+        # the jobs form runs every iteration of the level-1 chain once per step (as depth - 1 segments of different batches)
+        flop = 8.0 * B * (lv[0][0] - 1) * lv[0][1] if top["op"].endswith("_jobs") else sum(8.0 * B * (m - 1) * n for m, n in lv[1:])
+        ach = flop / (mine["ms_per_step"] * 1e-3) / 1e12
+        roofline = {"bound": "valu/latency", "kernel": f"pdm::fps_pruned_kernel (all launches of {top['op']})", "achieved": round(ach, 3),
+                    "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / VALU_F32_PEAK_TFLOPS, 4),
+                    "traffic": pmc_traffic("pdm::fps_pruned_kernel"), "launches_per_step": mine["calls_per_step"],
+                    "avg_launch_us": round(mine["ms_per_step"] * 1e3 / mine["calls_per_step"], 2),
+                    "alg_flop_per_launch": int(flop / mine["calls_per_step"]), "ms_per_step": mine["ms_per_step"],
+                    "measured": "in situ: HIP events on the launch stream inside the pipelined step"}
+    if roofline is None:
+        cands = [b for b in (roofline_mfma, roofline_fps) if b is not None]
+        roofline = max(cands, key=lambda b: b["ms_per_step"]) if cands else None
 
     with torch.no_grad():
         refops, gp = reference_op_section(backbone, points, B)
@@ -841,6 +895,7 @@ def main():
         "ball_query_plus_group": refops,
         "pdm_neck_forms": pdm,
         "ops": ops,
+        "ops_in_situ": insitu,
         "extras": extras,
         "cpu_baseline": cpu,
         "cpu_baseline_single_thread": cpu1,

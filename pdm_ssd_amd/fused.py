@@ -223,7 +223,7 @@ def rows_forward(pk, in_pm, out_pm, relu_last=True):
     cin = in_pm.shape[-1]
     rows = in_pm.numel() // cin
     assert pk.cin == cin and in_pm.is_contiguous() and out_pm.is_contiguous()
-    _count("pdm_rows_mlp_fused", rows, pk)
+    _count(f"pdm_rows_mlp_fused[{pk.nlayers} layers, {cin} in, {rows} rows]", rows, pk)   # bench.py keeps the shapes apart
     _native.call("pdm_rows_mlp_fused", _stream(in_pm), rows, cin, in_pm.data_ptr(), pk.nlayers, pk.dims_ptr,
                  pk.wpack.data_ptr(), pk.bias.data_ptr(), 1 if relu_last else 0, out_pm.data_ptr(),
                  out_pm.shape[-1], pk.cout)

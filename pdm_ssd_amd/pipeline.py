@@ -70,6 +70,11 @@ class PipelinedHotPath:
         self.neck = neck
         self.dense_head = dense_head
         self.point_head = point_head
+        # True: the heat-map head runs behind the neck on the neck's stream, i.e. beside the FP layers — two MFMA-bound
+        # branches sharing the chip; False: on the main stream behind the point head (the memory-bound neck still
+        # overlaps the FP layers).  Same step time either way (measured); False keeps each MFMA kernel's launch
+        # duration what it is alone, which is what the bench's in-situ roofline reads.
+        self.heads_overlap = False
         self.depth = depth
         self.side = torch.cuda.Stream()
         self.neck_stream = torch.cuda.Stream()
@@ -202,7 +207,7 @@ class PipelinedHotPath:
                 self.neck_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.neck_stream):
                     self.neck(d)
-                    if self.dense_head is not None:
+                    if self.dense_head is not None and self.heads_overlap:
                         self.dense_head(d)
             bd['after_sa_hook'] = start_neck
         bd = self.backbone(bd)
@@ -210,6 +215,8 @@ class PipelinedHotPath:
             bd = self.point_head(bd)
         if self.neck is not None:
             torch.cuda.current_stream().wait_stream(self.neck_stream)
+            if self.dense_head is not None and not self.heads_overlap:
+                bd = self.dense_head(bd)
         return bd
 
     @staticmethod
