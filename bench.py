@@ -100,6 +100,9 @@ def algorithmic_bytes(name, a):
     if name == "pdm_bev_depthwise3x3":
         B, H, W, C = a[:4]
         return 8 * B * H * W * C
+    if name == "pdm_bev_head_fused":
+        B, H, W, C = a[:4]
+        return 4 * B * H * W * C
     if name == "pdm_bev_normalize":
         B, C, W, H, D = a[:5]
         return B * H * W * D * (8 * C + 4)
@@ -724,6 +727,7 @@ def main():
                   "pdm_sa_mlp_packed": ("pdm::sa_packed_fused_kernel", "pdm::sa_reg_packed_kernel"),
                   "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
                   "pdm_fp_mlp_fused_pre": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<true>"),
+                  "pdm_bev_head_fused": ("pdm::rows_chain_kernel<8, 4, 4, 1, true>",),
                   "pdm_rows_mlp_fused": ("pdm::rows_chain_kernel", "pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
 
     def kernels_of(op):

@@ -280,6 +280,13 @@ int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const floa
  * stack run through pdm_rows_mlp_fused.  in / out (B, H, W, C) fp32, w (9, C) tap-major, shift (C); C % 4 == 0. */
 int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, const float *in, const float *w, const float *shift,
                          float *out, int relu);
+/* The heat-map head's inference stack in ONE launch: out[cell] = MLP(relu(depthwise3x3(map)[cell] + shift)), the
+ * depthwise convolution formed on the fly as the prologue of the register-resident row MLP (csrc/rows_chain.hip); same
+ * arithmetic order as pdm_bev_depthwise3x3 followed by pdm_rows_mlp_fused (bit-identical).  Packed weights as for
+ * pdm_rows_mlp_fused.  Instantiated for C = 128 -> 64 -> 64 -> <= 16; PDM_E_BADARG for other widths. */
+int pdm_bev_head_fused(void *stream, int B, int H, int W, int C, const float *map, const float *dw_w, const float *dw_shift,
+                       int nlayers, const int *dims, const float *wpack, const float *bias, int relu_last, float *out_pm,
+                       int out_stride, int cout);
 /* Weight gradient of that convolution (training): gw (9, C), zeroed by the caller, += sum over cells of gout * in[tap].
  * The data gradient is pdm_bev_depthwise3x3 on gout with the nine taps mirrored. */
 int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw);

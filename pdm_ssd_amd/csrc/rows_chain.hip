@@ -30,6 +30,10 @@ struct RowsChainArgs {
     int woff[3], boff[3];       // float offsets of each layer
     float *out;
     int out_stride, cout, relu_last;
+    // depthwise prologue (DW instantiations): a row is a cell of a channels-last (B, H, W, C) map and the chain's input
+    // is relu(depthwise3x3(map)[cell] + shift) formed on the fly (bev_head.hip's kernel, same fma order)
+    int dw_H, dw_W;
+    const float *dw_w, *dw_shift;   // (9, C) tap-major with the BatchNorm scale folded in, (C)
 };
 
 constexpr int RC_THREADS = 256;
@@ -113,9 +117,14 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
 }
 
 // NK0 = k-blocks (16 channels) of the input, NK1 .. NK3 = output blocks of layers 1 .. 3 (0 = layer absent)
-template <int NK0, int NK1, int NK2, int NK3>
+template <int NK0, int NK1, int NK2, int NK3, bool DW = false>
 __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs a) {
     __shared__ __attribute__((aligned(16))) f4 lds[2 * RC_CHUNK_F4];
+    __shared__ __attribute__((aligned(16))) f4 dww[DW ? 10 * NK0 * 4 : 1];   // 9 taps + shift, C / 4 quads each
+    if constexpr (DW) {
+        for (int i = threadIdx.x; i < 9 * NK0 * 4; i += RC_THREADS) dww[i] = reinterpret_cast<const f4 *>(a.dw_w)[i];
+        for (int i = threadIdx.x; i < NK0 * 4; i += RC_THREADS) dww[9 * NK0 * 4 + i] = reinterpret_cast<const f4 *>(a.dw_shift)[i];
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int pos = lane & 15, g = lane >> 4;
     const f4 *w1 = reinterpret_cast<const f4 *>(a.wpack + a.woff[0]);
@@ -124,7 +133,12 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     constexpr int NL = NK3 ? 3 : NK2 ? 2 : 1;
     const float neg_inf = -__builtin_inff();
     f4 r[4];
-    for (long long tile0 = (long long)blockIdx.x * 64; tile0 < a.rows; tile0 += (long long)gridDim.x * 64) {
+    __shared__ __attribute__((aligned(16))) f4 halo[DW ? 6 * 18 * 4 : 1];   // DW: (4 + 2) x (16 + 2) cells x 16 channels
+    __shared__ __attribute__((aligned(16))) f4 xs[DW ? 64 * (NK0 * 4 + 1) : 1];   // DW: the patch's convolved rows (+1 quad pad)
+    const int ntx = DW ? (a.dw_W + 15) / 16 : 1, nty = DW ? (a.dw_H + 3) / 4 : 1;
+    const long long ntiles = DW ? (long long)(a.rows / (a.dw_H * a.dw_W)) * nty * ntx : ((long long)a.rows + 63) / 64;
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long long tile0 = tl * 64;
         // (the weight pointers pass through an empty asm so the ~140 chunk addresses are formed inside the loop with
         //  scalar adds instead of being hoisted out of it as loop invariants, where they would take every register)
         asm volatile("" : "+s"(w1), "+s"(w2), "+s"(w3));
@@ -133,15 +147,71 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
         rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
         rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
         // this lane's input row: channels [16 kb + 4 g, +4) of row tile0 + 16 wave + pos
+        // (DW: the workgroup owns a 4 x 16 patch of cells of one image, wave = patch row, pos = cell in it)
         long long row = tile0 + 16 * wave + pos;
-        const bool live = row < a.rows;
+        bool live = row < a.rows;
+        int dw_b = 0, dw_y0 = 0, dw_x0 = 0;
+        if constexpr (DW) {
+            const int tx = (int)(tl % ntx), ty = (int)((tl / ntx) % nty);
+            dw_b = (int)(tl / ((long long)ntx * nty));
+            dw_y0 = ty * 4; dw_x0 = tx * 16;
+            live = dw_y0 + wave < a.dw_H && dw_x0 + pos < a.dw_W;
+            row = ((long long)dw_b * a.dw_H + dw_y0 + wave) * a.dw_W + dw_x0 + pos;
+        }
         if (!live) row = a.rows - 1;
-        const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
+        const long long out_row = row;
         f4 x0[NK0];
+        if constexpr (!DW) {
+            const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
 #pragma unroll
-        for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
-        __syncthreads();
-        float *__restrict__ orow = live ? a.out + (size_t)(tile0 + 16 * wave + pos) * a.out_stride : nullptr;
+            for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
+            __syncthreads();
+        } else {
+            // depthwise 3x3 + shift + ReLU: the patch's halo is staged through LDS 16 channels at a time (each cell of
+            // the map is fetched once per workgroup instead of up to nine times), the next slice's loads in flight
+            // under the current slice's taps
+            constexpr int C4 = NK0 * 4;
+            const f4 *__restrict__ img = reinterpret_cast<const f4 *>(a.in) + (size_t)dw_b * a.dw_H * a.dw_W * C4;
+            f4 hv[2];
+            auto fetch = [&](int kb) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = t + u * RC_THREADS;           // f4 index in the halo slice: (cell, quad)
+                    hv[u] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (i < 6 * 18 * 4) {
+                        const int cell = i >> 2, quad = i & 3;
+                        const int gy = dw_y0 - 1 + cell / 18, gx = dw_x0 - 1 + cell % 18;
+                        if (gy >= 0 && gy < a.dw_H && gx >= 0 && gx < a.dw_W) hv[u] = img[((size_t)gy * a.dw_W + gx) * C4 + kb * 4 + quad];
+                    }
+                }
+            };
+            fetch(0);
+            // a runtime loop over the 16-channel slices (unrolled, the compiler gathers all 80 tap reads up front and
+            // spills them); a lane parks its slice results in its own LDS row and reads them back as x0[] afterwards
+            f4 *mine = xs + (wave * 16 + pos) * (C4 + 1) + g;
+#pragma unroll 1
+            for (int kb = 0; kb < NK0; ++kb) {
+                if (t < 6 * 18 * 4) halo[t] = hv[0];
+                if (t + RC_THREADS < 6 * 18 * 4) halo[t + RC_THREADS] = hv[1];
+                __syncthreads();
+                if (kb + 1 < NK0) fetch(kb + 1);
+                f4 acc = dww[9 * C4 + kb * 4 + g];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const f4 v = halo[((wave + dy) * 18 + pos + dx) * 4 + g];
+                        const f4 k = dww[(dy * 3 + dx) * C4 + kb * 4 + g];
+                        acc.x = fmaf(k.x, v.x, acc.x); acc.y = fmaf(k.y, v.y, acc.y);
+                        acc.z = fmaf(k.z, v.z, acc.z); acc.w = fmaf(k.w, v.w, acc.w);
+                    }
+                mine[kb * 4] = f4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+                __syncthreads();
+            }
+#pragma unroll
+            for (int kb = 0; kb < NK0; ++kb) x0[kb] = mine[kb * 4];
+        }
+        float *__restrict__ orow = live ? a.out + (size_t)out_row * a.out_stride : nullptr;
         auto store = [&](auto &y, int nmb) {
             if (!orow) return;
 #pragma unroll
@@ -212,4 +282,54 @@ int rows_chain_launch(void *stream, int rows, int cin, const float *in_pm, int n
     return 0;
 }
 
+// The heat-map head's whole stack in one launch: depthwise 3x3 (+ folded BN + ReLU) as the chain's prologue.
+// Returns 1 in *launched when an instantiation fits.
+int rows_chain_dw_launch(void *stream, int B, int H, int W, int C, const float *map, const float *dw_w, const float *dw_shift,
+                         int nlayers, const int *dims, const float *wpack, const float *bias, int relu_last, float *out_pm,
+                         int out_stride, int cout, int *launched) {
+    *launched = 0;
+    const long long rows = (long long)B * H * W;
+    if (rows < 8192 || rows >= (1ll << 31) || C % 16 != 0 || nlayers != 3 || dims[0] != C) return 0;
+    RowsChainArgs a{};
+    a.rows = (int)rows; a.in_stride = C; a.in = map; a.wpack = wpack; a.bias = bias;
+    int wo = 0, bo = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        a.woff[l] = wo; a.boff[l] = bo;
+        wo += dims[l] * dims[l + 1];
+        bo += dims[l + 1];
+    }
+    a.out = out_pm; a.out_stride = out_stride; a.cout = cout; a.relu_last = relu_last;
+    a.dw_H = H; a.dw_W = W; a.dw_w = dw_w; a.dw_shift = dw_shift;
+    const long long tiles = (long long)B * ((H + 3) / 4) * ((W + 15) / 16);
+    const int grid = (int)(tiles < 256 * 12 ? tiles : 256 * 12);
+    if (rc_shape_is(nlayers, dims, 8, 4, 4, 1)) {
+        hipLaunchKernelGGL((rows_chain_kernel<8, 4, 4, 1, true>), dim3(grid), dim3(RC_THREADS), 0, as_stream(stream), a);
+        *launched = 1;
+        return check_launch("bev_head_fused");
+    }
+    return 0;
+}
+
 }  // namespace pdm
+
+// Depthwise 3x3 + folded BN + ReLU over a channels-last (B, H, W, C) map followed by a per-cell MLP, in ONE kernel
+// (the heat-map head in eval mode): out[cell] = MLP(relu(dw3x3(map)[cell] + shift)).  Only the shapes rows_chain.hip
+// instantiates (C = 128 -> 64 -> 64 -> <= 16); PDM_E_BADARG otherwise (the caller then runs the two kernels apart).
+extern "C" int pdm_bev_head_fused(void *stream, int B, int H, int W, int C, const float *map, const float *dw_w,
+                                  const float *dw_shift, int nlayers, const int *dims, const float *wpack, const float *bias,
+                                  int relu_last, float *out_pm, int out_stride, int cout) {
+    using namespace pdm;
+    PDM_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0, PDM_E_BADARG, "bev_head_fused: bad size");
+    if (B == 0) return 0;
+    PDM_REQUIRE(map && dw_w && dw_shift && dims && wpack && bias && out_pm, PDM_E_BADARG, "bev_head_fused: null pointer");
+    PDM_REQUIRE(cout > 0 && cout <= out_stride && out_stride % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(map) | reinterpret_cast<uintptr_t>(dw_w) | reinterpret_cast<uintptr_t>(dw_shift) |
+                      reinterpret_cast<uintptr_t>(wpack) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(out_pm)) & 15) == 0,
+                PDM_E_BADARG, "bev_head_fused: buffers must be 16-byte aligned, out_stride a multiple of 4");
+    int launched = 0;
+    const int rc = rows_chain_dw_launch(stream, B, H, W, C, map, dw_w, dw_shift, nlayers, dims, wpack, bias, relu_last, out_pm,
+                                        out_stride, cout, &launched);
+    if (rc) return rc;
+    PDM_REQUIRE(launched, PDM_E_BADARG, "bev_head_fused: no instantiation for these widths");
+    return 0;
+}

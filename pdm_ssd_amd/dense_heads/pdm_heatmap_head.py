@@ -163,11 +163,18 @@ class PDMHeatmapHead(nn.Module):
             cache['dw'] = (key, w.to(x.device), shift.to(x.device))
         _, w, shift = cache['dw']
         pk = fused.cached_layers(self, 'pw', self, lambda: [(mods[3], mods[4]), (self.hm[0], None), (self.hm[2], None)], x.device)
-        mid = torch.empty_like(rows)
-        _native.call("pdm_bev_depthwise3x3", torch.cuda.current_stream(x.device).cuda_stream, B, H, W, C, rows.data_ptr(),
-                     w.data_ptr(), shift.data_ptr(), mid.data_ptr(), 1)
         out = torch.empty((B, H, W, (self.num_class + 3) // 4 * 4), dtype=torch.float32, device=x.device)
-        fused.rows_forward(pk, mid, out, relu_last=False)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if getattr(self, 'use_one_kernel', True) and pk.dims == [128, 64, 64, 16]:
+            # the depthwise stage as the prologue of the per-cell MLP: the map is read once, nothing in between is written
+            fused._count(f"pdm_bev_head_fused", B * H * W, pk)
+            _native.call("pdm_bev_head_fused", stream, B, H, W, C, rows.data_ptr(), w.data_ptr(), shift.data_ptr(), pk.nlayers,
+                         pk.dims_ptr, pk.wpack.data_ptr(), pk.bias.data_ptr(), 0, out.data_ptr(), out.shape[-1], self.num_class)
+        else:
+            mid = torch.empty_like(rows)
+            _native.call("pdm_bev_depthwise3x3", stream, B, H, W, C, rows.data_ptr(), w.data_ptr(), shift.data_ptr(),
+                         mid.data_ptr(), 1)
+            fused.rows_forward(pk, mid, out, relu_last=False)
         return out[..., :self.num_class].permute(0, 3, 1, 2)
 
     def forward(self, data_dict):

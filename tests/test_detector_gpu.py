@@ -140,7 +140,10 @@ def test_heatmap_head_fused_inference_equals_torch_layers(dev):
         head.use_fused = False
         b = head({'spatial_features': sf})['bev_heatmap']
         lb = head.forward_ret_dict['hm_logits']
+        head.use_fused, head.use_one_kernel = True, False            # depthwise kernel, then the per-cell row MLP
+        lc = head({'spatial_features': sf}) and head.forward_ret_dict['hm_logits']
     assert tuple(a.shape) == (3, 3, 200, 176)
+    assert torch.equal(la, lc)                                       # one launch == two launches, bit for bit
     torch.testing.assert_close(la, lb, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
 
