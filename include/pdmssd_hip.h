@@ -287,6 +287,12 @@ int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, const float *
 int pdm_bev_head_fused(void *stream, int B, int H, int W, int C, const float *map, const float *dw_w, const float *dw_shift,
                        int nlayers, const int *dims, const float *wpack, const float *bias, int relu_last, float *out_pm,
                        int out_stride, int cout);
+/* Point head epilogue (point_head_box.py:97-113 in eval mode): score = sigmoid(max class logit), box = the
+ * PointResidualCoder decoding (box_coder_utils.py:188-222, use_mean_size) of the code with the arg-max class's mean size,
+ * for every point in one pass.  cls (N, cls_stride), code (N, code_stride >= 8, rows 16-byte aligned), pts (N, pts_stride >= 3),
+ * mean_size (num_class, 3) -> boxes (N, 7), scores (N). */
+int pdm_point_head_decode(void *stream, long long n, int num_class, const float *cls, int cls_stride, const float *code,
+                          int code_stride, const float *pts, int pts_stride, const float *mean_size, float *boxes, float *scores);
 /* Weight gradient of that convolution (training): gw (9, C), zeroed by the caller, += sum over cells of gout * in[tap].
  * The data gradient is pdm_bev_depthwise3x3 on gout with the nine taps mirrored. */
 int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw);

@@ -137,3 +137,59 @@ extern "C" int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int
                        C4, cells, per, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(gout), gw);
     return check_launch("bev_depthwise3x3_wgrad");
 }
+
+// Point head epilogue in one pass: class scores and decoded boxes of every point.
+//   score[i]  = sigmoid(max_c cls[i][c])                                  (point_head_box.py:97-98)
+//   box[i]    = PointResidualCoder.decode(code[i], point[i], argmax_c + 1)  (box_coder_utils.py:188-222, use_mean_size):
+//               x, y = t * sqrt(dxa^2 + dya^2) + point, z = t * dza + point, sizes = exp(t) * mean size, heading = atan2(sin, cos)
+// The reference does this with ~25 elementwise torch kernels over (N, 8) tensors; same formulas, one read and one write.
+namespace pdm {
+
+__global__ __launch_bounds__(256) void point_head_decode_kernel(long long n, int num_class, const float *__restrict__ cls, int cls_stride,
+                                                               const float *__restrict__ code, int code_stride,
+                                                               const float *__restrict__ pts, int pts_stride,
+                                                               const float *__restrict__ mean_size, float *__restrict__ boxes,
+                                                               float *__restrict__ scores) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *c = cls + i * cls_stride;
+    float best = c[0];
+    int arg = 0;
+    for (int k = 1; k < num_class; ++k) {
+        const float v = c[k];
+        if (v > best) { best = v; arg = k; }     // first maximum, as torch.max
+    }
+    scores[i] = 1.0f / (1.0f + expf(-best));
+    const float4 t0 = *reinterpret_cast<const float4 *>(code + i * code_stride);
+    const float4 t1 = *reinterpret_cast<const float4 *>(code + i * code_stride + 4);
+    const float dxa = mean_size[arg * 3], dya = mean_size[arg * 3 + 1], dza = mean_size[arg * 3 + 2];
+    const float diag = sqrtf(dxa * dxa + dya * dya);
+    const float *p = pts + i * pts_stride;
+    float *o = boxes + i * 7;
+    o[0] = t0.x * diag + p[0];
+    o[1] = t0.y * diag + p[1];
+    o[2] = t0.z * dza + p[2];
+    o[3] = expf(t0.w) * dxa;
+    o[4] = expf(t1.x) * dya;
+    o[5] = expf(t1.y) * dza;
+    o[6] = atan2f(t1.w, t1.z);
+}
+
+}  // namespace pdm
+
+// cls (N, cls_stride) logits with num_class live columns, code (N, code_stride >= 8) [x, y, z, dx, dy, dz, cos, sin] 16-byte
+// aligned rows, pts (N, pts_stride >= 3), mean_size (num_class, 3) -> boxes (N, 7), scores (N).
+extern "C" int pdm_point_head_decode(void *stream, long long n, int num_class, const float *cls, int cls_stride, const float *code,
+                                     int code_stride, const float *pts, int pts_stride, const float *mean_size, float *boxes,
+                                     float *scores) {
+    using namespace pdm;
+    PDM_REQUIRE(n >= 0 && num_class >= 1, PDM_E_BADARG, "point_head_decode: n=%lld num_class=%d", n, num_class);
+    if (n == 0) return 0;
+    PDM_REQUIRE(cls && code && pts && mean_size && boxes && scores, PDM_E_BADARG, "point_head_decode: null pointer");
+    PDM_REQUIRE(cls_stride >= num_class && code_stride >= 8 && code_stride % 4 == 0 && pts_stride >= 3 &&
+                    (reinterpret_cast<uintptr_t>(code) & 15) == 0, PDM_E_BADARG, "point_head_decode: strides / alignment");
+    PDM_REQUIRE(n <= 0x7fffffffll * 256, PDM_E_TOOLARGE, "point_head_decode: too many points");
+    hipLaunchKernelGGL(point_head_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), n, num_class, cls,
+                       cls_stride, code, code_stride, pts, pts_stride, mean_size, boxes, scores);
+    return check_launch("point_head_decode");
+}

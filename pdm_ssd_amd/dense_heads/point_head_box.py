@@ -91,6 +91,33 @@ class PointHeadBox(PointHeadTemplate):
                 return cls[0, :, :ncls], box[0, :, :nbox]
         return self.cls_layers(point_features), self.box_layers(point_features)
 
+    def _decode_fused(self, batch_dict, cls, box):
+        """Eval mode on the GPU: scores and decoded boxes of all points in one HIP pass (pdm_point_head_decode) instead
+        of ~25 elementwise torch kernels.  False when the configuration is not the fp32 mean-size coder path."""
+        from .. import _native
+        coords = batch_dict['point_coords']
+        coder = self.box_coder
+        if (self.training or torch.is_grad_enabled() or not cls.is_cuda or cls.dtype != torch.float32 or box.dtype != torch.float32
+                or not isinstance(coder, box_coder_utils.PointResidualCoder) or not coder.use_mean_size or coder.code_size != 8
+                or coords.dtype != torch.float32 or coords.stride(1) != 1 or cls.stride(1) != 1 or box.stride(1) != 1
+                or box.stride(0) % 4 or box.data_ptr() % 16 or not getattr(self, 'use_fused', True)):
+            return False
+        if coder.mean_size.device != cls.device:
+            coder.mean_size = coder.mean_size.to(cls.device)
+        n = cls.shape[0]
+        boxes = torch.empty((n, 7), dtype=torch.float32, device=cls.device)
+        scores = torch.empty((n,), dtype=torch.float32, device=cls.device)
+        pts = coords[:, 1:4]
+        _native.call("pdm_point_head_decode", torch.cuda.current_stream(cls.device).cuda_stream, n, self.num_class, cls.data_ptr(),
+                     cls.stride(0), box.data_ptr(), box.stride(0), pts.data_ptr(), coords.stride(0),
+                     coder.mean_size.contiguous().data_ptr(), boxes.data_ptr(), scores.data_ptr())
+        batch_dict['point_cls_scores'] = scores
+        batch_dict['batch_cls_preds'] = cls
+        batch_dict['batch_box_preds'] = boxes
+        batch_dict['batch_index'] = coords[:, 0]
+        batch_dict['cls_preds_normalized'] = False
+        return True
+
     def forward(self, batch_dict):
         """point_features (N1 + N2 + ..., C), point_coords (.., 4) [, gt_boxes (B, M, 8)] -> point_cls_scores and, in
         eval mode (or predict_boxes_when_training), batch_cls_preds / batch_box_preds / batch_index (ref :71-115)."""
@@ -99,6 +126,9 @@ class PointHeadBox(PointHeadTemplate):
         else:
             point_features = batch_dict['point_features']
         point_cls_preds, point_box_preds = self._layers(point_features)
+        if self._decode_fused(batch_dict, point_cls_preds, point_box_preds):
+            self.forward_ret_dict = {'point_cls_preds': point_cls_preds, 'point_box_preds': point_box_preds}
+            return batch_dict
         point_cls_preds_max, _ = point_cls_preds.max(dim=-1)
         batch_dict['point_cls_scores'] = torch.sigmoid(point_cls_preds_max)
         ret_dict = {'point_cls_preds': point_cls_preds, 'point_box_preds': point_box_preds}
