@@ -274,6 +274,60 @@ int pdm_stack_three_interpolate_grad(void *stream, int N, int C, const float *gr
 int pdm_stack_furthest_point_sampling(void *stream, int B, int max_n, const float *xyz, float *temp,
                                       const int *xyz_batch_cnt, int *idxs, const int *num_sampled_points);
 
+/* ---- pointnet2_stack: voxel query and the vector-pool family (second half) ------------
+ * pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:14 and :25-30 bind
+ *   voxel_query_wrapper                                  voxel_query.cpp:20 / voxel_query_gpu.cu:11-91
+ *   query_stacked_local_neighbor_idxs_wrapper_stack      vector_pool.cpp:63  / vector_pool_gpu.cu:125-205
+ *   query_three_nn_by_stacked_local_idxs_wrapper_stack   vector_pool.cpp:19  / vector_pool_gpu.cu:19-87
+ *   vector_pool_wrapper, vector_pool_grad_wrapper        vector_pool.cpp:113, :170 / vector_pool_gpu.cu:245-443
+ * The reference gives out slots of the stacked outputs with atomicAdd on a cursor and has python re-run the kernel
+ * with a larger buffer on overrun; here the cursor is an exclusive prefix sum of per-centre counts (centre order —
+ * one of the orders the race allows, and the same on every run), exposed as a count pass and a fill pass so a
+ * caller can size the buffers exactly.  pdm_stack_query_local_neighbor_idxs is the reference's one-call form
+ * (count + fill into a stack of avg_length * M slots, writes stop at the capacity, *cumsum += total).
+ *
+ * voxel_query: idx (M, nsample) GLOBAL indices, caller-zeroed; window cells visited z outer / x inner; kept when
+ *   d2 <= radius^2; the first hit fills the row; idx[0] = -1 when nothing was found.
+ * local neighbours: first by index, at most nsample when nsample > 0, never more than 1000; neighbor_type 1 = ball
+ *   (d2 <= r^2), otherwise cube (|l| <= r per axis); start_len (M,2) = [offset, length]; indices GLOBAL.
+ * three_nn_by_local_idxs: dist2 / idxs (M, num_total_grids, 3); idx -1 and +inf for an empty list; the best is
+ *   repeated into unfilled second / third slots.  stack_len = valid length of stack_neighbor_idxs.
+ * vector_pool: new_features (M, num_c_out) and new_local_xyz (M, 3G) are SUMS (overwritten, no zero-fill needed;
+ *   python divides by point_cnt_of_grid); input channel i folds onto i % (num_c_out / G); pooling_type 0 = sum,
+ *   1 = first point of each cell; grouped_idxs (num_max_sum_points, 3) = [support idx, centre, cell] at
+ *   entry_start[centre] + rank; entries past num_max_sum_points are dropped.  (num_c_out + 4G) * 4 B <= 48 KB.
+ * vector_pool_grad: grad_support_features (N, C_in) caller-zeroed, float atomics (order undefined, as upstream). */
+int pdm_stack_voxel_query(void *stream, int M, int Z, int Y, int X, int nsample, float radius, int z_range, int y_range,
+                          int x_range, const float *new_xyz, const float *xyz, const int *new_coords,
+                          const int *point_indices, int *idx);
+int pdm_stack_local_neighbor_count(void *stream, const float *support_xyz, const int *xyz_batch_cnt, const float *new_xyz,
+                                   const int *new_xyz_batch_cnt, int *start_len, int *cumsum, float max_neighbour_distance,
+                                   int batch_size, int M, int nsample, int neighbor_type);
+int pdm_stack_local_neighbor_fill(void *stream, const float *support_xyz, const int *xyz_batch_cnt, const float *new_xyz,
+                                  const int *new_xyz_batch_cnt, int *stack_neighbor_idxs, const int *start_len,
+                                  long long stack_capacity, float max_neighbour_distance, int batch_size, int M, int nsample,
+                                  int neighbor_type);
+int pdm_stack_query_local_neighbor_idxs(void *stream, const float *support_xyz, const int *xyz_batch_cnt,
+                                        const float *new_xyz, const int *new_xyz_batch_cnt, int *stack_neighbor_idxs,
+                                        int *start_len, int *cumsum, int avg_length_of_neighbor_idxs,
+                                        float max_neighbour_distance, int batch_size, int M, int nsample, int neighbor_type);
+int pdm_stack_three_nn_by_local_idxs(void *stream, const float *support_xyz, const float *new_xyz_grid_centers,
+                                     int *new_xyz_grid_idxs, float *new_xyz_grid_dist2, const int *stack_neighbor_idxs,
+                                     const int *start_len, long long stack_len, int M, int num_total_grids);
+/* entry_cnt (M) = entries each centre records, entry_start (M) = their exclusive prefix, *total += the sum */
+int pdm_stack_vector_pool_count(void *stream, const float *support_xyz, const int *xyz_batch_cnt, const float *new_xyz,
+                                const int *new_xyz_batch_cnt, int *entry_start, int *entry_cnt, int *total, int num_grid_x,
+                                int num_grid_y, int num_grid_z, float max_neighbour_distance, int batch_size, int M,
+                                int nsample, int neighbor_type, int pooling_type);
+int pdm_stack_vector_pool(void *stream, const float *support_xyz, const float *support_features, const int *xyz_batch_cnt,
+                          const float *new_xyz, float *new_features, float *new_local_xyz, const int *new_xyz_batch_cnt,
+                          int *point_cnt_of_grid, int *grouped_idxs, const int *entry_start, int num_grid_x, int num_grid_y,
+                          int num_grid_z, float max_neighbour_distance, int batch_size, int M, int num_c_in, int num_c_out,
+                          int use_xyz, int num_max_sum_points, int nsample, int neighbor_type, int pooling_type);
+int pdm_stack_vector_pool_grad(void *stream, const float *grad_new_features, const int *point_cnt_of_grid,
+                               const int *grouped_idxs, float *grad_support_features, int N, int M, int num_c_out,
+                               int num_c_in, int num_total_grids, int num_entries);
+
 /* ---- hybrid head (north_star configs[2]: "backbone + PDM neck + hybrid head"; no reference source: SURVEY.md F1) ----
  * Depthwise 3x3 convolution + folded BatchNorm + ReLU over the neck's channels-last BEV grid, the context stage of
  * the heat-map head (pdm_ssd_amd/dense_heads/pdm_heatmap_head.py); the point head's MLPs and the heat-map head's 1x1

@@ -25,7 +25,7 @@ _i32p = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pointnet2_stack_oracle.c", "iou3d_oracle.c", "pdm_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "pointnet2_stack_oracle.c", "vector_pool_oracle.c", "iou3d_oracle.c", "pdm_oracle.c", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -343,6 +343,105 @@ def stack_furthest_point_sample(xyz, xyz_batch_cnt, npoint):
     out = np.zeros((int(mc.sum()),), dtype=np.int32)
     rc = lib().oracle_stack_furthest_point_sampling(B, px, temp.ctypes.data_as(_f32p), pxc, out.ctypes.data_as(_i32p), pmc)
     assert rc == 0
+    return out
+
+
+# ---- voxel query and vector pool (N3 remainder): oracle/vector_pool_oracle.c ------------------------------------
+
+def stack_voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """pointnet2_stack/voxel_query_utils.py:10-47 -> (idx (M,nsample) int32 GLOBAL, empty_ball_mask (M,))."""
+    xyz, px = _f(xyz); new_xyz, pn = _f(new_xyz)
+    new_coords, pc = _i(new_coords); point_indices, pp = _i(point_indices)
+    M = new_coords.shape[0]
+    _, Z, Y, X = point_indices.shape
+    idx = np.zeros((M, nsample), dtype=np.int32)
+    zr, yr, xr = max_range
+    lib().oracle_stack_voxel_query(M, Z, Y, X, int(nsample), ctypes.c_float(radius), int(zr), int(yr), int(xr), pn, px, pc, pp,
+                                   idx.ctypes.data_as(_i32p))
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def stack_query_local_neighbor_idxs(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, avg_length, max_neighbour_distance,
+                                    nsample, neighbor_type):
+    """One call of query_stacked_local_neighbor_idxs_wrapper_stack on a stack of avg_length * M slots
+    -> (stack (avg_length*M,) int32, start_len (M,2) int32, total)."""
+    support_xyz, ps = _f(support_xyz); new_xyz, pn = _f(new_xyz)
+    xc, pxc = _i(xyz_batch_cnt); nc, pnc = _i(new_xyz_batch_cnt)
+    M = new_xyz.shape[0]
+    stack = np.zeros((int(avg_length) * M,), dtype=np.int32)
+    start_len = np.zeros((M, 2), dtype=np.int32)
+    cumsum = np.zeros((1,), dtype=np.int32)
+    total = lib().oracle_stack_query_local_neighbor_idxs(ps, pxc, pn, pnc, stack.ctypes.data_as(_i32p), start_len.ctypes.data_as(_i32p),
+                                                         cumsum.ctypes.data_as(_i32p), int(avg_length),
+                                                         ctypes.c_float(max_neighbour_distance), len(xc), M, int(nsample),
+                                                         int(neighbor_type))
+    return stack, start_len, int(total)
+
+
+def stack_three_nn_for_vector_pool_by_two_step(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_grid_centers, new_xyz_batch_cnt,
+                                               max_neighbour_distance, nsample, neighbor_type, avg_length_of_neighbor_idxs,
+                                               num_total_grids, neighbor_distance_multiplier):
+    """ThreeNNForVectorPoolByTwoStep.forward (pointnet2_utils.py:306-352), retry loop included
+    -> (dist (M,G,3) = sqrt(dist2), idx (M,G,3) int32 GLOBAL or -1, avg_length)."""
+    M = np.asarray(new_xyz).shape[0]
+    avg = int(avg_length_of_neighbor_idxs)
+    while True:
+        cap = avg * M
+        stack, start_len, total = stack_query_local_neighbor_idxs(
+            support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, avg,
+            float(max_neighbour_distance) * float(neighbor_distance_multiplier), nsample, neighbor_type)
+        avg = total // M + int(total % M > 0)
+        if total <= cap:
+            break
+    support_xyz, ps = _f(support_xyz); centers, pc = _f(new_xyz_grid_centers)
+    stack, pst = _i(stack[:total]); start_len, psl = _i(start_len)
+    d2 = np.zeros(centers.shape, dtype=np.float32)
+    idx = np.full(centers.shape, -1, dtype=np.int32)
+    lib().oracle_stack_three_nn_by_local_idxs(ps, pc, idx.ctypes.data_as(_i32p), d2.ctypes.data_as(_f32p), pst, psl, M,
+                                              int(num_total_grids))
+    return np.sqrt(d2), idx, avg
+
+
+def stack_vector_pool(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, num_grid, max_neighbour_distance,
+                      num_c_out_each_grid, use_xyz, num_mean_points_per_grid=100, nsample=-1, neighbor_type=0, pooling_type=0):
+    """VectorPoolWithVoxelQuery.forward (pointnet2_utils.py:360-428), retry loop included
+    -> dict(new_features (M, G*ceg), new_local_xyz (M, 3G), num_mean_points_per_grid, point_cnt_of_grid (M,G), grouped_idxs (T,3))."""
+    support_xyz, ps = _f(support_xyz); feats, pf = _f(support_features); new_xyz, pn = _f(new_xyz)
+    xc, pxc = _i(xyz_batch_cnt); nc, pnc = _i(new_xyz_batch_cnt)
+    gx, gy, gz = num_grid
+    G = gx * gy * gz
+    c_out = num_c_out_each_grid * G
+    M, c_in = new_xyz.shape[0], feats.shape[1]
+    mean = int(num_mean_points_per_grid)
+    while True:
+        nf = np.zeros((M, c_out), dtype=np.float32)
+        nl = np.zeros((M, 3 * G), dtype=np.float32)
+        pc = np.zeros((M, G), dtype=np.int32)
+        cap = mean * M
+        grouped = np.zeros((cap, 3), dtype=np.int32)
+        total = lib().oracle_stack_vector_pool(ps, pf, pxc, pn, nf.ctypes.data_as(_f32p), nl.ctypes.data_as(_f32p), pnc,
+                                               pc.ctypes.data_as(_i32p), grouped.ctypes.data_as(_i32p), gx, gy, gz,
+                                               ctypes.c_float(max_neighbour_distance), len(xc), M, c_in, c_out, int(bool(use_xyz)),
+                                               cap, int(nsample), int(neighbor_type), int(pooling_type))
+        mean = total // M + int(total % M > 0)
+        if total <= cap:
+            break
+    norm = np.maximum(pc[:, :, None].astype(np.float32), np.float32(1e-6))
+    nf = (nf.reshape(M, G, num_c_out_each_grid) / norm).reshape(M, c_out)
+    if use_xyz:
+        nl = (nl.reshape(M, G, 3) / norm).reshape(M, 3 * G)
+    return {'new_features': nf, 'new_local_xyz': nl, 'num_mean_points_per_grid': mean, 'point_cnt_of_grid': pc,
+            'grouped_idxs': grouped[:total]}
+
+
+def stack_vector_pool_grad(grad_new_features, point_cnt_of_grid, grouped_idxs, N, num_c_in):
+    g, pg = _f(grad_new_features); pc, ppc = _i(point_cnt_of_grid); gi, pgi = _i(grouped_idxs)
+    M, c_out = g.shape
+    out = np.zeros((N, num_c_in), dtype=np.float32)
+    lib().oracle_stack_vector_pool_grad(pg, ppc, pgi, out.ctypes.data_as(_f32p), int(N), M, c_out, int(num_c_in), pc.shape[1],
+                                        gi.shape[0])
     return out
 
 

@@ -66,6 +66,14 @@ _SIGNATURES = {
     "pdm_stack_three_interpolate": [_i, _i, _vp, _vp, _vp, _vp],
     "pdm_stack_three_interpolate_grad": [_i, _i, _vp, _vp, _vp, _vp],
     "pdm_stack_furthest_point_sampling": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_stack_voxel_query": [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_stack_local_neighbor_count": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i],
+    "pdm_stack_local_neighbor_fill": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _i, _i, _i, _i],
+    "pdm_stack_query_local_neighbor_idxs": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _i],
+    "pdm_stack_three_nn_by_local_idxs": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i],
+    "pdm_stack_vector_pool_count": [_vp] * 7 + [_i, _i, _i, _f, _i, _i, _i, _i, _i],
+    "pdm_stack_vector_pool": [_vp] * 10 + [_i, _i, _i, _f] + [_i] * 9,
+    "pdm_stack_vector_pool_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "pdm_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],

@@ -56,6 +56,38 @@ __device__ __forceinline__ void radix_pick256(const int *hist, int remaining, in
     }
 }
 
+// ---- ragged ("stacked") batches: per-sample counts -> LDS prefix tables (stack_ops.hip, vector_pool.hip) -------
+constexpr int ST_MAXB = 1024;   // samples per call held as LDS prefix tables
+
+// prefix[k] = sum of cnt[0..k) for k = 0..B, built once per workgroup
+__device__ __forceinline__ void build_prefix(int B, const int *__restrict__ cnt, int *prefix) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < B; ++k) { prefix[k] = acc; acc += cnt[k]; }
+        prefix[B] = acc;
+    }
+}
+// the reference's linear scan (ball_query_gpu.cu:27-32): the last sample absorbs elements past the total
+__device__ __forceinline__ int sample_of(int i, int B, const int *prefix) {
+    int bs = 0;
+    for (int k = 1; k < B; ++k) {
+        if (i < prefix[k]) break;
+        bs = k;
+    }
+    return bs;
+}
+
+// both tables of a (centres, points) pair: wave 0 builds one, wave 1 the other; the caller syncs the workgroup
+__device__ __forceinline__ void build_prefix_pair(int B, const int *__restrict__ cnt_a, int *prefix_a,
+                                                  const int *__restrict__ cnt_b, int *prefix_b) {
+    build_prefix(B, cnt_a, prefix_a);
+    if (threadIdx.x == 64) {
+        int acc = 0;
+        for (int k = 0; k < B; ++k) { prefix_b[k] = acc; acc += cnt_b[k]; }
+        prefix_b[B] = acc;
+    }
+}
+
 }  // namespace pdm
 
 #define PDM_REQUIRE(cond, code, ...)      \

@@ -6,26 +6,6 @@
 
 namespace pdm {
 
-constexpr int ST_MAXB = 1024;   // samples per call held as LDS prefix tables
-
-// prefix[k] = sum of cnt[0..k) for k = 0..B, built once per workgroup
-__device__ __forceinline__ void build_prefix(int B, const int *__restrict__ cnt, int *prefix) {
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int k = 0; k < B; ++k) { prefix[k] = acc; acc += cnt[k]; }
-        prefix[B] = acc;
-    }
-}
-// the reference's linear scan (ball_query_gpu.cu:27-32): the last sample absorbs elements past the total
-__device__ __forceinline__ int sample_of(int i, int B, const int *prefix) {
-    int bs = 0;
-    for (int k = 1; k < B; ++k) {
-        if (i < prefix[k]) break;
-        bs = k;
-    }
-    return bs;
-}
-
 // ---- ball query: one wave per centre, 64 candidates per step, ballot-ordered writes, early exit ----------
 __global__ __launch_bounds__(256) void stack_ball_query_kernel(int B, int M, float radius, int nsample,
                                                                const float *__restrict__ new_xyz,

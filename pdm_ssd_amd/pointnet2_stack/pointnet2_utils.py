@@ -3,9 +3,9 @@
 Mirrors the public names, argument order, shapes, dtypes and zero-fill behaviour of
 /root/reference/pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py for the PointNet++ operators
 (ball_query, grouping_operation, QueryAndGroup, farthest_point_sample, stack_farthest_point_sample, three_nn,
-three_interpolate); the vector-pool and voxel-query operators of that file are outside this build
-(SURVEY.md section 8(f) N3 covers "the same arithmetic with *_batch_cnt").  Every operator dispatches to a
-hand-written HIP kernel in libpdmssd_hip.so; there is no PyTorch or CPU fallback.
+three_interpolate) and for the vector-pool operators (three_nn_for_vector_pool_by_two_step,
+vector_pool_with_voxel_query_op); the voxel query lives in voxel_query_utils.py as upstream.  Every operator
+dispatches to a hand-written HIP kernel in libpdmssd_hip.so; there is no PyTorch or CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -200,3 +200,116 @@ class ThreeInterpolate(Function):
 
 
 three_interpolate = ThreeInterpolate.apply
+
+
+class ThreeNNForVectorPoolByTwoStep(Function):
+    """ref :305-353 — step 1 stacks every centre's neighbours within multiplier * max_neighbour_distance, step 2
+    takes the three nearest of them for each of the centre's local grid-cell centres.
+    -> (dist (M, G, 3) = sqrt(dist2), idx (M, G, 3) int32 GLOBAL or -1, tensor(avg_length_of_neighbor_idxs)).
+
+    Upstream guesses the stack size from avg_length_of_neighbor_idxs and re-runs step 1 until it fits; here step 1
+    is a count pass and a fill pass, so the stack is sized exactly after one host read of the total and
+    avg_length_of_neighbor_idxs only matters as the value handed back (ceil(total / M), as upstream's last round)."""
+
+    @staticmethod
+    def forward(ctx, support_xyz, xyz_batch_cnt, new_xyz, new_xyz_grid_centers, new_xyz_batch_cnt,
+                max_neighbour_distance, nsample, neighbor_type, avg_length_of_neighbor_idxs, num_total_grids,
+                neighbor_distance_multiplier):
+        num_new_xyz = new_xyz.shape[0]
+        new_xyz_grid_centers = new_xyz_grid_centers.float().contiguous()
+        new_xyz_grid_dist2 = new_xyz_grid_centers.new_zeros(new_xyz_grid_centers.shape)
+        new_xyz_grid_idxs = torch.full(new_xyz_grid_centers.shape, -1, dtype=torch.int32, device=new_xyz.device)
+        if num_new_xyz == 0:
+            return new_xyz_grid_dist2, new_xyz_grid_idxs, torch.tensor(int(avg_length_of_neighbor_idxs))
+        support_xyz, new_xyz = support_xyz.float().contiguous(), new_xyz.float().contiguous()
+        xyz_batch_cnt, new_xyz_batch_cnt = _i32(xyz_batch_cnt).contiguous(), _i32(new_xyz_batch_cnt).contiguous()
+        # same float product as upstream's python (:338) before it is narrowed to the wrapper's float argument
+        distance = max_neighbour_distance * neighbor_distance_multiplier
+        start_len = torch.zeros((num_new_xyz, 2), dtype=torch.int32, device=new_xyz.device)
+        cumsum = torch.zeros((1,), dtype=torch.int32, device=new_xyz.device)
+        pointnet2.local_neighbor_count(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, start_len, cumsum, distance,
+                                       nsample, neighbor_type)
+        total = int(cumsum.item())
+        avg_length_of_neighbor_idxs = total // num_new_xyz + int(total % num_new_xyz > 0)
+        stack_neighbor_idxs = torch.zeros((total,), dtype=torch.int32, device=new_xyz.device)
+        pointnet2.local_neighbor_fill(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, stack_neighbor_idxs, start_len,
+                                      distance, nsample, neighbor_type)
+        pointnet2.query_three_nn_by_stacked_local_idxs_wrapper_stack(
+            support_xyz, new_xyz, new_xyz_grid_centers, new_xyz_grid_idxs, new_xyz_grid_dist2,
+            stack_neighbor_idxs, start_len, num_new_xyz, num_total_grids)
+        return torch.sqrt(new_xyz_grid_dist2), new_xyz_grid_idxs, torch.tensor(avg_length_of_neighbor_idxs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None,) * 11
+
+
+three_nn_for_vector_pool_by_two_step = ThreeNNForVectorPoolByTwoStep.apply
+
+
+class VectorPoolWithVoxelQuery(Function):
+    """ref :358-448 — every centre's neighbours fall into the cells of its local num_grid_x * y * z lattice; per cell the
+    features (input channel i folded onto i % num_c_out_each_grid) and the local offsets are averaged (pooling_type 0)
+    or taken from the first point (pooling_type 1).
+    -> (new_features (M, G * num_c_out_each_grid), new_local_xyz (M, 3G), num_mean_points_per_grid (1,) int32 CPU,
+        point_cnt_of_grid (M, G) int32); the gradient goes to support_features only.
+
+    num_mean_points_per_grid is upstream's first guess for the size of the backward's index; it is not needed here
+    (count pass, then an exactly sized fill) and only its final value, ceil(entries / M), is reproduced."""
+
+    @staticmethod
+    def forward(ctx, support_xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor, support_features: torch.Tensor,
+                new_xyz: torch.Tensor, new_xyz_batch_cnt: torch.Tensor, num_grid_x, num_grid_y, num_grid_z,
+                max_neighbour_distance, num_c_out_each_grid, use_xyz,
+                num_mean_points_per_grid=100, nsample=-1, neighbor_type=0, pooling_type=0):
+        for name, t in (("support_xyz", support_xyz), ("support_features", support_features), ("xyz_batch_cnt", xyz_batch_cnt),
+                        ("new_xyz", new_xyz), ("new_xyz_batch_cnt", new_xyz_batch_cnt)):
+            assert t.is_contiguous(), f"{name} must be contiguous"
+        num_total_grids = num_grid_x * num_grid_y * num_grid_z
+        num_c_out = num_c_out_each_grid * num_total_grids
+        N, num_c_in = support_features.shape
+        M = new_xyz.shape[0]
+        assert num_c_in % num_c_out_each_grid == 0, \
+            f'the input channels ({num_c_in}) should be an integral multiple of num_c_out_each_grid({num_c_out_each_grid})'
+
+        dev = new_xyz.device
+        new_features = torch.zeros((M, num_c_out), dtype=torch.float32, device=dev)
+        new_local_xyz = torch.zeros((M, 3 * num_total_grids), dtype=torch.float32, device=dev)
+        point_cnt_of_grid = torch.zeros((M, num_total_grids), dtype=torch.int32, device=dev)
+        grouped_idxs = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+        if M > 0:
+            support_xyz, new_xyz = support_xyz.float(), new_xyz.float()
+            xyz_batch_cnt, new_xyz_batch_cnt = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+            entry_start, total = pointnet2.vector_pool_count(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, num_grid_x,
+                                                             num_grid_y, num_grid_z, max_neighbour_distance, nsample,
+                                                             neighbor_type, pooling_type)
+            num_cum_sum = int(total.item())
+            num_mean_points_per_grid = num_cum_sum // M + int(num_cum_sum % M > 0)
+            grouped_idxs = torch.zeros((num_cum_sum, 3), dtype=torch.int32, device=dev)
+            pointnet2.vector_pool_fill(support_xyz, xyz_batch_cnt, support_features.float(), new_xyz, new_xyz_batch_cnt,
+                                       new_features, new_local_xyz, point_cnt_of_grid, grouped_idxs, entry_start, num_grid_x,
+                                       num_grid_y, num_grid_z, max_neighbour_distance, use_xyz, nsample, neighbor_type,
+                                       pooling_type)
+
+        normalizer = torch.clamp_min(point_cnt_of_grid[:, :, None].float(), min=1e-6)   # ref :416-420
+        new_features = (new_features.view(-1, num_total_grids, num_c_out_each_grid) / normalizer).view(-1, num_c_out)
+        if use_xyz:
+            new_local_xyz = (new_local_xyz.view(-1, num_total_grids, 3) / normalizer).view(-1, num_total_grids * 3)
+
+        num_mean_points_per_grid = torch.Tensor([num_mean_points_per_grid]).int()
+        nsample = torch.Tensor([nsample]).int()
+        ctx.vector_pool_for_backward = (point_cnt_of_grid, grouped_idxs, N, num_c_in)
+        ctx.mark_non_differentiable(new_local_xyz, num_mean_points_per_grid, nsample, point_cnt_of_grid)
+        return new_features, new_local_xyz, num_mean_points_per_grid, point_cnt_of_grid
+
+    @staticmethod
+    def backward(ctx, grad_new_features: torch.Tensor, grad_local_xyz: torch.Tensor, grad_num_cum_sum, grad_point_cnt_of_grid):
+        point_cnt_of_grid, grouped_idxs, N, num_c_in = ctx.vector_pool_for_backward
+        grad_support_features = grad_new_features.new_zeros((N, num_c_in), dtype=torch.float32)
+        if grouped_idxs.shape[0] > 0:
+            pointnet2.vector_pool_grad_wrapper(grad_new_features.float().contiguous(), point_cnt_of_grid, grouped_idxs,
+                                               grad_support_features)
+        return (None, None, grad_support_features) + (None,) * 12
+
+
+vector_pool_with_voxel_query_op = VectorPoolWithVoxelQuery.apply
