@@ -218,3 +218,91 @@ def test_vector_pool_large_cloud_properties(dev):
     nf.sum().backward()
     # each pooled (point, centre) pair contributes 1 / count per channel; summed over a cell that is 1 per channel
     assert abs(float(f.grad.sum()) - float(filled.sum()) * 16) < 1e-3 * float(filled.sum()) * 16
+
+
+# ---- the modules built on the operators (pointnet2_modules.py:160-470) ---------------------------------------------
+
+def _module_inputs(dev, c=16):
+    counts, mcounts = [1800, 1100], [70, 50]
+    xyz = ragged_clouds(counts, 17)
+    new = centres_from(xyz, counts, mcounts, 5)
+    feats = np.random.default_rng(6).normal(size=(xyz.shape[0], c)).astype(np.float32)
+    return counts, mcounts, xyz, new, feats
+
+
+def test_local_interpolate_module_matches_oracle(oracle, dev):
+    from pdm_ssd_amd.pointnet2_stack.pointnet2_modules import VectorPoolAggregationModule, VectorPoolLocalInterpolateModule
+    counts, mcounts, xyz, new, feats = _module_inputs(dev)
+    new[4] += 400.0                                                                   # no neighbours: its cells come out zero
+    grid, R = (3, 3, 2), 0.9
+    mod = VectorPoolLocalInterpolateModule(None, grid, R, -1, 1, use_xyz=True, neighbour_distance_multiplier=2.0).to(dev)
+    centres_t = VectorPoolAggregationModule.get_dense_voxels_by_center(T(new, dev), R, grid)
+    centres = centres_t.cpu().numpy()
+    # lattice: x slowest, z fastest, cell centres at -R + (2i + 1) R / n
+    want_axis = [(-R + (2 * np.arange(n) + 1) * R / n) for n in grid]
+    off = np.stack(np.meshgrid(*want_axis, indexing="ij"), -1).reshape(-1, 3)
+    np.testing.assert_allclose(centres, new[:, None, :] + off[None], atol=1e-5)
+    xc, nc = T(np.array(counts, np.int32), dev), T(np.array(mcounts, np.int32), dev)
+    out = mod(T(xyz, dev), T(feats, dev), xc, T(new, dev), centres_t, nc).cpu().numpy()
+    G = 18
+    d, i, _ = oracle.stack_three_nn_for_vector_pool_by_two_step(xyz, counts, new, centres, mcounts, R, -1, 1, 1000, G, 2.0)
+    d, i = d.reshape(-1, 3), i.reshape(-1, 3).copy()
+    empty = i[:, 0] == -1
+    i[empty] = 0
+    with np.errstate(over="ignore", invalid="ignore"):
+        rec = np.float32(1.0) / (d + np.float32(1e-8))
+        w = rec / np.maximum(rec.sum(-1, keepdims=True), np.float32(1e-8))
+    w[empty] = 0
+    interp = oracle.stack_three_interpolate(feats, i, w.astype(np.float32))
+    offsets = (centres.reshape(-1, 1, 3) - xyz[i]).reshape(-1, 9)
+    want = np.concatenate([interp, offsets], 1)
+    want[empty] = 0
+    assert empty.reshape(-1, G)[4].all() and not empty.all()
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["voxel_avg_pool", "voxel_random_choice", "local_interpolation"])
+def test_vector_pool_aggregation_module(oracle, dev, kind):
+    """The gather stage against the oracle, then the module's own layers (grouped 1x1 + BN + ReLU, post MLPs) against
+    the same layers run on the CPU; the backward reaches the support features."""
+    import copy
+    from pdm_ssd_amd.pointnet2_stack.pointnet2_modules import VectorPoolAggregationModule
+    counts, mcounts, xyz, new, feats = _module_inputs(dev, c=32)
+    torch.manual_seed(0)
+    mod = VectorPoolAggregationModule(32, (3, 3, 3), kind, 16, 8, (24, 20), 0.9, -1, 0, 2.0).eval()
+    cpu = copy.deepcopy(mod)
+    mod = mod.to(dev)
+    xc, nc = T(np.array(counts, np.int32), dev), T(np.array(mcounts, np.int32), dev)
+    f = T(feats, dev).requires_grad_(True)
+    key_xyz, out = mod(T(xyz, dev), xc, T(new, dev), nc, f)
+    assert out.shape == (120, 20) and key_xyz.shape == (120, 3)
+    red = feats.reshape(-1, 2, 16).sum(1)
+    if kind == "local_interpolation":
+        vec = mod.vector_pool_with_local_interpolate(T(xyz, dev), xc, T(red, dev), T(new, dev), nc).cpu()
+        assert vec.shape == (120, 27 * 25)
+    else:
+        r = oracle.stack_vector_pool(xyz, counts, red, new, mcounts, (3, 3, 3), 0.9, 16, True, 20, -1, 0, 0 if kind == "voxel_avg_pool" else 1)
+        vec = torch.from_numpy(np.concatenate([r['new_local_xyz'].reshape(120, 27, 3), r['new_features'].reshape(120, 27, 16)], -1).reshape(120, -1))
+        got, cnt = mod.vector_pool_with_voxel_query(T(xyz, dev), xc, T(red, dev), T(new, dev), nc)
+        np.testing.assert_allclose(got.cpu().numpy(), vec.numpy(), rtol=1e-6, atol=1e-6)   # red is summed on the GPU by torch
+        np.testing.assert_array_equal(cnt.cpu().numpy(), r['point_cnt_of_grid'])
+    with torch.no_grad():
+        want = cpu.post_mlps(cpu.separate_local_aggregation_layer(vec.t()[None])).squeeze(0).t()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
+    out.square().sum().backward()
+    assert torch.isfinite(f.grad).all() and float(f.grad.abs().sum()) > 0
+
+
+def test_vector_pool_msg_module_from_config(dev):
+    from pdm_ssd_amd.pointnet2_stack.pointnet2_modules import build_local_aggregation_module
+    cfg = {'NAME': 'VectorPoolAggregationModuleMSG', 'NUM_GROUPS': 2, 'LOCAL_AGGREGATION_TYPE': 'local_interpolation',
+           'NUM_REDUCED_CHANNELS': 8, 'NUM_CHANNELS_OF_LOCAL_AGGREGATION': 16, 'MSG_POST_MLPS': [32],
+           'GROUP_CFG_0': {'NUM_LOCAL_VOXEL': [2, 2, 2], 'MAX_NEIGHBOR_DISTANCE': 0.4, 'NEIGHBOR_NSAMPLE': -1, 'POST_MLPS': [32, 32]},
+           'GROUP_CFG_1': {'NUM_LOCAL_VOXEL': [3, 3, 3], 'MAX_NEIGHBOR_DISTANCE': 0.8, 'NEIGHBOR_NSAMPLE': -1, 'POST_MLPS': [32, 32]}}
+    layer, c_out = build_local_aggregation_module(16, cfg)
+    assert c_out == 32 and {k.split('.')[0] for k in layer.state_dict()} == {'layer_0', 'layer_1', 'msg_post_mlps'}
+    layer = layer.to(dev).eval()
+    counts, mcounts, xyz, new, feats = _module_inputs(dev)
+    xc, nc = T(np.array(counts, np.int32), dev), T(np.array(mcounts, np.int32), dev)
+    key_xyz, out = layer(xyz=T(xyz, dev), xyz_batch_cnt=xc, new_xyz=T(new, dev), new_xyz_batch_cnt=nc, features=T(feats, dev))
+    assert out.shape == (120, 32) and torch.isfinite(out).all() and torch.equal(key_xyz, T(new, dev))
