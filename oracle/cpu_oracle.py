@@ -380,6 +380,17 @@ def stack_query_local_neighbor_idxs(support_xyz, xyz_batch_cnt, new_xyz, new_xyz
     return stack, start_len, int(total)
 
 
+def stack_three_nn_by_local_idxs(support_xyz, new_xyz_grid_centers, stack_neighbor_idxs, start_len):
+    """One call of query_three_nn_by_stacked_local_idxs_wrapper_stack -> (dist2 (M,G,3), idx (M,G,3) int32, -1 = none)."""
+    support_xyz, ps = _f(support_xyz); centers, pc = _f(new_xyz_grid_centers)
+    stack, pst = _i(stack_neighbor_idxs); start_len, psl = _i(start_len)
+    M, G = centers.shape[0], centers.shape[1]
+    d2 = np.zeros(centers.shape, dtype=np.float32)
+    idx = np.full(centers.shape, -1, dtype=np.int32)
+    lib().oracle_stack_three_nn_by_local_idxs(ps, pc, idx.ctypes.data_as(_i32p), d2.ctypes.data_as(_f32p), pst, psl, M, G)
+    return d2, idx
+
+
 def stack_three_nn_for_vector_pool_by_two_step(support_xyz, xyz_batch_cnt, new_xyz, new_xyz_grid_centers, new_xyz_batch_cnt,
                                                max_neighbour_distance, nsample, neighbor_type, avg_length_of_neighbor_idxs,
                                                num_total_grids, neighbor_distance_multiplier):
@@ -395,36 +406,45 @@ def stack_three_nn_for_vector_pool_by_two_step(support_xyz, xyz_batch_cnt, new_x
         avg = total // M + int(total % M > 0)
         if total <= cap:
             break
-    support_xyz, ps = _f(support_xyz); centers, pc = _f(new_xyz_grid_centers)
-    stack, pst = _i(stack[:total]); start_len, psl = _i(start_len)
-    d2 = np.zeros(centers.shape, dtype=np.float32)
-    idx = np.full(centers.shape, -1, dtype=np.int32)
-    lib().oracle_stack_three_nn_by_local_idxs(ps, pc, idx.ctypes.data_as(_i32p), d2.ctypes.data_as(_f32p), pst, psl, M,
-                                              int(num_total_grids))
+    d2, idx = stack_three_nn_by_local_idxs(support_xyz, new_xyz_grid_centers, stack[:total], start_len)
+    assert idx.shape[1] == num_total_grids
     return np.sqrt(d2), idx, avg
+
+
+def stack_vector_pool_once(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, num_grid, max_neighbour_distance,
+                           num_c_out, use_xyz, num_max_sum_points, nsample, neighbor_type, pooling_type):
+    """One call of vector_pool_wrapper: -> (SUMS new_features (M,c_out), new_local_xyz (M,3G), point_cnt_of_grid (M,G),
+    grouped_idxs (num_max_sum_points,3), number of entries wanted)."""
+    support_xyz, ps = _f(support_xyz); feats, pf = _f(support_features); new_xyz, pn = _f(new_xyz)
+    xc, pxc = _i(xyz_batch_cnt); nc, pnc = _i(new_xyz_batch_cnt)
+    gx, gy, gz = (int(v) for v in num_grid)
+    G = gx * gy * gz
+    M, c_in = new_xyz.shape[0], feats.shape[1]
+    nf = np.zeros((M, num_c_out), dtype=np.float32)
+    nl = np.zeros((M, 3 * G), dtype=np.float32)
+    pc = np.zeros((M, G), dtype=np.int32)
+    grouped = np.zeros((int(num_max_sum_points), 3), dtype=np.int32)
+    total = lib().oracle_stack_vector_pool(ps, pf, pxc, pn, nf.ctypes.data_as(_f32p), nl.ctypes.data_as(_f32p), pnc,
+                                           pc.ctypes.data_as(_i32p), grouped.ctypes.data_as(_i32p), gx, gy, gz,
+                                           ctypes.c_float(max_neighbour_distance), len(xc), M, c_in, int(num_c_out),
+                                           int(bool(use_xyz)), int(num_max_sum_points), int(nsample), int(neighbor_type),
+                                           int(pooling_type))
+    return nf, nl, pc, grouped, int(total)
 
 
 def stack_vector_pool(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt, num_grid, max_neighbour_distance,
                       num_c_out_each_grid, use_xyz, num_mean_points_per_grid=100, nsample=-1, neighbor_type=0, pooling_type=0):
     """VectorPoolWithVoxelQuery.forward (pointnet2_utils.py:360-428), retry loop included
     -> dict(new_features (M, G*ceg), new_local_xyz (M, 3G), num_mean_points_per_grid, point_cnt_of_grid (M,G), grouped_idxs (T,3))."""
-    support_xyz, ps = _f(support_xyz); feats, pf = _f(support_features); new_xyz, pn = _f(new_xyz)
-    xc, pxc = _i(xyz_batch_cnt); nc, pnc = _i(new_xyz_batch_cnt)
-    gx, gy, gz = num_grid
-    G = gx * gy * gz
+    G = int(num_grid[0]) * int(num_grid[1]) * int(num_grid[2])
     c_out = num_c_out_each_grid * G
-    M, c_in = new_xyz.shape[0], feats.shape[1]
+    M = np.asarray(new_xyz).shape[0]
     mean = int(num_mean_points_per_grid)
     while True:
-        nf = np.zeros((M, c_out), dtype=np.float32)
-        nl = np.zeros((M, 3 * G), dtype=np.float32)
-        pc = np.zeros((M, G), dtype=np.int32)
         cap = mean * M
-        grouped = np.zeros((cap, 3), dtype=np.int32)
-        total = lib().oracle_stack_vector_pool(ps, pf, pxc, pn, nf.ctypes.data_as(_f32p), nl.ctypes.data_as(_f32p), pnc,
-                                               pc.ctypes.data_as(_i32p), grouped.ctypes.data_as(_i32p), gx, gy, gz,
-                                               ctypes.c_float(max_neighbour_distance), len(xc), M, c_in, c_out, int(bool(use_xyz)),
-                                               cap, int(nsample), int(neighbor_type), int(pooling_type))
+        nf, nl, pc, grouped, total = stack_vector_pool_once(support_xyz, xyz_batch_cnt, support_features, new_xyz, new_xyz_batch_cnt,
+                                                            num_grid, max_neighbour_distance, c_out, use_xyz, cap, nsample,
+                                                            neighbor_type, pooling_type)
         mean = total // M + int(total % M > 0)
         if total <= cap:
             break

@@ -178,3 +178,84 @@ def test_gpu_stack_modules_match_reference_fixtures(sref, dev):
             fo = fp(xyz, xc, new_xyz, nc, feat, t(sref['fp_kfeat']))
         np.testing.assert_allclose(nf.cpu().numpy(), sref['sa_out'], rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(fo.cpu().numpy(), sref['fp_out'], rtol=1e-4, atol=1e-4)
+
+
+# ---- vector pool / voxel query: fixtures produced by the reference's own python (tests/golden/gen_vector_pool_fixtures.py) ----
+
+@pytest.fixture(scope="module")
+def vref():
+    return np.load(os.path.join(G, "ref_vector_pool_modules.npz"))
+
+
+def _vp_cfg(kind):
+    return {'NAME': 'VectorPoolAggregationModuleMSG', 'NUM_GROUPS': 2, 'LOCAL_AGGREGATION_TYPE': kind, 'NUM_REDUCED_CHANNELS': 4,
+            'NUM_CHANNELS_OF_LOCAL_AGGREGATION': 6, 'MSG_POST_MLPS': [10],
+            'GROUP_CFG_0': {'NUM_LOCAL_VOXEL': [2, 2, 2], 'MAX_NEIGHBOR_DISTANCE': 0.5, 'NEIGHBOR_NSAMPLE': -1, 'POST_MLPS': [8, 8]},
+            'GROUP_CFG_1': {'NUM_LOCAL_VOXEL': [3, 3, 2], 'MAX_NEIGHBOR_DISTANCE': 0.9, 'NEIGHBOR_NSAMPLE': -1, 'POST_MLPS': [12, 8]}}
+
+
+def test_vector_pool_gather_stage_matches_reference_python(vref):
+    """What the reference's python makes of the kernels' raw outputs (retry loops, division by the cell counts,
+    [mean offset | pooled features] per cell; cell-centre lattice, inverse-distance weights, empty-cell zeroing,
+    [interpolated | 3 x offset] per cell) == the same composition of this repo's oracle wrappers."""
+    xyz, new, counts, mcounts = vref['xyz'], vref['new_xyz'], vref['counts'], vref['mcounts']
+    red = vref['feat'].reshape(-1, 2, 4).sum(1)
+    for tag, pooling in (('avg', 0), ('first', 1)):
+        r = o.stack_vector_pool(xyz, counts, red, new, mcounts, (3, 3, 2), 0.9, 4, True, 20, -1, 0, pooling)
+        vec = np.concatenate([r['new_local_xyz'].reshape(32, 18, 3), r['new_features'].reshape(32, 18, 4)], -1).reshape(32, -1)
+        np.testing.assert_array_equal(r['point_cnt_of_grid'], vref[f'{tag}_cnt'])
+        np.testing.assert_allclose(vec, vref[f'{tag}_vec'], rtol=0, atol=1e-6)       # torch summed the channel groups
+    R, n = 0.9, (3, 3, 2)
+    axes = [(-R + (2 * np.arange(k) + 1) * R / k).astype(np.float32) for k in n]
+    centres = (new[:, None, :] + np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)[None]).astype(np.float32)
+    d, i, _ = o.stack_three_nn_for_vector_pool_by_two_step(xyz, counts, new, centres, mcounts, R, -1, 0, 1000, 18, 2.0)
+    d, i = d.reshape(-1, 3), i.reshape(-1, 3).copy()
+    empty = i[:, 0] == -1
+    i[empty] = 0
+    with np.errstate(over="ignore", invalid="ignore"):
+        rec = np.float32(1.0) / (d + np.float32(1e-8))
+        w = (rec / np.maximum(rec.sum(-1, keepdims=True), np.float32(1e-8))).astype(np.float32)
+    w[empty] = 0
+    vec = np.concatenate([o.stack_three_interpolate(red, i, w), (centres.reshape(-1, 1, 3) - xyz[i]).reshape(-1, 9)], 1)
+    vec[empty] = 0
+    assert empty.reshape(32, 18)[3].all()
+    np.testing.assert_allclose(vec.reshape(32, -1), vref['interp_vec'], rtol=1e-5, atol=1e-5)
+
+
+def test_vector_pool_msg_state_dict_loads_strictly(vref):
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    for tag, kind in (('interp', 'local_interpolation'), ('avg', 'voxel_avg_pool'), ('first', 'voxel_random_choice')):
+        layer, c_out = sm.build_local_aggregation_module(8, _vp_cfg(kind))
+        _load(layer, vref, f'{tag}_state.')
+        assert c_out == 10
+
+
+@pytest.mark.gpu
+def test_gpu_vector_pool_modules_match_reference_fixtures(vref, dev):
+    """HIP vector-pool / voxel-query operators + this repo's modules against the outputs AND input gradients of the
+    reference's VectorPoolAggregationModuleMSG (three aggregation types) and VoxelQueryAndGrouping."""
+    from pdm_ssd_amd.pointnet2_stack import pointnet2_modules as sm
+    from pdm_ssd_amd.pointnet2_stack import voxel_query_utils as vq
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xyz, new_xyz, xc, nc = t(vref['xyz']), t(vref['new_xyz']), t(vref['counts']), t(vref['mcounts'])
+    for tag, kind in (('interp', 'local_interpolation'), ('avg', 'voxel_avg_pool'), ('first', 'voxel_random_choice')):
+        layer, _ = sm.build_local_aggregation_module(8, _vp_cfg(kind))
+        layer = _load(layer, vref, f'{tag}_state.').to(dev).eval()
+        f = t(vref['feat']).requires_grad_(True)
+        key, out = layer(xyz=xyz, xyz_batch_cnt=xc, new_xyz=new_xyz, new_xyz_batch_cnt=nc, features=f)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), vref[f'{tag}_out'], rtol=1e-4, atol=1e-4)
+        out.backward(t(vref[f'{tag}_grad_out']))
+        np.testing.assert_allclose(f.grad.cpu().numpy(), vref[f'{tag}_grad_feat'], rtol=1e-4, atol=1e-4)
+        red = t(vref['feat']).view(-1, 2, 4).sum(1)
+        with torch.no_grad():
+            if kind == 'local_interpolation':
+                vec = layer.layer_1.vector_pool_with_local_interpolate(xyz, xc, red, new_xyz, nc)
+            else:
+                vec, cnt = layer.layer_1.vector_pool_with_voxel_query(xyz, xc, red.contiguous(), new_xyz, nc)
+                np.testing.assert_array_equal(cnt.cpu().numpy(), vref[f'{tag}_cnt'])
+        np.testing.assert_allclose(vec.cpu().numpy(), vref[f'{tag}_vec'], rtol=1e-5, atol=1e-5)
+    mod = vq.VoxelQueryAndGrouping((1, 2, 2), 0.8, 6)
+    gf, gx, mask = mod(t(vref['vq_coords']), xyz, xc, new_xyz, nc, t(vref['feat']), t(vref['vq_vox']))
+    np.testing.assert_array_equal(mask.cpu().numpy(), vref['vq_mask'])
+    np.testing.assert_array_equal(gf.cpu().numpy(), vref['vq_feat'])
+    np.testing.assert_array_equal(gx.cpu().numpy(), vref['vq_xyz'])
