@@ -335,6 +335,18 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device):
     for _ in range(max(1, args.warmup)):
         step()
     dist_utils.barrier()
+    if args.train_profile:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        if rank == 0:
+            with open(args.train_profile, "w") as f:
+                f.write("# 3 steady-state train steps (divide totals by 3 for one step)\n")
+                f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=110))
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -592,6 +604,9 @@ def main():
                     help="BASELINE config 4 instead: bf16-autocast forward+backward+AdamW step of the detector, "
                          "DistributedDataParallel gradient all-reduce over RCCL when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-profile", metavar="FILE", default=None,
+                    help="with --train: after the warm-up, run 3 steps under torch.profiler and write the per-kernel table "
+                         "(steady state: MIOpen's one-off solver search stays outside) to FILE instead of timing")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra measurements of the default line (lidar-like clouds, configs[4] stress shape, "

@@ -1132,6 +1132,9 @@ int rows_gemm_launch(void *stream, int rows, int cin, const float *in_pm, int k0
 int rows_chain_launch(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims, const float *wpack,
                       const float *bias, int relu_last, float *out_pm, int out_stride, int cout, int *launched);   // rows_chain.hip
 static int g_fused_chain = 1;       // 0: many-row MLPs go through the general chain kernel instead of rows_chain.hip
+int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride, const float *skip_pm,
+                    const int *idx, const float *weight, const int *dims, const float *wpack, const float *bias, float *out_pm,
+                    int out_stride, int cout, int *launched);
 int fp_pre_gemm_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride,
                        const float *skip_pm, const int *idx, const float *weight, int k1, int c2,
                        const float *wpack, const float *bias, float *out_pm, int out_stride, int cout);
@@ -1403,6 +1406,14 @@ static int fp_fused_launch(void *stream, int mode, int relu_last, int b, int n, 
     FpArgs a{b, n, m, c_known, c_skip, known_pm, skip_pm, idx, weight, out_pm, out_stride, cout, mode == 1 ? z_pm : nullptr, z_stride};
     const bool pre_form = mode == 1;
     PDM_REQUIRE(!pre_form || (long long)m * z_stride < (1ll << 31), PDM_E_TOOLARGE, "fp_mlp_fused_pre: m * z_stride overflows 32-bit row offsets");
+    if (g_fused_chain && pre_form && nlayers == 2 && z_stride >= d.K[1] &&
+        (c_skip <= 4 || (c_skip % 4 == 0 && (reinterpret_cast<uintptr_t>(skip_pm) & 15) == 0))) {
+        // many rows, widths that fit the register-resident chain (rows_chain.hip): FP1 and FP2 of the bench model
+        int launched = 0;
+        const int crc = fp_chain_launch(stream, b, n, m, c_skip, z_pm, z_stride, skip_pm, idx, weight, dims, wpack, bias, out_pm,
+                                        out_stride, cout, &launched);
+        if (crc || launched) return crc;
+    }
     if (g_fused_gemm && pre_form && nlayers == 2 && c_skip <= 4 && d.K[0] == 16 && d.K[1] >= 64 && d.K[2] >= 64 &&
         (long long)b * n >= 32768 && (long long)b * n < (1ll << 31) && z_stride >= d.K[1])
         // wide second layer over many rows: LDS-tiled GEMM, layer 1 made on the fly while staging (rows_gemm.hip)

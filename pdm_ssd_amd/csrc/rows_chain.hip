@@ -41,10 +41,11 @@ constexpr int RC_CHUNK_F4 = 16 * 64;   // 16 fragments x 64 lanes
 
 // chunk (mb0 .. mb0 + nmb - 1) x (kb0 .. kb0 + 3) of a layer with NKB k-blocks: thread t fetches lane t % 64 of
 // fragments (mb0 + i, kb0 + t / 64)
-__device__ __forceinline__ void rc_fetch(f4 (&r)[4], const f4 *__restrict__ w, int nkb, int mb0, int kb0, int nmb, int t) {
+// (nkg < 4: the layer's last, partial group of k-blocks — the waves past it fetch nothing)
+__device__ __forceinline__ void rc_fetch(f4 (&r)[4], const f4 *__restrict__ w, int nkb, int mb0, int kb0, int nmb, int t, int nkg = 4) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (i < nmb) r[i] = (w + ((size_t)(mb0 + i) * nkb + kb0) * 64)[t];   // uniform base (SGPRs) + one lane offset
+        if (i < nmb && (nkg == 4 || (t >> 6) < nkg)) r[i] = (w + ((size_t)(mb0 + i) * nkb + kb0) * 64)[t];   // uniform base (SGPRs) + one lane offset
 }
 __device__ __forceinline__ void rc_stash(const f4 (&r)[4], f4 *buf, int nmb, int t) {
 #pragma unroll
@@ -58,8 +59,7 @@ template <int NKB, int NMB>
 __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], const f4 *__restrict__ w, const float *__restrict__ bias,
                                          f4 *lds, int &p, float floor, const f4 *__restrict__ next_w, int next_nkb, int next_nmb,
                                          int t, int lane, f4 (&r)[4]) {
-    static_assert(NKB % 4 == 0, "rows_chain: layer inputs are multiples of 64 channels");
-    constexpr int KG = NKB / 4, MG = (NMB + 3) / 4, NCH = KG * MG;
+    constexpr int KG = (NKB + 3) / 4, MG = (NMB + 3) / 4, NCH = KG * MG;   // the last k-group of a layer may hold < 4 k-blocks
     const int g = lane >> 4;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) acc[mb] = *reinterpret_cast<const f4 *>(bias + 16 * mb + 4 * g);
@@ -68,20 +68,22 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
         const int mb0 = (c / KG) * 4, kb0 = (c % KG) * 4;
         constexpr int dummy = 0; (void)dummy;
         const int nmb = NMB - mb0 < 4 ? NMB - mb0 : 4;
+        const int nkg = NKB - kb0 < 4 ? NKB - kb0 : 4;
         // next chunk -> registers
         int fn = 0;
         if (c + 1 < NCH) {
             const int nm0 = ((c + 1) / KG) * 4, nk0 = ((c + 1) % KG) * 4;
             fn = NMB - nm0 < 4 ? NMB - nm0 : 4;
-            rc_fetch(r, w, NKB, nm0, nk0, fn, t);
+            rc_fetch(r, w, NKB, nm0, nk0, fn, t, NKB - nk0 < 4 ? NKB - nk0 : 4);
         } else if (next_w) {
             fn = next_nmb < 4 ? next_nmb : 4;
-            rc_fetch(r, next_w, next_nkb, 0, 0, fn, t);
+            rc_fetch(r, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
         }
         // this chunk: 4 k-blocks x nmb output blocks
         const f4 *buf = lds + p * RC_CHUNK_F4 + lane;
 #pragma unroll
         for (int kbi = 0; kbi < 4; ++kbi) {
+            if (kbi >= nkg) break;
             f4 a[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -137,15 +139,17 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     __shared__ __attribute__((aligned(16))) f4 xs[DW ? 64 * (NK0 * 4 + 1) : 1];   // DW: the patch's convolved rows (+1 quad pad)
     const int ntx = DW ? (a.dw_W + 15) / 16 : 1, nty = DW ? (a.dw_H + 3) / 4 : 1;
     const long long ntiles = DW ? (long long)(a.rows / (a.dw_H * a.dw_W)) * nty * ntx : ((long long)a.rows + 63) / 64;
+    // first chunk of layer 1 for the first tile; every later tile finds it prefetched behind the last chunk of the
+    // tile before (the weights are the same for every tile), so the stream of chunks never stops at a tile boundary
+    int p = 0;
+    rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
+    rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
+    __syncthreads();
     for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long long tile0 = tl * 64;
         // (the weight pointers pass through an empty asm so the ~140 chunk addresses are formed inside the loop with
         //  scalar adds instead of being hoisted out of it as loop invariants, where they would take every register)
         asm volatile("" : "+s"(w1), "+s"(w2), "+s"(w3));
-        // first chunk of layer 1 (the barrier of the previous iteration's last chunk makes the buffer free)
-        int p = 0;
-        rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
-        rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
         // this lane's input row: channels [16 kb + 4 g, +4) of row tile0 + 16 wave + pos
         // (DW: the workgroup owns a 4 x 16 patch of cells of one image, wave = patch row, pos = cell in it)
         long long row = tile0 + 16 * wave + pos;
@@ -165,7 +169,6 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
             const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
 #pragma unroll
             for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
-            __syncthreads();
         } else {
             // depthwise 3x3 + shift + ReLU: the patch's halo is staged through LDS 16 channels at a time (each cell of
             // the map is fetched once per workgroup instead of up to nine times), the next slice's loads in flight
@@ -226,22 +229,253 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
             }
         };
         f4 x1[NK1];
-        rc_layer<NK0, NK1>(x0, x1, w1, a.bias + a.boff[0], lds, p, (NL > 1 || a.relu_last) ? 0.0f : neg_inf, w2, NK1, NK2, t, lane, r);
+        rc_layer<NK0, NK1>(x0, x1, w1, a.bias + a.boff[0], lds, p, (NL > 1 || a.relu_last) ? 0.0f : neg_inf, NL > 1 ? w2 : w1,
+                           NL > 1 ? NK1 : NK0, NL > 1 ? NK2 : NK1, t, lane, r);
         if constexpr (NL == 1) {
             store(x1, NK1);
         } else {
             f4 x2[NK2 ? NK2 : 1];
-            rc_layer<NK1, (NK2 ? NK2 : 1)>(x1, x2, w2, a.bias + a.boff[1], lds, p, (NL > 2 || a.relu_last) ? 0.0f : neg_inf, w3, NK2, NK3, t, lane, r);
+            rc_layer<NK1, (NK2 ? NK2 : 1)>(x1, x2, w2, a.bias + a.boff[1], lds, p, (NL > 2 || a.relu_last) ? 0.0f : neg_inf,
+                                           NL > 2 ? w3 : w1, NL > 2 ? NK2 : NK0, NL > 2 ? NK3 : NK1, t, lane, r);
             if constexpr (NL == 2) {
                 store(x2, NK2);
             } else {
                 f4 x3[NK3 ? NK3 : 1];
-                rc_layer<(NK2 ? NK2 : 4), (NK3 ? NK3 : 1)>(x2, x3, w3, a.bias + a.boff[2], lds, p, a.relu_last ? 0.0f : neg_inf, nullptr, 0, 0, t,
+                rc_layer<(NK2 ? NK2 : 4), (NK3 ? NK3 : 1)>(x2, x3, w3, a.bias + a.boff[2], lds, p, a.relu_last ? 0.0f : neg_inf, w1, NK0, NK1, t,
                                                           lane, r);
                 store(x3, NK3);
             }
         }
     }
+}
+
+// ---- FP module in the hoisted form, chain in registers ---------------------------------------------------------------
+//   h1[r] = relu(sum_k w_k z[idx_k[r]] + W1s skip[r] + b1),   out[r] = relu(W2 h1[r] + b2)
+// (fused_mlp.hip "pre" form: z = W1[:, known] f was made over the m known points of each cloud.)  Same ownership as
+// rows_chain_kernel: a wave holds 16 rows and every channel; the three z rows of a point arrive as the lane's own
+// float4s of the accumulator layout (channels 16 mb + 4 g + i of row pos), requested before the skip GEMM so they
+// land under its MFMAs.  NK0 = k-blocks of the skip input (0: c_skip <= 4, applied with scalar FMAs), NK1 / NK2 =
+// blocks of h1 / out.
+#ifndef FPC_DIAG
+#define FPC_DIAG 0
+#endif
+#ifndef FPC_LATE
+#define FPC_LATE 1   // with a skip GEMM, request the z rows behind it (0: under it — 23 spilled registers at FP2's widths, 246 us against 237)
+#endif
+struct FpChainArgs {
+    int rows, n, m, c_skip, z_stride;
+    const float *z, *skip, *weight;
+    const int *idx;
+    const float *wpack, *bias;
+    int woff[2], boff[2];
+    float *out;
+    int out_stride, cout;
+};
+
+template <int NK0, int NK1, int NK2>
+__global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) {
+    static_assert(NK1 % 8 == 0 && NK2 % 8 == 0, "fp_chain: widths are multiples of 128 channels (one staging pass)");
+    __shared__ __attribute__((aligned(16))) f4 lds[2 * RC_CHUNK_F4];
+    // per-wave transposition buffer: 16 rows x 128 channels (+1 quad per row: D-layout reads of a 16-lane group then
+    // touch 16 different bank quads).  Gathers and stores move whole 128-byte lines per row (8 lanes x 16 B); the
+    // accumulator layout (lane (pos, g) = channels 16 mb + 4 g + i of row pos) would move 64-byte halves of them.
+    constexpr int SQ = 33;
+    __shared__ __attribute__((aligned(16))) f4 stage_all[4 * 16 * SQ];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int pos = lane & 15, g = lane >> 4;
+    const int grow = lane >> 3, gq = lane & 7;   // line-wise role: rows grow and grow + 8 of the wave's tile, quad gq + 8 j
+    f4 *stage = stage_all + wave * 16 * SQ;
+    const f4 *w1 = reinterpret_cast<const f4 *>(a.wpack + a.woff[0]);
+    const f4 *w2 = reinterpret_cast<const f4 *>(a.wpack + a.woff[1]);
+    const float neg_inf = -__builtin_inff();
+    f4 r[4];
+    const long long ntiles = ((long long)a.rows + 63) / 64;
+    // Workgroups are dealt to the 8 XCDs round-robin; when the clouds split evenly, XCD x walks clouds x, x + 8, ... so
+    // its L2 holds one cloud's z rows at a time (2 MB at FP1's shape) instead of a slice of every cloud in flight.
+    const int tpc = a.n / 64, nclouds = a.rows / a.n;
+    const bool by_xcd = tpc * 64 == a.n && (nclouds & 7) == 0 && (gridDim.x & 7) == 0;
+    const long long per_xcd = by_xcd ? (long long)(nclouds >> 3) * tpc : 0;
+    const long long first = by_xcd ? (blockIdx.x >> 3) : blockIdx.x, step = by_xcd ? (gridDim.x >> 3) : gridDim.x,
+                    last = by_xcd ? per_xcd : ntiles;
+    const float *__restrict__ zbase = a.z;
+    auto tile_of = [&](long long u) { return by_xcd ? ((u / tpc) * 8 + (blockIdx.x & 7)) * tpc + u % tpc : u; };
+    // line-wise rows of this lane in tile tl: neighbours as 32-bit element offsets from the uniform base
+    // (b m z_stride < 2^31, host check), their weights
+    auto neighbours = [&](long long tl, unsigned (&ze)[2][3], float (&zw)[2][3]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            long long rr = tl * 64 + 16 * wave + grow + 8 * h;
+            if (rr >= a.rows) rr = a.rows - 1;
+            const unsigned zrow0 = (unsigned)(rr / a.n) * (unsigned)a.m;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ze[h][k] = (zrow0 + (unsigned)a.idx[rr * 3 + k]) * (unsigned)a.z_stride + 4u * gq;
+                zw[h][k] = a.weight[rr * 3 + k];
+            }
+        }
+    };
+    unsigned ze[2][3];
+    float zw[2][3];
+    f4 zv[2][3][4];
+    auto request = [&](int cb) {   // channels [cb, cb + 128) of the six rows
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#if FPC_DIAG & 1   // timing build (tools/diag/fp_chain_rate.py): no z gathers
+                    zv[h][k][j] = f4{zw[h][k], 0.f, 0.f, 0.f};
+                    continue;
+#endif
+                    zv[h][k][j] = *reinterpret_cast<const f4 *>(zbase + (ze[h][k] + (unsigned)(cb + 32 * j)));
+                }
+    };
+    // interpolate (pinned order, as three_interpolate) and park the 16 x 128 block in the staging buffer
+    auto park = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f4 z0 = zv[h][0][j], z1 = zv[h][1][j], z2 = zv[h][2][j];
+                f4 v;
+                v.x = fmaf(zw[h][2], z2.x, fmaf(zw[h][1], z1.x, zw[h][0] * z0.x));
+                v.y = fmaf(zw[h][2], z2.y, fmaf(zw[h][1], z1.y, zw[h][0] * z0.y));
+                v.z = fmaf(zw[h][2], z2.z, fmaf(zw[h][1], z1.z, zw[h][0] * z0.z));
+                v.w = fmaf(zw[h][2], z2.w, fmaf(zw[h][1], z1.w, zw[h][0] * z0.w));
+                stage[(grow + 8 * h) * SQ + gq + 8 * j] = v;
+            }
+    };
+    // The weight chunks stream without a stop at tile boundaries: the first chunk of a tile is prefetched behind the
+    // last chunk of the tile before.  The z rows of a tile are requested one tile ahead (see the loop).
+    int p = 0;
+    if constexpr (NK0 > 0) {
+        rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t, NK0 < 4 ? NK0 : 4);
+        rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
+    } else {
+        rc_fetch(r, w2, NK1, 0, 0, NK2 < 4 ? NK2 : 4, t, NK1 < 4 ? NK1 : 4);
+        rc_stash(r, lds, NK2 < 4 ? NK2 : 4, t);
+    }
+    __syncthreads();
+    for (long long u = first; u < last; u += step) {
+        const long long tl = tile_of(u);
+        asm volatile("" : "+s"(w1), "+s"(w2));
+        const long long wrow0 = tl * 64 + 16 * wave;
+        long long row = wrow0 + pos;          // accumulator-layout row of this lane
+        if (row >= a.rows) row = a.rows - 1;
+        const long long lrow[2] = {wrow0 + grow, wrow0 + grow + 8};
+        neighbours(tl, ze, zw);
+        if constexpr (NK0 == 0 || !FPC_LATE) request(0);
+        f4 x1[NK1];
+        if constexpr (NK0 > 0) {
+            f4 x0[NK0];
+            const float *__restrict__ src = a.skip + (size_t)row * a.c_skip + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < NK0; ++kb) {
+                x0[kb] = f4{0.f, 0.f, 0.f, 0.f};
+                if (16 * kb + 4 * g + 4 <= a.c_skip) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);   // c_skip % 4 == 0 (host check)
+            }
+            rc_layer<NK0, NK1>(x0, x1, w1, a.bias + a.boff[0], lds, p, neg_inf, w2, NK1, NK2, t, lane, r);
+            if constexpr (FPC_LATE) request(0);
+        } else {
+            // c_skip <= 4 raw input channels; the packed layer-1 weights are zero past c_skip, so all four terms are formed
+            const float *__restrict__ sp = a.skip + (size_t)row * a.c_skip;
+            const float s0 = a.c_skip > 0 ? sp[0] : 0.f, s1 = a.c_skip > 1 ? sp[1] : 0.f, s2 = a.c_skip > 2 ? sp[2] : 0.f,
+                        s3 = a.c_skip > 3 ? sp[3] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < NK1; ++mb) {
+                x1[mb] = *reinterpret_cast<const f4 *>(a.bias + a.boff[0] + 16 * mb + 4 * g);
+                const f4 *wr = w1 + (size_t)mb * 64 + 4 * g;   // layer 1 packed with ONE k-block: W1[16 mb + 4 g + j][0..3] = wr[j]
+                const f4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
+                x1[mb].x += fmaf(q0.w, s3, fmaf(q0.z, s2, fmaf(q0.y, s1, q0.x * s0)));
+                x1[mb].y += fmaf(q1.w, s3, fmaf(q1.z, s2, fmaf(q1.y, s1, q1.x * s0)));
+                x1[mb].z += fmaf(q2.w, s3, fmaf(q2.z, s2, fmaf(q2.y, s1, q2.x * s0)));
+                x1[mb].w += fmaf(q3.w, s3, fmaf(q3.z, s2, fmaf(q3.y, s1, q3.x * s0)));
+            }
+        }
+        // h1 = relu(. + interpolated z), 128 channels per staging pass
+#pragma unroll
+        for (int mb0 = 0; mb0 < NK1; mb0 += 8) {
+            park();
+            if (mb0 + 8 < NK1) request(16 * (mb0 + 8));
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f4 v = stage[pos * SQ + 4 * i + g];
+                f4 &h = x1[mb0 + i];
+                h.x = fmaxf(h.x + v.x, 0.f); h.y = fmaxf(h.y + v.y, 0.f); h.z = fmaxf(h.z + v.z, 0.f); h.w = fmaxf(h.w + v.w, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        f4 x2[NK2];
+        // one line-wise piece (row grow + 8 h, quads gq + 8 j of channel block mb0) from the staging buffer to memory
+        auto store_piece = [&](const long long (&lr)[2], int mb0, int h, int j) {
+            if (lr[h] >= a.rows) return;
+            float *__restrict__ orow = a.out + (size_t)lr[h] * a.out_stride + 16 * mb0;
+            const f4 v = stage[(grow + 8 * h) * SQ + gq + 8 * j];
+            const int c0 = 16 * mb0 + 4 * (gq + 8 * j);
+            if (c0 + 4 <= a.cout) *reinterpret_cast<f4 *>(orow + 4 * (gq + 8 * j)) = v;
+            else {
+                if (c0 < a.cout) orow[4 * (gq + 8 * j)] = v.x;
+                if (c0 + 1 < a.cout) orow[4 * (gq + 8 * j) + 1] = v.y;
+                if (c0 + 2 < a.cout) orow[4 * (gq + 8 * j) + 2] = v.z;
+            }
+        };
+#if FPC_DIAG & 4   // timing build: no second layer
+#pragma unroll
+        for (int mb = 0; mb < NK2; ++mb) x2[mb] = x1[mb % NK1];
+        __syncthreads();
+#else
+        rc_layer<NK1, NK2>(x1, x2, w2, a.bias + a.boff[1], lds, p, 0.0f, NK0 > 0 ? w1 : w2, NK0 > 0 ? NK0 : NK1, NK0 > 0 ? NK1 : NK2, t, lane, r);
+#endif
+        // rows leave line-wise through the same buffer.  (Measured and dropped: the next tile's z rows requested ahead
+        // of these stores, 272 us against 258 at FP1's shape; the stores deferred by a tile and spread behind the next
+        // tile's weight chunks, 407 us — vmcnt retires in order, so every chunk's prefetch then waits for stores.)
+#if !(FPC_DIAG & 2)
+#pragma unroll
+        for (int mb0 = 0; mb0 < NK2; mb0 += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stage[pos * SQ + 4 * i + g] = x2[mb0 + i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) store_piece(lrow, mb0, h, j);
+            __builtin_amdgcn_wave_barrier();
+        }
+#endif
+    }
+}
+
+static int g_fpc_pad_lds = 0;   // diagnostic: extra dynamic LDS per workgroup (forces one workgroup per CU at 90 KB)
+extern "C" int pdm_tune_fp_chain_pad_lds(int bytes) { const int old = g_fpc_pad_lds; g_fpc_pad_lds = bytes; return old; }
+
+// Returns 1 in *launched when an instantiation fits (two-layer FP module, hoisted form, many rows).
+int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride, const float *skip_pm,
+                    const int *idx, const float *weight, const int *dims, const float *wpack, const float *bias, float *out_pm,
+                    int out_stride, int cout, int *launched) {
+    *launched = 0;
+    const long long rows = (long long)b * n;
+    if (rows < 32768 || rows >= (1ll << 31) || (long long)b * m * z_stride >= (1ll << 31)) return 0;
+    FpChainArgs a{};
+    a.rows = (int)rows; a.n = n; a.m = m; a.c_skip = c_skip; a.z_stride = z_stride;
+    a.z = z_pm; a.skip = skip_pm; a.weight = weight; a.idx = idx; a.wpack = wpack; a.bias = bias;
+    a.woff[0] = 0; a.boff[0] = 0; a.woff[1] = dims[0] * dims[1]; a.boff[1] = dims[1];
+    a.out = out_pm; a.out_stride = out_stride; a.cout = cout;
+    const long long tiles = (rows + 63) / 64;
+    int grid = (int)(tiles < 256 * 12 ? tiles : 256 * 12);
+    if (grid >= 8) grid &= ~7;   // a multiple of the 8 XCDs (the tile loop covers the rest)
+#define FC_TRY(K0, K1, K2, COND)                                                                                      \
+    if ((COND) && dims[1] == 16 * K1 && dims[2] == 16 * K2) {                                                        \
+        if (g_fpc_pad_lds > 65536 - 50000) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_chain_kernel<K0, K1, K2>), hipFuncAttributeMaxDynamicSharedMemorySize, g_fpc_pad_lds); \
+        hipLaunchKernelGGL((fp_chain_kernel<K0, K1, K2>), dim3(grid), dim3(RC_THREADS), g_fpc_pad_lds, as_stream(stream), a);    \
+        *launched = 1;                                                                                               \
+        return check_launch("fp_mlp_fused_pre(chain)");                                                              \
+    }
+    FC_TRY(0, 8, 8, c_skip <= 4 && dims[0] == 16)                               // FP1: raw input channels -> 128 -> 128
+    FC_TRY(6, 16, 16, c_skip % 4 == 0 && c_skip > 4 && dims[0] == 96)           // FP2: 96 skip channels -> 256 -> 256
+#undef FC_TRY
+    return 0;
 }
 
 static bool rc_shape_is(int nlayers, const int *dims, int k0, int k1, int k2, int k3) {

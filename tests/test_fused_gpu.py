@@ -66,6 +66,8 @@ def test_sa_fused_matches_cpu_graph(dev, cin, mlps, nsamples):
     (256, 1, [128, 128], 1000, 300),      # FP1 shapes: c_skip = 1, n not a multiple of 16
     (40, 0, [64, 32], 333, 50),           # no skip features
     (36, 6, [48], 100, 20),               # single layer, unaligned skip rows
+    (256, 1, [128, 128], 16390, 4096),    # FP1 at full size: the register-resident chain (rows_chain.hip), tiles across clouds
+    (512, 96, [256, 256], 16390, 1024),   # FP2 widths over enough rows for the chain: skip GEMM with a partial k-group
 ])
 def test_fp_fused_matches_cpu_graph(dev, ck, cs, mlp, n, m):
     from oracle import cpu_backbone
