@@ -328,6 +328,23 @@ int pdm_stack_vector_pool_grad(void *stream, const float *grad_new_features, con
                                const int *grouped_idxs, float *grad_support_features, int N, int M, int num_c_out,
                                int num_c_in, int num_total_grids, int num_entries);
 
+/* ---- training-mode BatchNorm + ReLU as one operator (configs[3], the shared MLPs' Conv/Linear -> BN -> ReLU triples:
+ * pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:19-55, models/dense_heads/point_head_template.py:35-48) ----
+ * dtype 0 = fp32, 1 = bf16 activations (statistics, gamma/beta and gradients of gamma/beta always fp32).
+ * layout 0: x is (n rows, C) with the channel fastest, C a multiple of 4 (fp32) / 8 (bf16); L ignored.
+ * layout 1: x is (n, C, L) with the position fastest, L a multiple of 4 / 8.
+ * forward: batch mean / biased variance per channel, y = [relu]((x - mean) * invstd * gamma + beta); running_mean /
+ *   running_var (may be null) updated as torch.nn.BatchNorm does (momentum, unbiased variance); coef (4, C) fp32 =
+ *   [mean | invstd | gamma*invstd | beta] is what the backward needs besides x.
+ * backward: dx (same type and layout as x), grads (4, C) fp32 = [dgamma | dbeta | p | q] (dx = gamma invstd (g - p - (x - mean) q)).
+ * partial: workspace of pdm_bn_parts(layout, n, C, L) * C * 2 floats (slice sums, folded in double: reproducible). */
+int pdm_bn_parts(int layout, long long n, int C, long long L);
+int pdm_bn_relu_forward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, void *y,
+                        const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                        float *running_var, float *coef, float *partial, int relu);
+int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
+                         void *dx, const float *coef, float *grads, float *partial, int relu);
+
 /* ---- hybrid head (north_star configs[2]: "backbone + PDM neck + hybrid head"; no reference source: SURVEY.md F1) ----
  * Depthwise 3x3 convolution + folded BatchNorm + ReLU over the neck's channels-last BEV grid, the context stage of
  * the heat-map head (pdm_ssd_amd/dense_heads/pdm_heatmap_head.py); the point head's MLPs and the heat-map head's 1x1

@@ -1,0 +1,376 @@
+// Training-mode BatchNorm + ReLU as one operator (forward and backward), for the shared MLPs of the train step
+// (Conv/Linear -> BatchNorm -> ReLU triples of pointnet2_modules.py:19-55, point_head_template.py:35-48 of the
+// reference, which run them as three torch modules).  Batch statistics in fp32 whatever the activation type (fp32 or
+// bf16 under autocast), two layouts:
+//   CL  rows x C, channel fastest   (Linear outputs, channels-last conv outputs: SA groups, BEV maps)
+//   CF  n x C x L, position fastest (NCHW / NCL tensors: FP modules, the neck's projection)
+// Passes: forward  = statistics (1 read) -> per-channel finalize -> normalise + ReLU (1 read, 1 write)
+//         backward = two sums per channel (2 reads) -> finalize -> input gradient (2 reads, 1 write)
+// Bound: HBM.  Partial sums go to a (parts, C, 2) buffer and are folded in double by the finalize kernels, so a run is
+// bit-reproducible (no float atomics).
+#include "common.h"
+
+namespace pdm {
+
+template <class T> struct BnVec;
+template <> struct BnVec<float> {
+    static constexpr int V = 4;
+    typedef float4 raw;
+    __device__ static void load(const float *p, float (&v)[4]) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    __device__ static void store(float *p, const float (&v)[4]) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round to nearest even; NaN stays NaN
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+template <> struct BnVec<bf16_t> {
+    static constexpr int V = 8;
+    __device__ static void load(const bf16_t *p, float (&v)[8]) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ static void store(bf16_t *p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+struct BnCoef {   // per-channel constants, all (C) fp32
+    const float *mean, *invstd, *scale, *shift;   // scale = gamma * invstd, shift = beta:  y = (x - mean) * scale + beta
+    const float *p, *q;                           // backward: dx = scale * (g - p - (x - mean) * q), p = sum(g) / count, q = invstd sum(g xhat) / count
+    float *pivot;                                 // statistics pass: per-channel shift of the sums (the channel's first element)
+};
+
+template <int V>
+__device__ __forceinline__ void ldv(const float *p, float (&v)[V]) {   // V consecutive floats, 16-byte aligned
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p + i);
+        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+}
+
+// ---- CL: rows x C.  A workgroup walks rows blockIdx.x * RPP + k * gridDim.x * RPP; thread = (row in pass, V channels) --
+// MODE 0: sums of x and x^2.  MODE 1: sums of g and g * xhat with g = dy * [x scale + shift > 0] (or dy when !relu).
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void bn_cl_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dy, long long rows, int C,
+                                                           BnCoef k, int relu, float *__restrict__ partial) {
+    constexpr int V = BnVec<T>::V;
+    __shared__ float s_a[256 * V], s_b[256 * V];
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int rin = threadIdx.x / tpr, col = (threadIdx.x % tpr) * V;
+    float a[V], b[V], mean[V], istd[V], sc[V], sh[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a[i] = b[i] = 0.f; mean[i] = istd[i] = sc[i] = sh[i] = 0.f; }
+    if (rin < rpp) {
+        if (MODE == 1) { ldv<V>(k.mean + col, mean); ldv<V>(k.invstd + col, istd); ldv<V>(k.scale + col, sc); ldv<V>(k.shift + col, sh); }
+        else {
+            // sums are taken of x - pivot (pivot = the channel's first element): E[x^2] - E[x]^2 then loses nothing to a large mean
+            BnVec<T>::load(x + col, mean);
+            if (blockIdx.x == 0 && rin == 0) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) k.pivot[col + i] = mean[i];
+            }
+        }
+    }
+    if (rin < rpp) {
+        for (long long r = (long long)blockIdx.x * rpp + rin; r < rows; r += (long long)gridDim.x * rpp) {
+            float xv[V];
+            BnVec<T>::load(x + r * C + col, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) { const float d = xv[i] - mean[i]; a[i] += d; b[i] = fmaf(d, d, b[i]); }
+            } else {
+                float gv[V];
+                BnVec<T>::load(dy + r * C + col, gv);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float d = xv[i] - mean[i];
+                    const float g = (!relu || fmaf(d, sc[i], sh[i]) > 0.f) ? gv[i] : 0.f;
+                    a[i] += g;
+                    b[i] = fmaf(g, d * istd[i], b[i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s_a[threadIdx.x * V + i] = a[i]; s_b[threadIdx.x * V + i] = b[i]; }
+    __syncthreads();
+    // channel c of this workgroup = sum over the rpp row slots; one thread per channel
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float ta = 0.f, tb = 0.f;
+        const int t0 = c / V, i = c % V;
+        for (int q = 0; q < rpp; ++q) { ta += s_a[(q * tpr + t0) * V + i]; tb += s_b[(q * tpr + t0) * V + i]; }
+        partial[((size_t)blockIdx.x * C + c) * 2] = ta;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = tb;
+    }
+}
+
+// MODE 0: y = [relu](x scale + shift).  MODE 1: dx = scale * (g - k1 - xhat k2).
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void bn_cl_apply_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ out,
+                                                          long long nvec, int C, BnCoef k, int relu) {
+    constexpr int V = BnVec<T>::V;
+    const int tpr = C / V;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long long)gridDim.x * 256) {
+        const int col = (int)(e % tpr) * V;
+        float xv[V], ov[V], sc[V], sh[V], mu[V];
+        BnVec<T>::load(x + e * V, xv);
+        ldv<V>(k.scale + col, sc); ldv<V>(k.shift + col, sh); ldv<V>(k.mean + col, mu);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float y = fmaf(xv[i] - mu[i], sc[i], sh[i]);   // the centred form: no cancellation when |mean| >> std
+                ov[i] = relu ? fmaxf(y, 0.f) : y;
+            }
+        } else {
+            float gv[V], pp[V], qq[V];
+            BnVec<T>::load(dy + e * V, gv);
+            ldv<V>(k.p + col, pp); ldv<V>(k.q + col, qq);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float d = xv[i] - mu[i];
+                const float g = (!relu || fmaf(d, sc[i], sh[i]) > 0.f) ? gv[i] : 0.f;
+                ov[i] = sc[i] * (g - pp[i] - d * qq[i]);
+            }
+        }
+        BnVec<T>::store(out + e * V, ov);
+    }
+}
+
+// ---- CF: n x C x L.  blockIdx.x = channel, blockIdx.y = slice of the n * (L / V) vectors of that channel -------------
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void bn_cf_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dy, long long n, int C, long long L,
+                                                           BnCoef k, int relu, float *__restrict__ partial) {
+    constexpr int V = BnVec<T>::V;
+    __shared__ float s_a[256], s_b[256];
+    const int c = blockIdx.x;
+    const long long lv = L / V, total = n * lv;
+    float a = 0.f, b = 0.f;
+    float mean = MODE ? k.mean[c] : 0.f;
+    const float istd = MODE ? k.invstd[c] : 0.f, sc = MODE ? k.scale[c] : 0.f, sh = MODE ? k.shift[c] : 0.f;
+    if (MODE == 0) {   // pivot = the channel's first element (see the CL kernel)
+        float first[V];
+        BnVec<T>::load(x + (size_t)c * L, first);
+        mean = first[0];
+        if (blockIdx.y == 0 && threadIdx.x == 0) k.pivot[c] = mean;
+    }
+    for (long long e = (long long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long long)gridDim.y * 256) {
+        const long long s = e / lv, l = (e - s * lv) * V;
+        const size_t off = ((size_t)s * C + c) * L + l;
+        float xv[V];
+        BnVec<T>::load(x + off, xv);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) { const float d = xv[i] - mean; a += d; b = fmaf(d, d, b); }
+        } else {
+            float gv[V];
+            BnVec<T>::load(dy + off, gv);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float d = xv[i] - mean;
+                const float g = (!relu || fmaf(d, sc, sh) > 0.f) ? gv[i] : 0.f;
+                a += g;
+                b = fmaf(g, d * istd, b);
+            }
+        }
+    }
+    s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (threadIdx.x < half) { s_a[threadIdx.x] += s_a[threadIdx.x + half]; s_b[threadIdx.x] += s_b[threadIdx.x + half]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[((size_t)blockIdx.y * C + c) * 2] = s_a[0];
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = s_b[0];
+    }
+}
+
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void bn_cf_apply_kernel(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ out,
+                                                          long long nvec, int C, long long L, BnCoef k, int relu) {
+    constexpr int V = BnVec<T>::V;
+    const long long lv = L / V;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long long)gridDim.x * 256) {
+        const int c = (int)((e / lv) % C);
+        float xv[V], ov[V];
+        BnVec<T>::load(x + e * V, xv);
+        const float sc = k.scale[c], sh = k.shift[c], mu = k.mean[c];
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float y = fmaf(xv[i] - mu, sc, sh);
+                ov[i] = relu ? fmaxf(y, 0.f) : y;
+            }
+        } else {
+            float gv[V];
+            BnVec<T>::load(dy + e * V, gv);
+            const float pp = k.p[c], qq = k.q[c];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float d = xv[i] - mu;
+                const float g = (!relu || fmaf(d, sc, sh) > 0.f) ? gv[i] : 0.f;
+                ov[i] = sc * (g - pp - d * qq);
+            }
+        }
+        BnVec<T>::store(out + e * V, ov);
+    }
+}
+
+// ---- per-channel finalize: one wave per channel folds the parts in double -------------------------------------------
+__device__ __forceinline__ void bn_fold(const float *__restrict__ partial, int parts, int C, int c, double &s, double &q) {
+    __shared__ double sh_s[64], sh_q[64];
+    double ls = 0.0, lq = 0.0;
+    for (int p = threadIdx.x; p < parts; p += 64) { ls += partial[((size_t)p * C + c) * 2]; lq += partial[((size_t)p * C + c) * 2 + 1]; }
+    sh_s[threadIdx.x] = ls; sh_q[threadIdx.x] = lq;
+    __syncthreads();
+    for (int half = 32; half >= 1; half >>= 1) {
+        if ((int)threadIdx.x < half) { sh_s[threadIdx.x] += sh_s[threadIdx.x + half]; sh_q[threadIdx.x] += sh_q[threadIdx.x + half]; }
+        __syncthreads();
+    }
+    s = sh_s[0]; q = sh_q[0];
+}
+// forward: mean, biased variance -> invstd, scale, shift; running statistics updated as torch.nn.BatchNorm does
+// (momentum, unbiased variance).  coef layout: [mean | invstd | gamma invstd | beta] (4, C); on entry row 3 holds the pivots.
+__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const float *__restrict__ partial, int parts, int C, double count,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                             float momentum, float *running_mean, float *running_var,
+                                                             float *__restrict__ coef) {
+    const int c = blockIdx.x;
+    double s, q;
+    bn_fold(partial, parts, C, c, s, q);
+    if (threadIdx.x != 0) return;
+    const double dm = s / count, mean = (double)coef[3 * C + c] + dm;
+    double var = q / count - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float scale = g * invstd;
+    coef[c] = (float)mean; coef[C + c] = invstd; coef[2 * C + c] = scale; coef[3 * C + c] = b;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+// backward: dbeta = sum g, dgamma = sum g xhat; the input gradient is dx = scale (g - p - (x - mean) q) with
+// p = dbeta / count, q = invstd dgamma / count.  out layout [dgamma | dbeta | p | q]
+__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const float *__restrict__ partial, int parts, int C, double count,
+                                                             const float *__restrict__ coef, float *__restrict__ out) {
+    const int c = blockIdx.x;
+    double s, q;
+    bn_fold(partial, parts, C, c, s, q);
+    if (threadIdx.x != 0) return;
+    out[c] = (float)q; out[C + c] = (float)s;
+    out[2 * C + c] = (float)(s / count);
+    out[3 * C + c] = (float)((double)coef[C + c] * q / count);
+}
+
+static int bn_check(const char *who, int dtype, int layout, long long n, int C, long long L, const void *p0, const void *p1) {
+    PDM_REQUIRE(dtype == 0 || dtype == 1, PDM_E_BADARG, "%s: dtype %d (0 = fp32, 1 = bf16)", who, dtype);
+    PDM_REQUIRE(layout == 0 || layout == 1, PDM_E_BADARG, "%s: layout %d (0 = rows x C, 1 = n x C x L)", who, layout);
+    const int V = dtype ? 8 : 4;
+    PDM_REQUIRE(n >= 0 && C >= 1 && L >= 1, PDM_E_BADARG, "%s: n=%lld C=%d L=%lld", who, n, C, L);
+    if (layout == 0) PDM_REQUIRE(C % V == 0 && C / V <= 256, PDM_E_BADARG, "%s: rows x C needs C a multiple of %d, at most %d", who, V, 256 * V);
+    else PDM_REQUIRE(L % V == 0 && C <= 65535, PDM_E_BADARG, "%s: n x C x L needs L a multiple of %d", who, V);
+    PDM_REQUIRE(n == 0 || (p0 && p1), PDM_E_BADARG, "%s: null pointer", who);
+    PDM_REQUIRE(((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1)) & 15) == 0, PDM_E_BADARG, "%s: buffers must be 16-byte aligned", who);
+    return 0;
+}
+
+static BnCoef coef_of(const float *coef, const float *bwd, int C) {
+    BnCoef k{};
+    if (coef) { k.mean = coef; k.invstd = coef + C; k.scale = coef + 2 * C; k.shift = coef + 3 * C; }
+    if (bwd) { k.p = bwd + 2 * C; k.q = bwd + 3 * C; }
+    return k;
+}
+
+}  // namespace pdm
+
+using namespace pdm;
+
+// Number of partial-sum slices the reduce passes write for this shape ((parts, C, 2) floats of workspace).
+extern "C" int pdm_bn_parts(int layout, long long n, int C, long long L) {
+    const long long elems = n * (layout ? L : 1) * (layout ? 1 : C);
+    if (layout == 0) { const long long want = (elems + 65535) / 65536; return (int)(want < 1 ? 1 : want > 1024 ? 1024 : want); }
+    const long long want = (n * L + 32767) / 32768;   // slices per channel
+    return (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+}
+
+// Forward: statistics + finalize + y = [relu]((x - mean) invstd gamma + beta).  coef (4, C) fp32 is kept for the backward.
+// n = rows (layout 0, L ignored) or batch entries (layout 1).  running_mean / running_var may be null.
+extern "C" int pdm_bn_relu_forward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, void *y,
+                                   const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                   float *running_var, float *coef, float *partial, int relu) {
+    if (layout == 0) L = 1;
+    if (int rc = bn_check("bn_relu_forward", dtype, layout, n, C, L, x, y)) return rc;
+    PDM_REQUIRE(coef && partial, PDM_E_BADARG, "bn_relu_forward: null workspace");
+    if (n == 0) return 0;
+    const int parts = pdm_bn_parts(layout, n, C, L);
+    BnCoef none{};
+    none.pivot = coef + 3 * (size_t)C;   // parked in the shift row until the finalize kernel replaces it
+    const int V = dtype ? 8 : 4;
+    const long long nvec = n * C * L / V;
+    const long long ag = (nvec + 255) / 256;
+    const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
+    if (layout == 0) {
+        if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, n, C, none, relu, partial);
+        else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, n, C, none, relu, partial);
+    } else {
+        if (dtype) hipLaunchKernelGGL((bn_cf_reduce_kernel<bf16_t, 0>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, n, C, L, none, relu, partial);
+        else hipLaunchKernelGGL((bn_cf_reduce_kernel<float, 0>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, n, C, L, none, relu, partial);
+    }
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n * (double)L, gamma,
+                       beta, eps, momentum, running_mean, running_var, coef);
+    const BnCoef k = coef_of(coef, nullptr, C);
+    if (layout == 0) {
+        if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, k, relu);
+        else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, (float *)y, nvec, C, k, relu);
+    } else {
+        if (dtype) hipLaunchKernelGGL((bn_cf_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, L, k, relu);
+        else hipLaunchKernelGGL((bn_cf_apply_kernel<float, 0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, (float *)y, nvec, C, L, k, relu);
+    }
+    return check_launch("bn_relu_forward");
+}
+
+// Backward: dx, and grads (4, C) = [dgamma | dbeta | k1 | k2] (the caller reads the first two rows).
+extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
+                                    void *dx, const float *coef, float *grads, float *partial, int relu) {
+    if (layout == 0) L = 1;
+    if (int rc = bn_check("bn_relu_backward", dtype, layout, n, C, L, x, dy)) return rc;
+    PDM_REQUIRE(coef && grads && partial && (n == 0 || dx), PDM_E_BADARG, "bn_relu_backward: null pointer");
+    PDM_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, PDM_E_BADARG, "bn_relu_backward: dx must be 16-byte aligned");
+    if (n == 0) return 0;
+    const int parts = pdm_bn_parts(layout, n, C, L);
+    const int V = dtype ? 8 : 4;
+    const long long nvec = n * C * L / V;
+    const long long ag = (nvec + 255) / 256;
+    const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
+    BnCoef k = coef_of(coef, nullptr, C);
+    if (layout == 0) {
+        if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, k, relu, partial);
+        else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, k, relu, partial);
+    } else {
+        if (dtype) hipLaunchKernelGGL((bn_cf_reduce_kernel<bf16_t, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, L, k, relu, partial);
+        else hipLaunchKernelGGL((bn_cf_reduce_kernel<float, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, L, k, relu, partial);
+    }
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n * (double)L, coef, grads);
+    k = coef_of(coef, grads, C);
+    if (layout == 0) {
+        if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, k, relu);
+        else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, k, relu);
+    } else {
+        if (dtype) hipLaunchKernelGGL((bn_cf_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, L, k, relu);
+        else hipLaunchKernelGGL((bn_cf_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, L, k, relu);
+    }
+    return check_launch("bn_relu_backward");
+}

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from ..utils import centernet_utils, loss_utils
 from .point_head_template import _get
+from ..fused_bn import TrainSequential
 
 
 class _Depthwise3x3CL(torch.autograd.Function):
@@ -97,7 +98,7 @@ class PDMHeatmapHead(nn.Module):
             else:
                 layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
             c = width
-        self.shared_conv = nn.Sequential(*layers)
+        self.shared_conv = TrainSequential(*layers)
         self.hm = nn.Sequential(nn.Conv2d(c, width, 1, bias=True), nn.ReLU(), nn.Conv2d(width, num_class, 1, bias=True))
         self.hm[-1].bias.data.fill_(-2.19)   # CenterPoint's prior: sigmoid(-2.19) = 0.1 (center_head.py:47)
         self.add_module('hm_loss_func', loss_utils.FocalLossCenterNet())

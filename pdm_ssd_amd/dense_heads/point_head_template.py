@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from ..iou3d_nms import iou3d_nms_utils
 from ..utils import loss_utils
+from ..fused_bn import TrainSequential
 
 
 def _get(cfg, key, default=None):
@@ -47,7 +48,7 @@ class PointHeadTemplate(nn.Module):
             layers.extend([nn.Linear(c_in, width, bias=False), nn.BatchNorm1d(width), nn.ReLU()])
             c_in = width
         layers.append(nn.Linear(c_in, output_channels, bias=True))
-        return nn.Sequential(*layers)
+        return TrainSequential(*layers)   # nn.Sequential whose BatchNorm + ReLU pairs run fused in training (fused_bn.py)
 
     # ------------------------------------------------------------------ targets
 

@@ -1,0 +1,112 @@
+"""Training-mode BatchNorm + ReLU as ONE operator (HIP kernels of csrc/bn_relu.hip) and the Sequential that uses it.
+
+The reference builds its shared MLPs as torch triples Conv/Linear -> BatchNorm -> ReLU
+(/root/reference/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:19-55,
+models/dense_heads/point_head_template.py:35-48); in a train step on MI355X the BatchNorm and ReLU kernels of
+torch / MIOpen took about a quarter of the device time at a fraction of the HBM rate (profiles/).  `TrainSequential` is
+a drop-in `nn.Sequential` (same child indices, hence the same state_dict keys) that, in training mode on the GPU,
+runs every (BatchNorm, ReLU) pair after a convolution / linear layer as one forward kernel pair and one backward
+kernel pair, statistics in fp32, activations fp32 or bf16 (autocast).  Anything it does not recognise — eval mode,
+CPU tensors, exotic shapes, `momentum=None`, `track_running_stats=False` — goes through the torch modules unchanged.
+"""
+import os
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _native
+
+ENABLED = os.environ.get("PDM_FUSED_BN", "1") != "0"
+
+
+def _layout(x):
+    """(layout, n, L) of the C-ABI for a dense (N, C, ...) tensor, or None when neither layout applies."""
+    if x.dim() < 2 or x.numel() == 0:
+        return None
+    C = x.shape[1]
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    if x.dim() == 2:
+        return (0, x.shape[0], 1) if x.is_contiguous() and C % v == 0 and C // v <= 256 else None
+    L = x.numel() // (x.shape[0] * C)
+    if x.is_contiguous():
+        if L == 1:
+            return (0, x.shape[0], 1) if C % v == 0 and C // v <= 256 else None
+        return (1, x.shape[0], L) if L % v == 0 and C <= 65535 else None
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return (0, x.numel() // C, 1) if C % v == 0 and C // v <= 256 else None
+    return None
+
+
+class _BnRelu(Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L):
+        C = x.shape[1]
+        dtype = 1 if x.dtype == torch.bfloat16 else 0
+        y = torch.empty_like(x)
+        coef = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        parts = _native.lib().pdm_bn_parts(layout, n, C, L)
+        partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
+        _native.call("pdm_bn_relu_forward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
+                     y.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), float(momentum),
+                     0 if running_mean is None else running_mean.data_ptr(), 0 if running_var is None else running_var.data_ptr(),
+                     coef.data_ptr(), partial.data_ptr(), int(relu))
+        ctx.save_for_backward(x, coef)
+        ctx.meta = (dtype, layout, n, C, L, int(relu), parts)
+        ctx.mark_non_differentiable()
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, coef = ctx.saved_tensors
+        dtype, layout, n, C, L, relu, parts = ctx.meta
+        if dy.dtype != x.dtype or dy.stride() != x.stride():
+            dy = torch.empty_like(x).copy_(dy)       # same type and memory format as x
+        dx = torch.empty_like(x)
+        grads = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
+        _native.call("pdm_bn_relu_backward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
+                     dy.data_ptr(), dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), relu)
+        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None
+
+
+def applies(x, bn):
+    return (ENABLED and bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32
+            and x.dim() >= 2 and x.shape[1] == bn.num_features and _layout(x) is not None)
+
+
+def batch_norm_relu(x, bn, relu=True):
+    """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch."""
+    if not applies(x, bn):
+        y = bn(x)
+        return torch.relu(y) if relu else y
+    layout, n, L = _layout(x)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L)
+
+
+_BN = (nn.BatchNorm1d, nn.BatchNorm2d)
+
+
+class TrainSequential(nn.Sequential):
+    """nn.Sequential whose (BatchNorm, ReLU) pairs run fused in training mode on the GPU (see the module docstring)."""
+
+    def forward(self, x):
+        if not (ENABLED and self.training and x.is_cuda):
+            return super().forward(x)
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, _BN) and applies(x, m):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = batch_norm_relu(x, m, relu)
+                i += 2 if relu else 1
+            else:
+                x = m(x)
+                i += 1
+        return x

@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import fused, pdm_ops
+from .fused_bn import TrainSequential
 
 
 def _get(cfg, key, default=None):
@@ -43,7 +44,7 @@ class PDMNeck(nn.Module):
         self.grid = pdm_ops.BevGrid(pcr, cell)
         assert self.grid.D == self.height_bins
         self.nsh = (self.degree + 1) ** 2
-        self.proj = nn.Sequential(nn.Conv1d(in_ch, self.feature_dim, 1, bias=False),
+        self.proj = TrainSequential(nn.Conv1d(in_ch, self.feature_dim, 1, bias=False),
                                   nn.BatchNorm1d(self.feature_dim), nn.ReLU())
         self.coef = nn.Conv1d(in_ch, self.nsh + 1, 1)   # SH coefficients + raw scale
         self.num_bev_features = self.feature_dim * self.height_bins

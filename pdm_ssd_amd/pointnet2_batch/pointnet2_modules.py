@@ -15,6 +15,7 @@ from . import pointnet2_utils
 from .. import fused
 
 import os
+from ..fused_bn import TrainSequential
 # The autograd path feeds the shared MLPs (Conv2d 1x1 + BatchNorm2d + ReLU, torch/MIOpen) a channels-last tensor:
 # MIOpen's NHWC batch-norm and implicit-GEMM kernels need no layout transposes (measured bs=32 train step 67.9 -> 49.7 ms).
 CHANNELS_LAST_TRAINING = os.environ.get("PDM_CHANNELS_LAST", "1") == "1"
@@ -26,7 +27,7 @@ def _shared_mlp(spec: List[int]) -> nn.Sequential:
     layers = []
     for cin, cout in zip(spec[:-1], spec[1:]):
         layers += [nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
-    return nn.Sequential(*layers)
+    return TrainSequential(*layers)
 
 
 class _PointnetSAModuleBase(nn.Module):

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import pointnet2_utils
 from .. import fused
 from ..pointnet2_batch.pointnet2_modules import PRE_MIN_CIN
+from ..fused_bn import TrainSequential
 
 
 def _cfg(config, key, default=None):
@@ -42,7 +43,7 @@ def _conv_bn_relu(spec):
     layers = []
     for cin, cout in zip(spec[:-1], spec[1:]):
         layers += [nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
-    return nn.Sequential(*layers)
+    return TrainSequential(*layers)
 
 
 def _row_starts(cnt_src, cnt_rows):
@@ -175,7 +176,7 @@ def _conv1d_bn_relu(widths, groups=1):
     layers = []
     for cin, cout in zip(widths[:-1], widths[1:]):
         layers += [nn.Conv1d(cin, cout, kernel_size=1, groups=groups, bias=False), nn.BatchNorm1d(cout), nn.ReLU()]
-    return nn.Sequential(*layers)
+    return TrainSequential(*layers)
 
 
 class VectorPoolLocalInterpolateModule(nn.Module):

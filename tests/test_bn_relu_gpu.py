@@ -1,0 +1,97 @@
+"""Fused training-mode BatchNorm + ReLU (csrc/bn_relu.hip, pdm_ssd_amd/fused_bn.py) against torch's own
+batch_norm + relu in fp32 on the CPU: outputs, running statistics, gradients of the input and of gamma / beta.
+fp32 activations 1e-5; bf16 activations within bf16 rounding of the fp32 result computed from the same bf16 inputs."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from pdm_ssd_amd import fused_bn
+
+
+def reference(x, bn_cpu, relu, gy):
+    x = x.detach().float().cpu().requires_grad_(True)
+    y = bn_cpu(x)
+    if relu:
+        y = torch.relu(y)
+    y.backward(gy.float().cpu())
+    return y.detach(), x.grad, bn_cpu.weight.grad, bn_cpu.bias.grad
+
+
+CASES = [
+    # shape, channels_last, dtype, relu
+    ((5000, 64), False, torch.float32, True),          # Linear output (rows, C)
+    ((5000, 64), False, torch.bfloat16, True),
+    ((2, 32, 50, 16), True, torch.float32, True),      # SA group tensor, channels-last
+    ((2, 96, 37, 8), True, torch.bfloat16, True),      # C / 8 = 12 threads per row: does not divide 256
+    ((3, 24, 1024), False, torch.float32, True),       # Conv1d output (B, C, L)
+    ((2, 16, 256, 1), False, torch.bfloat16, True),    # FP module: (B, C, n, 1), position fastest
+    ((4, 128, 512, 1), False, torch.float32, False),   # BatchNorm without ReLU
+    ((70000, 256), False, torch.bfloat16, True),       # more rows than one pass of the grid
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cl,dtype,relu", CASES)
+def test_fused_bn_relu_matches_torch(dev, shape, cl, dtype, relu):
+    torch.manual_seed(sum(shape))
+    C = shape[1]
+    bn = (nn.BatchNorm1d if len(shape) <= 3 else nn.BatchNorm2d)(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) + 0.5); bn.bias.copy_(torch.randn(C) * 0.2)
+        bn.running_mean.copy_(torch.randn(C) * 0.1); bn.running_var.copy_(torch.rand(C) + 0.5)
+    bn_g = copy.deepcopy(bn).to(dev).train()
+    x = (torch.randn(shape) * 1.5 + 0.3).to(dtype)
+    gy = torch.randn(shape).to(dtype)
+    xg = x.to(dev)
+    if cl:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg.requires_grad_(True)
+    assert fused_bn.applies(xg, bn_g)
+    y = fused_bn.batch_norm_relu(xg, bn_g, relu)
+    assert y.dtype == dtype and y.stride() == xg.stride()
+    y.backward(gy.to(dev))
+    ry, rdx, rdw, rdb = reference(x, bn.train(), relu, gy)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(y.detach().float().cpu(), ry, **tol)
+    torch.testing.assert_close(xg.grad.float().cpu(), rdx, **(tol if dtype == torch.float32 else dict(rtol=5e-2, atol=2e-2)))
+    scale = max(1.0, float(rdw.abs().max()))
+    torch.testing.assert_close(bn_g.weight.grad.cpu(), rdw, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=(1e-4 if dtype == torch.float32 else 2e-2) * scale)
+    torch.testing.assert_close(bn_g.bias.grad.cpu(), rdb, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=(1e-4 if dtype == torch.float32 else 2e-2) * scale)
+    torch.testing.assert_close(bn_g.running_mean.cpu(), bn.running_mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn_g.running_var.cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn_g.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+def test_train_sequential_fuses_and_falls_back(dev):
+    """Conv -> BN -> ReLU -> Conv -> BN -> ReLU through TrainSequential == through nn.Sequential (fp32); shapes the
+    kernels do not take (C = 6) and eval mode go through torch."""
+    torch.manual_seed(1)
+    layers = [nn.Conv2d(8, 6, 1, bias=False), nn.BatchNorm2d(6), nn.ReLU(), nn.Conv2d(6, 32, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU()]
+    plain = nn.Sequential(*copy.deepcopy(layers)).to(dev).train()
+    fused = fused_bn.TrainSequential(*copy.deepcopy(layers)).to(dev).train()
+    assert list(plain.state_dict()) == list(fused.state_dict())
+    x = torch.randn(4, 8, 64, 16, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = plain(xa), fused(xb)
+    torch.testing.assert_close(ya, yb, rtol=1e-4, atol=1e-5)
+    ya.square().sum().backward(); yb.square().sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-3, atol=1e-4)
+    for (k, pa), (_, pb) in zip(plain.named_parameters(), fused.named_parameters()):
+        torch.testing.assert_close(pa.grad, pb.grad, rtol=1e-3, atol=1e-3, msg=k)
+    for (k, ba), (_, bb) in zip(plain.named_buffers(), fused.named_buffers()):
+        torch.testing.assert_close(ba.float(), bb.float(), rtol=1e-4, atol=1e-5, msg=k)
+    plain.eval(); fused.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(plain(x), fused(x))
+
+
+def test_train_sequential_is_a_plain_sequential_on_cpu():
+    seq = fused_bn.TrainSequential(nn.Linear(4, 8, bias=False), nn.BatchNorm1d(8), nn.ReLU()).train()
+    ref = nn.Sequential(*copy.deepcopy(list(seq))).train()
+    x = torch.randn(16, 4)
+    torch.testing.assert_close(seq(x), ref(x))
+    assert isinstance(seq, nn.Sequential) and list(seq.state_dict()) == list(ref.state_dict())
