@@ -89,6 +89,40 @@ def batch_norm_relu(x, bn, relu=True):
     return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L)
 
 
+class _LinearSplitK(Function):
+    """y = x W^T (+ b) for VERY tall x (the point head: 524288 rows x 128-256 channels).  The weight gradient
+    dW = dy^T x contracts over the rows; the vendor GEMM gives that shape (256 x 256 outputs, K = 524288) a handful of
+    workgroups (measured 0.86-1.5 ms per layer).  Here the rows are cut into slabs, one batched GEMM forms a partial dW per
+    slab, and the partials are summed in fp32."""
+    SLAB = 8192
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        s = x.shape[0] // _LinearSplitK.SLAB
+        dw = torch.bmm(dy.view(s, _LinearSplitK.SLAB, -1).transpose(1, 2), x.view(s, _LinearSplitK.SLAB, -1)).float().sum(0).to(weight.dtype)
+        db = dy.float().sum(0).to(dy.dtype) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def tall_linear(x, lin):
+    """lin(x) with the split-K weight gradient when x is a tall bf16-autocast matrix on the GPU."""
+    if (ENABLED and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= 8 * _LinearSplitK.SLAB
+            and x.shape[0] % _LinearSplitK.SLAB == 0 and torch.is_autocast_enabled() and lin.weight.requires_grad):
+        return _LinearSplitK.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 _BN = (nn.BatchNorm1d, nn.BatchNorm2d)
 
 
@@ -106,6 +140,9 @@ class TrainSequential(nn.Sequential):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = batch_norm_relu(x, m, relu)
                 i += 2 if relu else 1
+            elif isinstance(m, nn.Linear):
+                x = tall_linear(x, m)
+                i += 1
             else:
                 x = m(x)
                 i += 1

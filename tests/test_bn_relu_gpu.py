@@ -95,3 +95,27 @@ def test_train_sequential_is_a_plain_sequential_on_cpu():
     x = torch.randn(16, 4)
     torch.testing.assert_close(seq(x), ref(x))
     assert isinstance(seq, nn.Sequential) and list(seq.state_dict()) == list(ref.state_dict())
+
+
+@pytest.mark.gpu
+def test_tall_linear_split_k_weight_gradient(dev):
+    """Linear over 65536+ rows under bf16 autocast: same output as nn.Linear, weight / bias / input gradients equal to
+    the fp32 result within bf16 rounding (the split-K sum is carried in fp32)."""
+    torch.manual_seed(3)
+    lin = nn.Linear(64, 48, bias=True).to(dev)
+    x = torch.randn(8 * 8192, 64, device=dev)
+    gy = torch.randn(8 * 8192, 48, device=dev)
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = fused_bn.tall_linear(xa, lin)
+        yb = lin(x)
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb)
+    ya.backward(gy.to(ya.dtype))
+    ref_w = (gy.bfloat16().float().t() @ x.bfloat16().float())
+    ref_b = gy.bfloat16().float().sum(0)
+    ref_x = gy.bfloat16().float() @ lin.weight.detach().bfloat16().float()
+    torch.testing.assert_close(lin.weight.grad, ref_w, rtol=1e-2, atol=1e-2 * float(ref_w.abs().max()))
+    torch.testing.assert_close(lin.bias.grad, ref_b, rtol=1e-2, atol=1e-2 * float(ref_b.abs().max()))
+    torch.testing.assert_close(xa.grad, ref_x, rtol=2e-2, atol=2e-2)
+    # short matrices and fp32 runs go through the module itself
+    assert fused_bn.tall_linear(x[:100], lin).dtype == torch.float32
