@@ -210,4 +210,4 @@ def test_build_local_aggregation_module_contract(dev):
     assert cout == 48 and cfg['MLPS'][0][0] == 11                    # input channels prepended, +3 for xyz, in place
     assert sorted(layer.state_dict())[0] == 'mlps.0.0.weight' and layer.mlps[0][0].weight.shape == (16, 11, 1, 1)
     with pytest.raises(NotImplementedError):
-        sm.build_local_aggregation_module(8, {'NAME': 'VectorPoolAggregationModuleMSG'})
+        sm.build_local_aggregation_module(8, {'NAME': 'SomethingElse'})                 # the reference's own fall-through (ref :26)
