@@ -607,7 +607,7 @@ def main():
     ap.add_argument("--train-profile", metavar="FILE", default=None,
                     help="with --train: after the warm-up, run 3 steps under torch.profiler and write the per-kernel table "
                          "(steady state: MIOpen's one-off solver search stays outside) to FILE instead of timing")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="clouds of the bounded CPU-baseline sample (about 10 s of CPU work per leg)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra measurements of the default line (lidar-like clouds, configs[4] stress shape, "
                          "single-thread CPU leg, median over 50 steps)")
@@ -741,7 +741,7 @@ def main():
                   "pdm_sa_mlp_fused_pre": ("pdm::sa_mlp_fused_kernel",),
                   "pdm_sa_mlp_packed": ("pdm::sa_packed_fused_kernel", "pdm::sa_reg_packed_kernel"),
                   "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
-                  "pdm_fp_mlp_fused_pre": ("pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<true>"),
+                  "pdm_fp_mlp_fused_pre": ("pdm::fp_chain_kernel", "pdm::fp_mlp_fused_kernel"),   # FP1-2 chain, FP3-4 tiled
                   "pdm_bev_head_fused": ("pdm::rows_chain_kernel<8, 4, 4, 1, true>",),
                   "pdm_rows_mlp_fused": ("pdm::rows_chain_kernel", "pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
 
@@ -850,7 +850,7 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(model, N, args.clouds, frames=args.cpu_frames)
         if not args.no_extras:
-            cpu1 = cpu_baseline(model, N, args.clouds, frames=1, threads=1)
+            cpu1 = cpu_baseline(model, N, args.clouds, frames=args.cpu_frames, threads=1)
 
     if not args.no_extras and not args.serial:
         del bench
