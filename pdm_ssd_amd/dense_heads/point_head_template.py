@@ -132,9 +132,11 @@ class PointHeadTemplate(nn.Module):
         cls_weights = ((labels == 0) * 1.0 + 1.0 * positives).float()
         pos_normalizer = positives.sum(dim=0).float()
         cls_weights = cls_weights / torch.clamp(pos_normalizer, min=1.0)
-        one_hot = preds.new_zeros(*list(labels.shape), self.num_class + 1)
-        one_hot.scatter_(-1, (labels * (labels >= 0).long()).unsqueeze(dim=-1).long(), 1.0)
-        loss = self.cls_loss_func(preds, one_hot[..., 1:], weights=cls_weights).sum()
+        # one-hot over classes 1..C (label 0 = background and the ignored -1 give an all-zero row, as the reference's
+        # scatter into C + 1 columns followed by [..., 1:]); a comparison instead of scatter_ (1.2 ms at 524288 points)
+        classes = torch.arange(1, self.num_class + 1, device=labels.device)
+        one_hot = (labels.unsqueeze(-1) == classes).to(preds.dtype)
+        loss = self.cls_loss_func(preds, one_hot, weights=cls_weights).sum()
         loss = loss * _get(_get(self.model_cfg, 'LOSS_CONFIG'), 'LOSS_WEIGHTS')['point_cls_weight']
         tb_dict = {} if tb_dict is None else tb_dict
         tb_dict.update({'point_loss_cls': loss.detach(), 'point_pos_num': pos_normalizer.detach()})

@@ -113,7 +113,7 @@ int main() {
         run<6>("s_barrier", threads, dout);
         run<7>("v_cmp + v_max + nop + v_cndmask (3 VALU)", threads, dout);
         run<8>("lds write + barrier + lds read", threads, dout);
-        run<9>("set_gpr_idx + v_mov + readlane", threads, dout);
+        // run<9> (s_set_gpr_idx + v_mov + readlane) hangs on gfx950 as written: left out of the run
     }
     return 0;
 }
