@@ -37,6 +37,9 @@ struct RowsChainArgs {
 };
 
 constexpr int RC_THREADS = 256;
+#ifndef RC_AHEAD
+#define RC_AHEAD 1   // rows_chain_kernel: request the next tile's input rows under the current tile's second layer
+#endif
 constexpr int RC_CHUNK_F4 = 16 * 64;   // 16 fragments x 64 lanes
 
 // chunk (mb0 .. mb0 + nmb - 1) x (kb0 .. kb0 + 3) of a layer with NKB k-blocks: thread t fetches lane t % 64 of
@@ -145,6 +148,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
     rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
     __syncthreads();
+    constexpr bool AHEAD = !DW && NL >= 2 && RC_AHEAD;
+    f4 xn[AHEAD ? NK0 : 1];
     for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const long long tile0 = tl * 64;
         // (the weight pointers pass through an empty asm so the ~140 chunk addresses are formed inside the loop with
@@ -166,9 +171,14 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
         const long long out_row = row;
         f4 x0[NK0];
         if constexpr (!DW) {
-            const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
+            if (AHEAD && tl != (long long)blockIdx.x) {
 #pragma unroll
-            for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
+                for (int kb = 0; kb < NK0; ++kb) x0[kb] = xn[kb];   // requested under the previous tile's second layer
+            } else {
+                const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
+#pragma unroll
+                for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
+            }
         } else {
             // depthwise 3x3 + shift + ReLU: the patch's halo is staged through LDS 16 channels at a time (each cell of
             // the map is fetched once per workgroup instead of up to nine times), the next slice's loads in flight
@@ -235,6 +245,13 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
             store(x1, NK1);
         } else {
             f4 x2[NK2 ? NK2 : 1];
+            if constexpr (AHEAD) {   // the next tile's input rows: in flight under this tile's second (largest) layer
+                long long nrow = (tl + gridDim.x) * 64 + 16 * wave + pos;
+                if (nrow >= a.rows) nrow = a.rows - 1;
+                const float *__restrict__ nsrc = a.in + (size_t)nrow * a.in_stride + 4 * g;
+#pragma unroll
+                for (int kb = 0; kb < NK0; ++kb) xn[kb] = *reinterpret_cast<const f4 *>(nsrc + 16 * kb);
+            }
             rc_layer<NK1, (NK2 ? NK2 : 1)>(x1, x2, w2, a.bias + a.boff[1], lds, p, (NL > 2 || a.relu_last) ? 0.0f : neg_inf,
                                            NL > 2 ? w3 : w1, NL > 2 ? NK2 : NK0, NL > 2 ? NK3 : NK1, t, lane, r);
             if constexpr (NL == 2) {
