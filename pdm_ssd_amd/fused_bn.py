@@ -54,7 +54,6 @@ class _BnRelu(Function):
                      coef.data_ptr(), partial.data_ptr(), int(relu))
         ctx.save_for_backward(x, coef)
         ctx.meta = (dtype, layout, n, C, L, int(relu), parts)
-        ctx.mark_non_differentiable()
         return y
 
     @staticmethod
@@ -123,6 +122,62 @@ def tall_linear(x, lin):
     return lin(x)
 
 
+def _slab(rows):
+    """largest power-of-two slab <= 16384 that divides `rows` into at least 8 slabs, else 0"""
+    s = 16384
+    while s >= 512:
+        if rows % s == 0 and rows // s >= 8:
+            return s
+        s //= 2
+    return 0
+
+
+class _Conv1x1SplitK(Function):
+    """1x1 convolution (the shared MLPs' layers) whose WEIGHT gradient is formed as a batched GEMM over slabs of
+    positions summed in fp32 (dW = sum over positions of dy x^T: MIOpen's weight-gradient kernels, their fp32 workspace
+    fills, casts and transposes took ~5 ms of the train step).  Forward and input gradient stay the vendor kernels."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight) if x.dim() == 4 else torch.nn.functional.conv1d(x, weight)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        nd = x.dim() - 2
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
+                                                     (True, False, False))[0]
+        cout, cin = weight.shape[0], weight.shape[1]
+        if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+            xv = x.permute(0, 2, 3, 1).reshape(-1, cin)                       # views: positions x channels
+            gv = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cout)
+            s = _slab(xv.shape[0])
+            if s:
+                dw = torch.bmm(gv.view(-1, s, cout).transpose(1, 2), xv.view(-1, s, cin)).float().sum(0)
+            else:
+                dw = (gv.t() @ xv).float()
+        else:                                                                   # (B, C, L...) position fastest: one GEMM per sample
+            xb = x.reshape(x.shape[0], cin, -1)
+            gb = dy.contiguous().reshape(x.shape[0], cout, -1)
+            dw = torch.bmm(gb, xb.transpose(1, 2)).float().sum(0)
+        return dx, dw.to(weight.dtype).view_as(weight)
+
+
+def conv1x1(x, conv):
+    """conv(x) for a plain 1x1 convolution, with the split-K weight gradient under bf16 autocast on the GPU."""
+    if (ENABLED and x.is_cuda and torch.is_autocast_enabled() and conv.bias is None and conv.weight.requires_grad
+            and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride) and all(v == 0 for v in conv.padding)
+            and all(v == 1 for v in conv.dilation) and conv.groups == 1 and isinstance(conv.padding, tuple)
+            and x.dim() == conv.weight.dim() and x.numel() >= (1 << 20)):
+        return _Conv1x1SplitK.apply(x, conv.weight)
+    return conv(x)
+
+
 _BN = (nn.BatchNorm1d, nn.BatchNorm2d)
 
 
@@ -142,6 +197,9 @@ class TrainSequential(nn.Sequential):
                 i += 2 if relu else 1
             elif isinstance(m, nn.Linear):
                 x = tall_linear(x, m)
+                i += 1
+            elif type(m) in (nn.Conv1d, nn.Conv2d):
+                x = conv1x1(x, m)
                 i += 1
             else:
                 x = m(x)

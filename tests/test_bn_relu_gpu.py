@@ -119,3 +119,27 @@ def test_tall_linear_split_k_weight_gradient(dev):
     torch.testing.assert_close(xa.grad, ref_x, rtol=2e-2, atol=2e-2)
     # short matrices and fp32 runs go through the module itself
     assert fused_bn.tall_linear(x[:100], lin).dtype == torch.float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cl", [((8, 32, 1024, 16), True), ((8, 64, 4096, 1), False), ((4, 24, 300, 7), True)])
+def test_conv1x1_split_k_weight_gradient(dev, shape, cl):
+    """1x1 convolution under bf16 autocast through fused_bn.conv1x1: output identical to the module, weight and input
+    gradients equal to the fp32 result of the bf16-rounded operands within bf16 rounding."""
+    torch.manual_seed(5)
+    conv = nn.Conv2d(shape[1], 48, 1, bias=False).to(dev)
+    x = torch.randn(shape, device=dev)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    gy = torch.randn(shape[0], 48, shape[2], shape[3], device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = fused_bn.conv1x1(xa, conv)
+        yb = conv(x)
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb)
+    ya.backward(gy.to(ya.dtype))
+    xr = x.bfloat16().float(); gr = gy.bfloat16().float(); wr = conv.weight.detach().bfloat16().float().view(48, -1)
+    ref_w = torch.einsum("bohw,bihw->oi", gr, xr)
+    ref_x = torch.einsum("bohw,oi->bihw", gr, wr)
+    torch.testing.assert_close(conv.weight.grad.view(48, -1), ref_w, rtol=1e-2, atol=1e-2 * float(ref_w.abs().max()))
+    torch.testing.assert_close(xa.grad, ref_x, rtol=2e-2, atol=2e-2)

@@ -1,0 +1,28 @@
+import sys, os, json
+sys.argv = ["bench.py", "--train", "--warmup", "4", "--no-cpu-baseline", "--train-profile", "/dev/null"]
+sys.path.insert(0, os.getcwd())
+import torch
+from torch.profiler import profile, ProfilerActivity
+import bench
+orig = profile
+def patched(*a, **k):
+    k["activities"] = [ProfilerActivity.CPU, ProfilerActivity.CUDA]
+    k["with_stack"] = True
+    p = orig(*a, **k)
+    bench._PROF = p
+    return p
+import torch.profiler as tp
+tp.profile = patched
+try:
+    bench.main()
+except SystemExit:
+    pass
+p = bench._PROF
+rows = []
+for e in p.events():
+    if "scatter_gather" in e.name or "SubTensorOpWithScalar" in e.name:
+        pass
+ka = p.key_averages(group_by_stack_n=6)
+for e in sorted(ka, key=lambda e: -e.device_time_total)[:400]:
+    if e.key.startswith("aten::gather") or e.key.startswith("aten::scatter") or "index" in e.key or e.key.startswith("aten::take"):
+        print(e.key, round(e.device_time_total / 3e3, 3), "ms/step", e.count, [s for s in e.stack[:6]])
