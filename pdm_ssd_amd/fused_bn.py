@@ -133,37 +133,48 @@ def _slab(rows):
 
 
 class _Conv1x1SplitK(Function):
-    """1x1 convolution (the shared MLPs' layers) whose WEIGHT gradient is formed as a batched GEMM over slabs of
-    positions summed in fp32 (dW = sum over positions of dy x^T: MIOpen's weight-gradient kernels, their fp32 workspace
-    fills, casts and transposes took ~5 ms of the train step).  Forward and input gradient stay the vendor kernels."""
+    """1x1 convolution (the shared MLPs' layers) as three GEMMs over the tensor's own storage: a channels-last (B, C, H, W)
+    tensor IS a (positions, C) matrix and a position-fastest (B, C, L) tensor is B (C, L) matrices, so the forward and
+    the input gradient are plain (batched) GEMMs and the WEIGHT gradient (dW = sum over positions of dy x^T) is a batched
+    GEMM over slabs of positions summed in fp32.  MIOpen's weight-gradient kernels with their fp32 workspace fills, casts
+    and transposes, and the zero-fills in front of its data-gradient kernels, took ~6 ms of the train step."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
-        return torch.nn.functional.conv2d(x, weight) if x.dim() == 4 else torch.nn.functional.conv1d(x, weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        w2 = weight.view(cout, cin)
+        ctx.cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        if ctx.cl:
+            B, _, H, W = x.shape
+            return (x.permute(0, 2, 3, 1).reshape(-1, cin) @ w2.t()).view(B, H, W, cout).permute(0, 3, 1, 2)
+        xb = x.contiguous().reshape(x.shape[0], cin, -1)
+        return torch.matmul(w2, xb).view(x.shape[0], cout, *x.shape[2:])
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        nd = x.dim() - 2
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
-                                                     (True, False, False))[0]
         cout, cin = weight.shape[0], weight.shape[1]
-        if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        w2 = weight.view(cout, cin)
+        dx = None
+        if ctx.cl:
+            B, _, H, W = x.shape
             xv = x.permute(0, 2, 3, 1).reshape(-1, cin)                       # views: positions x channels
             gv = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cout)
+            if ctx.needs_input_grad[0]:
+                dx = (gv @ w2).view(B, H, W, cin).permute(0, 3, 1, 2)
             s = _slab(xv.shape[0])
             if s:
                 dw = torch.bmm(gv.view(-1, s, cout).transpose(1, 2), xv.view(-1, s, cin)).float().sum(0)
             else:
                 dw = (gv.t() @ xv).float()
         else:                                                                   # (B, C, L...) position fastest: one GEMM per sample
-            xb = x.reshape(x.shape[0], cin, -1)
+            xb = x.contiguous().reshape(x.shape[0], cin, -1)
             gb = dy.contiguous().reshape(x.shape[0], cout, -1)
+            if ctx.needs_input_grad[0]:
+                dx = torch.matmul(w2.t(), gb).view(x.shape)
             dw = torch.bmm(gb, xb.transpose(1, 2)).float().sum(0)
         return dx, dw.to(weight.dtype).view_as(weight)
 

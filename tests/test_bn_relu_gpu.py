@@ -124,7 +124,7 @@ def test_tall_linear_split_k_weight_gradient(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,cl", [((8, 32, 1024, 16), True), ((8, 64, 4096, 1), False), ((4, 24, 300, 7), True)])
 def test_conv1x1_split_k_weight_gradient(dev, shape, cl):
-    """1x1 convolution under bf16 autocast through fused_bn.conv1x1: output identical to the module, weight and input
+    """1x1 convolution under bf16 autocast through fused_bn.conv1x1: output equal to the module's within bf16 rounding (and in the same memory format), weight and input
     gradients equal to the fp32 result of the bf16-rounded operands within bf16 rounding."""
     torch.manual_seed(5)
     conv = nn.Conv2d(shape[1], 48, 1, bias=False).to(dev)
@@ -136,7 +136,8 @@ def test_conv1x1_split_k_weight_gradient(dev, shape, cl):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ya = fused_bn.conv1x1(xa, conv)
         yb = conv(x)
-    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb)
+    assert ya.dtype == torch.bfloat16 and ya.stride() == yb.stride()
+    torch.testing.assert_close(ya.float(), yb.float(), rtol=1e-2, atol=1e-2)     # same bf16 GEMM, another kernel's summation order
     ya.backward(gy.to(ya.dtype))
     xr = x.bfloat16().float(); gr = gy.bfloat16().float(); wr = conv.weight.detach().bfloat16().float().view(48, -1)
     ref_w = torch.einsum("bohw,bihw->oi", gr, xr)
