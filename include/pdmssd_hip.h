@@ -345,6 +345,21 @@ int pdm_bn_relu_forward(void *stream, int dtype, int layout, long long n, int C,
 int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                          void *dx, const float *coef, float *grads, float *partial, int relu);
 
+/* The tail of an SA scale in training — BatchNorm + ReLU + max over the ns neighbours of each group
+ * (pointnet2_modules.py:46-52: the last (BatchNorm2d, ReLU) of the shared MLP, then F.max_pool2d over nsample) — as ONE
+ * operator.  x is (G groups, ns <= 255, C) with the channel fastest; y (G, C).  relu(bn(.)) is monotone in x, so one pass
+ * over x gives the statistics and each group's max / min (+ first index), the pooled output is the function of that
+ * extreme, and the normalised tensor is never written; backward = sums over the pooled tensors + one pass for dx.
+ * xmax / xmin (G, C, x's type) and imax / imin (G, C, bytes) are the forward's record for the backward.
+ * pdm_bn_pool_parts: slices of `partial` ((parts, C, 2) floats). */
+int pdm_bn_pool_parts(int dtype, long long G, int C);
+int pdm_bn_relu_pool_forward(void *stream, int dtype, long long G, int ns, int C, const void *x, void *y, void *xmax, void *xmin,
+                             unsigned char *imax, unsigned char *imin, const float *gamma, const float *beta, float eps,
+                             float momentum, float *running_mean, float *running_var, float *coef, float *partial, int relu);
+int pdm_bn_relu_pool_backward(void *stream, int dtype, long long G, int ns, int C, const void *x, const void *dy, void *dx,
+                              const void *xmax, const void *xmin, const unsigned char *imax, const unsigned char *imin,
+                              const float *coef, float *grads, float *partial, int relu);
+
 /* ---- hybrid head (north_star configs[2]: "backbone + PDM neck + hybrid head"; no reference source: SURVEY.md F1) ----
  * Depthwise 3x3 convolution + folded BatchNorm + ReLU over the neck's channels-last BEV grid, the context stage of
  * the heat-map head (pdm_ssd_amd/dense_heads/pdm_heatmap_head.py); the point head's MLPs and the heat-map head's 1x1

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "pdm_stack_three_interpolate": [_i, _i, _vp, _vp, _vp, _vp],
     "pdm_stack_three_interpolate_grad": [_i, _i, _vp, _vp, _vp, _vp],
     "pdm_stack_furthest_point_sampling": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdm_bn_relu_pool_forward": [_i, ctypes.c_longlong, _i, _i] + [_vp] * 8 + [_f, _f, _vp, _vp, _vp, _vp, _i],
+    "pdm_bn_relu_pool_backward": [_i, ctypes.c_longlong, _i, _i] + [_vp] * 10 + [_i],
     "pdm_bn_relu_forward": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_bn_relu_backward": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "pdm_stack_voxel_query": [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -105,7 +107,7 @@ EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_b
            "pdm_fps_max_coresident_workgroups",
            "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
            "pdm_sa_pack_rows", "pdm_three_interpolate_grad_ws_bytes",
-           "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes", "pdm_bn_parts"] + list(_SIGNATURES)
+           "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes", "pdm_bn_parts", "pdm_bn_pool_parts"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -146,6 +148,8 @@ def lib():
         l.pdm_sa_pack_rows.restype = ctypes.c_size_t
         l.pdm_sa_pack_rows.argtypes = [_i, _i, _i]
         l.pdm_nms_workspace_bytes.argtypes = [_i]
+        l.pdm_bn_pool_parts.restype = _i
+        l.pdm_bn_pool_parts.argtypes = [_i, ctypes.c_longlong, _i]
         l.pdm_bn_parts.restype = _i
         l.pdm_bn_parts.argtypes = [_i, ctypes.c_longlong, _i, ctypes.c_longlong]
         if l.pdm_abi_version() != ABI_VERSION:

@@ -229,6 +229,156 @@ __global__ __launch_bounds__(256) void bn_cf_apply_kernel(const T *__restrict__ 
     }
 }
 
+// ---- BatchNorm + ReLU + max over the `ns` neighbours of a group (the tail of an SA scale: pointnet2_modules.py:46-52) ----
+// x is (G groups, ns, C) with the channel fastest.  relu((x - mean) scale + beta) is monotone in x (rising for scale >= 0,
+// falling otherwise), so the pooled output is that function of the group's max (or min) of x: ONE pass over x yields
+// the batch statistics AND every group's max / min with the first index attaining them; the normalised tensor is never
+// written.  Backward: the pooled gradient belongs to that one element, so the two sums run over the pooled tensors
+// only, and the input gradient is one pass (read x, write dx).  Thread = (group, V channels), looping over s.
+template <class T>
+__global__ __launch_bounds__(256) void bn_pool_stats_kernel(const T *__restrict__ x, long long G, int ns, int C, float *pivot,
+                                                            T *__restrict__ xmax, T *__restrict__ xmin,
+                                                            unsigned char *__restrict__ imax, unsigned char *__restrict__ imin,
+                                                            float *__restrict__ partial) {
+    constexpr int V = BnVec<T>::V;
+    __shared__ float s_a[256 * V], s_b[256 * V];
+    const int tpr = C / V, gpp = 256 / tpr;
+    const int gin = threadIdx.x / tpr, col = (threadIdx.x % tpr) * V;
+    float a[V], b[V], pv[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a[i] = b[i] = 0.f; pv[i] = 0.f; }
+    if (gin < gpp) {
+        BnVec<T>::load(x + col, pv);
+        if (blockIdx.x == 0 && gin == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) pivot[col + i] = pv[i];
+        }
+        for (long long g = (long long)blockIdx.x * gpp + gin; g < G; g += (long long)gridDim.x * gpp) {
+            float mx[V], mn[V];
+            int ix[V], in_[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) { mx[i] = -INFINITY; mn[i] = INFINITY; ix[i] = in_[i] = 0; }
+            const T *__restrict__ row = x + (size_t)g * ns * C + col;
+            for (int s_ = 0; s_ < ns; ++s_) {
+                float xv[V];
+                BnVec<T>::load(row + (size_t)s_ * C, xv);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float d = xv[i] - pv[i];
+                    a[i] += d; b[i] = fmaf(d, d, b[i]);
+                    if (xv[i] > mx[i]) { mx[i] = xv[i]; ix[i] = s_; }   // strict: the FIRST index attaining the extreme
+                    if (xv[i] < mn[i]) { mn[i] = xv[i]; in_[i] = s_; }
+                }
+            }
+            BnVec<T>::store(xmax + (size_t)g * C + col, mx);
+            BnVec<T>::store(xmin + (size_t)g * C + col, mn);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { imax[(size_t)g * C + col + i] = (unsigned char)ix[i]; imin[(size_t)g * C + col + i] = (unsigned char)in_[i]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s_a[threadIdx.x * V + i] = a[i]; s_b[threadIdx.x * V + i] = b[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float ta = 0.f, tb = 0.f;
+        const int t0 = c / V, i = c % V;
+        for (int q = 0; q < gpp; ++q) { ta += s_a[(q * tpr + t0) * V + i]; tb += s_b[(q * tpr + t0) * V + i]; }
+        partial[((size_t)blockIdx.x * C + c) * 2] = ta;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = tb;
+    }
+}
+
+// MODE 0: y[g][c] = [relu]((sel - mean) scale + beta), sel = scale >= 0 ? xmax : xmin.
+// MODE 1: the backward's two sums over the pooled tensors (g = dy where the pooled value passed the ReLU).
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void bn_pool_small_kernel(const T *__restrict__ xmax, const T *__restrict__ xmin, const T *__restrict__ dy,
+                                                            T *__restrict__ y, long long G, int C, BnCoef k, int relu,
+                                                            float *__restrict__ partial) {
+    constexpr int V = BnVec<T>::V;
+    __shared__ float s_a[MODE ? 256 * V : 1], s_b[MODE ? 256 * V : 1];
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int rin = threadIdx.x / tpr, col = (threadIdx.x % tpr) * V;
+    float a[V], b[V], mean[V], istd[V], sc[V], sh[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a[i] = b[i] = 0.f; mean[i] = istd[i] = sc[i] = sh[i] = 0.f; }
+    if (rin < rpp) {
+        ldv<V>(k.mean + col, mean); ldv<V>(k.invstd + col, istd); ldv<V>(k.scale + col, sc); ldv<V>(k.shift + col, sh);
+        for (long long g = (long long)blockIdx.x * rpp + rin; g < G; g += (long long)gridDim.x * rpp) {
+            float hi[V], lo[V];
+            BnVec<T>::load(xmax + (size_t)g * C + col, hi);
+            BnVec<T>::load(xmin + (size_t)g * C + col, lo);
+            if (MODE == 0) {
+                float ov[V];
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float v = fmaf((sc[i] >= 0.f ? hi[i] : lo[i]) - mean[i], sc[i], sh[i]);
+                    ov[i] = relu ? fmaxf(v, 0.f) : v;
+                }
+                BnVec<T>::store(y + (size_t)g * C + col, ov);
+            } else {
+                float gv[V];
+                BnVec<T>::load(dy + (size_t)g * C + col, gv);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float d = (sc[i] >= 0.f ? hi[i] : lo[i]) - mean[i];
+                    const float gg = (!relu || fmaf(d, sc[i], sh[i]) > 0.f) ? gv[i] : 0.f;
+                    a[i] += gg;
+                    b[i] = fmaf(gg, d * istd[i], b[i]);
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s_a[threadIdx.x * V + i] = a[i]; s_b[threadIdx.x * V + i] = b[i]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float ta = 0.f, tb = 0.f;
+            const int t0 = c / V, i = c % V;
+            for (int q = 0; q < rpp; ++q) { ta += s_a[(q * tpr + t0) * V + i]; tb += s_b[(q * tpr + t0) * V + i]; }
+            partial[((size_t)blockIdx.x * C + c) * 2] = ta;
+            partial[((size_t)blockIdx.x * C + c) * 2 + 1] = tb;
+        }
+    }
+}
+
+// dx[g][s][c] = scale * (g_sel - p - (x - mean) q), g_sel = dy[g][c] at the selected s (if it passed the ReLU), else 0
+template <class T>
+__global__ __launch_bounds__(256) void bn_pool_dx_kernel(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict__ xmax,
+                                                         const T *__restrict__ xmin, const unsigned char *__restrict__ imax,
+                                                         const unsigned char *__restrict__ imin, T *__restrict__ dx, long long G, int ns,
+                                                         int C, BnCoef k, int relu) {
+    constexpr int V = BnVec<T>::V;
+    const int tpr = C / V, gpp = 256 / tpr;
+    const int gin = threadIdx.x / tpr, col = (threadIdx.x % tpr) * V;
+    if (gin >= gpp) return;
+    float mean[V], sc[V], sh[V], pp[V], qq[V];
+    ldv<V>(k.mean + col, mean); ldv<V>(k.scale + col, sc); ldv<V>(k.shift + col, sh); ldv<V>(k.p + col, pp); ldv<V>(k.q + col, qq);
+    for (long long g = (long long)blockIdx.x * gpp + gin; g < G; g += (long long)gridDim.x * gpp) {
+        float hi[V], lo[V], gv[V];
+        int sel[V];
+        BnVec<T>::load(xmax + (size_t)g * C + col, hi);
+        BnVec<T>::load(xmin + (size_t)g * C + col, lo);
+        BnVec<T>::load(dy + (size_t)g * C + col, gv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const bool up = sc[i] >= 0.f;
+            const float d = (up ? hi[i] : lo[i]) - mean[i];
+            if (relu && !(fmaf(d, sc[i], sh[i]) > 0.f)) gv[i] = 0.f;
+            sel[i] = up ? imax[(size_t)g * C + col + i] : imin[(size_t)g * C + col + i];
+        }
+        const T *__restrict__ row = x + (size_t)g * ns * C + col;
+        T *__restrict__ orow = dx + (size_t)g * ns * C + col;
+        for (int s_ = 0; s_ < ns; ++s_) {
+            float xv[V], ov[V];
+            BnVec<T>::load(row + (size_t)s_ * C, xv);
+#pragma unroll
+            for (int i = 0; i < V; ++i) ov[i] = sc[i] * ((s_ == sel[i] ? gv[i] : 0.f) - pp[i] - (xv[i] - mean[i]) * qq[i]);
+            BnVec<T>::store(orow + (size_t)s_ * C, ov);
+        }
+    }
+}
+
 // ---- per-channel finalize: one wave per channel folds the parts in double -------------------------------------------
 __device__ __forceinline__ void bn_fold(const float *__restrict__ partial, int parts, int C, int c, double &s, double &q) {
     __shared__ double sh_s[64], sh_q[64];
@@ -373,4 +523,71 @@ extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long lo
         else hipLaunchKernelGGL((bn_cf_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, L, k, relu);
     }
     return check_launch("bn_relu_backward");
+}
+
+static int bn_pool_check(const char *who, int dtype, long long G, int ns, int C, const void *a, const void *b, const void *c,
+                         const void *d, const void *e, const void *f) {
+    PDM_REQUIRE(dtype == 0 || dtype == 1, PDM_E_BADARG, "%s: dtype %d (0 = fp32, 1 = bf16)", who, dtype);
+    const int V = dtype ? 8 : 4;
+    PDM_REQUIRE(G >= 0 && ns >= 1 && ns <= 255 && C >= 1 && C % V == 0 && C / V <= 256, PDM_E_BADARG,
+                "%s: G=%lld ns=%d (1..255) C=%d (a multiple of %d, at most %d)", who, G, ns, C, V, 256 * V);
+    PDM_REQUIRE(G == 0 || (a && b && c && d && e && f), PDM_E_BADARG, "%s: null pointer", who);
+    PDM_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                  reinterpret_cast<uintptr_t>(d)) & 15) == 0, PDM_E_BADARG, "%s: buffers must be 16-byte aligned", who);
+    return 0;
+}
+
+static unsigned bn_pool_grid(long long units, int per_block) {
+    const long long want = (units + per_block - 1) / per_block;
+    return (unsigned)(want < 1 ? 1 : want > 1024 ? 1024 : want);
+}
+
+// Number of partial-sum slices of the pooled operator's passes ((parts, C, 2) floats of workspace).
+extern "C" int pdm_bn_pool_parts(int dtype, long long G, int C) {
+    const int V = dtype ? 8 : 4;
+    if (C < V || C / V > 256) return 1;
+    return (int)bn_pool_grid(G, 256 / (C / V));
+}
+
+// BatchNorm(train) + ReLU + max over the ns rows of each group, x (G, ns, C) channel fastest -> y (G, C).
+// xmax / xmin (G, C) of x's type and imax / imin (G, C) bytes are kept for the backward, with coef (4, C).
+extern "C" int pdm_bn_relu_pool_forward(void *stream, int dtype, long long G, int ns, int C, const void *x, void *y, void *xmax,
+                                        void *xmin, unsigned char *imax, unsigned char *imin, const float *gamma,
+                                        const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                        float *coef, float *partial, int relu) {
+    if (int rc = bn_pool_check("bn_relu_pool_forward", dtype, G, ns, C, x, y, xmax, xmin, imax, imin)) return rc;
+    PDM_REQUIRE(coef && partial, PDM_E_BADARG, "bn_relu_pool_forward: null workspace");
+    if (G == 0) return 0;
+    const int V = dtype ? 8 : 4, per = 256 / (C / V);
+    const unsigned parts = bn_pool_grid(G, per);
+    float *pivot = coef + 3 * (size_t)C;
+    if (dtype) hipLaunchKernelGGL((bn_pool_stats_kernel<bf16_t>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, G, ns, C, pivot, (bf16_t *)xmax, (bf16_t *)xmin, imax, imin, partial);
+    else hipLaunchKernelGGL((bn_pool_stats_kernel<float>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, G, ns, C, pivot, (float *)xmax, (float *)xmin, imax, imin, partial);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, (int)parts, C, (double)G * (double)ns, gamma, beta,
+                       eps, momentum, running_mean, running_var, coef);
+    const BnCoef k = coef_of(coef, nullptr, C);
+    if (dtype) hipLaunchKernelGGL((bn_pool_small_kernel<bf16_t, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)xmax, (const bf16_t *)xmin, (const bf16_t *)nullptr, (bf16_t *)y, G, C, k, relu, (float *)nullptr);
+    else hipLaunchKernelGGL((bn_pool_small_kernel<float, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)xmax, (const float *)xmin, (const float *)nullptr, (float *)y, G, C, k, relu, (float *)nullptr);
+    return check_launch("bn_relu_pool_forward");
+}
+
+// Backward of the above: dx (G, ns, C) from dy (G, C); grads (4, C) = [dgamma | dbeta | p | q].
+extern "C" int pdm_bn_relu_pool_backward(void *stream, int dtype, long long G, int ns, int C, const void *x, const void *dy, void *dx,
+                                         const void *xmax, const void *xmin, const unsigned char *imax, const unsigned char *imin,
+                                         const float *coef, float *grads, float *partial, int relu) {
+    if (int rc = bn_pool_check("bn_relu_pool_backward", dtype, G, ns, C, x, dy, xmax, xmin, imax, imin)) return rc;
+    PDM_REQUIRE(coef && grads && partial && (G == 0 || dx) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0, PDM_E_BADARG,
+                "bn_relu_pool_backward: null or unaligned pointer");
+    if (G == 0) return 0;
+    const int V = dtype ? 8 : 4, per = 256 / (C / V);
+    const unsigned parts = bn_pool_grid(G, per);
+    BnCoef k = coef_of(coef, nullptr, C);
+    if (dtype) hipLaunchKernelGGL((bn_pool_small_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)xmax, (const bf16_t *)xmin, (const bf16_t *)dy, (bf16_t *)nullptr, G, C, k, relu, partial);
+    else hipLaunchKernelGGL((bn_pool_small_kernel<float, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)xmax, (const float *)xmin, (const float *)dy, (float *)nullptr, G, C, k, relu, partial);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, (int)parts, C, (double)G * (double)ns, coef, grads);
+    k = coef_of(coef, grads, C);
+    const unsigned dgrid = (unsigned)((G + per - 1) / per > 16384 ? 16384 : (G + per - 1) / per);
+    if (dtype) hipLaunchKernelGGL((bn_pool_dx_kernel<bf16_t>), dim3(dgrid), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (const bf16_t *)xmax, (const bf16_t *)xmin, imax, imin, (bf16_t *)dx, G, ns, C, k, relu);
+    else hipLaunchKernelGGL((bn_pool_dx_kernel<float>), dim3(dgrid), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (const float *)xmax, (const float *)xmin, imax, imin, (float *)dx, G, ns, C, k, relu);
+    return check_launch("bn_relu_pool_backward");
 }

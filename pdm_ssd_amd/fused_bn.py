@@ -71,6 +71,55 @@ class _BnRelu(Function):
         return dx, grads[0], grads[1], None, None, None, None, None, None, None, None
 
 
+class _BnReluPool(Function):
+    """relu(bn(x)) max-pooled over the last axis of a channels-last (B, C, M, ns) tensor -> (B, C, M, 1), as one operator
+    (csrc/bn_relu.hip, "BatchNorm + ReLU + max over the ns neighbours").  Ties go to the first neighbour attaining the
+    extreme of x (torch's max_pool2d picks the first maximum of the ROUNDED output: the same element unless two
+    different inputs round to one bf16 output)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        B, C, M, ns = x.shape
+        G = B * M
+        dtype = 1 if x.dtype == torch.bfloat16 else 0
+        dev = x.device
+        y = torch.empty((B, M, 1, C), dtype=x.dtype, device=dev)
+        keep = torch.empty((2, G, C), dtype=x.dtype, device=dev)
+        idx = torch.empty((2, G, C), dtype=torch.uint8, device=dev)
+        coef = torch.empty((4, C), dtype=torch.float32, device=dev)
+        parts = _native.lib().pdm_bn_pool_parts(dtype, G, C)
+        partial = torch.empty((parts, C, 2), dtype=torch.float32, device=dev)
+        _native.call("pdm_bn_relu_pool_forward", torch.cuda.current_stream(dev).cuda_stream, dtype, G, ns, C, x.data_ptr(), y.data_ptr(),
+                     keep[0].data_ptr(), keep[1].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                     float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(),
+                     partial.data_ptr(), 1)
+        ctx.save_for_backward(x, keep, idx, coef)
+        ctx.meta = (dtype, G, ns, C, parts)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, keep, idx, coef = ctx.saved_tensors
+        dtype, G, ns, C, parts = ctx.meta
+        dyp = dy.permute(0, 2, 3, 1).to(x.dtype).contiguous()       # (B, M, 1, C): rows x channels
+        dx = torch.empty_like(x)
+        grads = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
+        _native.call("pdm_bn_relu_pool_backward", torch.cuda.current_stream(x.device).cuda_stream, dtype, G, ns, C, x.data_ptr(),
+                     dyp.data_ptr(), dx.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(),
+                     coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), 1)
+        return dx, grads[0], grads[1], None, None, None, None
+
+
+def pool_applies(x, bn):
+    """the pooled operator takes channels-last (B, C, M, ns) tensors, ns <= 255"""
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    return (applies(x, bn) and x.dim() == 4 and x.shape[3] <= 255 and x.is_contiguous(memory_format=torch.channels_last)
+            and not x.is_contiguous() and x.shape[1] % v == 0 and x.shape[1] // v <= 256)
+
+
 def applies(x, bn):
     return (ENABLED and bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and bn.affine
             and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32
@@ -195,10 +244,30 @@ _BN = (nn.BatchNorm1d, nn.BatchNorm2d)
 class TrainSequential(nn.Sequential):
     """nn.Sequential whose (BatchNorm, ReLU) pairs run fused in training mode on the GPU (see the module docstring)."""
 
+    def forward_max_pooled(self, x):
+        """F.max_pool2d(self(x), kernel_size=[1, x.size(3)]) for a stack that ends in (BatchNorm2d, ReLU): in training
+        mode on the GPU the last pair and the pooling run as one operator (the normalised tensor is never written)."""
+        mods = list(self)
+        if (ENABLED and self.training and x.is_cuda and len(mods) >= 3 and isinstance(mods[-1], nn.ReLU)
+                and isinstance(mods[-2], nn.BatchNorm2d)):
+            h = self._run(x, mods[:-2])
+            bn = mods[-2]
+            if pool_applies(h, bn):
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+                return _BnReluPool.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+            h = self._run(h, mods[-2:])
+        else:
+            h = self(x)
+        return torch.nn.functional.max_pool2d(h, kernel_size=[1, h.size(3)])
+
     def forward(self, x):
         if not (ENABLED and self.training and x.is_cuda):
             return super().forward(x)
-        mods = list(self)
+        return self._run(x, list(self))
+
+    @staticmethod
+    def _run(x, mods):
         i = 0
         while i < len(mods):
             m = mods[i]

@@ -142,10 +142,12 @@ class _PointnetSAModuleBase(nn.Module):
             x = grouper(xyz, new_xyz, features)
             if CHANNELS_LAST_TRAINING:
                 x = x.contiguous(memory_format=torch.channels_last)
-            x = mlp(x)  # (B, mlp[-1], npoint, nsample)
-            if self.pool_method == 'max_pool':
-                x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
+            if self.pool_method == 'max_pool' and isinstance(mlp, TrainSequential):
+                x = mlp.forward_max_pooled(x)   # last BatchNorm + ReLU and the max over nsample as one operator when training
+            elif self.pool_method == 'max_pool':
+                x = F.max_pool2d(mlp(x), kernel_size=[1, x.size(3)])
             elif self.pool_method == 'avg_pool':
+                x = mlp(x)  # (B, mlp[-1], npoint, nsample)
                 x = F.avg_pool2d(x, kernel_size=[1, x.size(3)])
             else:
                 raise NotImplementedError

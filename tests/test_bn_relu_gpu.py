@@ -144,3 +144,39 @@ def test_conv1x1_split_k_weight_gradient(dev, shape, cl):
     ref_x = torch.einsum("bohw,oi->bihw", gr, wr)
     torch.testing.assert_close(conv.weight.grad.view(48, -1), ref_w, rtol=1e-2, atol=1e-2 * float(ref_w.abs().max()))
     torch.testing.assert_close(xa.grad, ref_x, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((2, 32, 200, 16), torch.float32), ((3, 64, 500, 32), torch.bfloat16), ((2, 96, 64, 7), torch.bfloat16)])
+def test_bn_relu_max_pool_as_one_operator(dev, shape, dtype):
+    """The tail of an SA scale in training: relu(bn(x)) max-pooled over nsample, one operator against torch's three on
+    the CPU in fp32 — with duplicated neighbours (exact ties, as ball-query padding makes them), negative gammas (the
+    pooled value then comes from the group's MINIMUM), groups that never pass the ReLU."""
+    torch.manual_seed(shape[2])
+    B, C, M, ns = shape
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C)); bn.bias.copy_(torch.randn(C) * 0.5)
+        bn.weight[1] = 0.7; bn.bias[1] = -50.0                                       # a channel that is never positive
+    x = (torch.randn(B, C, M, ns) * 1.3 + 0.2).to(dtype)
+    x[..., ns // 2:] = x[..., :1]                                                     # padding copies of the first neighbour
+    gy = torch.randn(B, C, M, 1).to(dtype)
+    seq = fused_bn.TrainSequential(nn.Identity(), copy.deepcopy(bn), nn.ReLU()).to(dev).train()
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert fused_bn.pool_applies(xg, seq[1])
+    y = seq.forward_max_pooled(xg)
+    assert y.shape == (B, C, M, 1) and y.dtype == dtype
+    y.backward(gy.to(dev))
+    xc = x.float().requires_grad_(True)
+    bn.train()
+    yc = torch.nn.functional.max_pool2d(torch.relu(bn(xc)), kernel_size=[1, ns])
+    yc.backward(gy.float())
+    f32 = dtype == torch.float32
+    torch.testing.assert_close(y.detach().float().cpu(), yc.detach(), rtol=1e-5 if f32 else 2e-2, atol=1e-5 if f32 else 2e-2)
+    torch.testing.assert_close(xg.grad.float().cpu(), xc.grad, rtol=1e-4 if f32 else 5e-2, atol=1e-5 if f32 else 2e-2)
+    sw, sb = max(1.0, float(bn.weight.grad.abs().max())), max(1.0, float(bn.bias.grad.abs().max()))
+    torch.testing.assert_close(seq[1].weight.grad.cpu(), bn.weight.grad, rtol=1e-4 if f32 else 2e-2, atol=(1e-4 if f32 else 2e-2) * sw)
+    torch.testing.assert_close(seq[1].bias.grad.cpu(), bn.bias.grad, rtol=1e-4 if f32 else 2e-2, atol=(1e-4 if f32 else 2e-2) * sb)
+    torch.testing.assert_close(seq[1].running_mean.cpu(), bn.running_mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(seq[1].running_var.cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
+    assert float(y[:, 1].abs().max()) == 0.0 and float(xg.grad[:, 1].abs().max()) < 1e-3
