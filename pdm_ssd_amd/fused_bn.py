@@ -145,30 +145,38 @@ class _LinearSplitK(Function):
     SLAB = 8192
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        # operands rounded to bf16 here (what autocast would do), so the fp32 parameters get fp32 gradients straight
+        # from the fp32 slab sum: no bf16 round trip of the gradient, three small cast kernels fewer per layer
+        xb, wb = x.to(torch.bfloat16), weight.to(torch.bfloat16)
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias, ctx.xdtype = bias is not None, x.dtype
+        return torch.nn.functional.linear(xb, wb, None if bias is None else bias.to(torch.bfloat16))
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dx = (dy @ weight).to(ctx.xdtype) if ctx.needs_input_grad[0] else None
         s = x.shape[0] // _LinearSplitK.SLAB
-        dw = torch.bmm(dy.view(s, _LinearSplitK.SLAB, -1).transpose(1, 2), x.view(s, _LinearSplitK.SLAB, -1)).float().sum(0).to(weight.dtype)
-        db = dy.float().sum(0).to(dy.dtype) if ctx.has_bias else None
+        dw = torch.bmm(dy.view(s, _LinearSplitK.SLAB, -1).transpose(1, 2), x.view(s, _LinearSplitK.SLAB, -1)).sum(0, dtype=torch.float32)
+        db = dy.sum(0, dtype=torch.float32) if ctx.has_bias else None
         return dx, dw, db
 
 
 def tall_linear(x, lin):
     """lin(x) with the split-K weight gradient when x is a tall bf16-autocast matrix on the GPU."""
     if (ENABLED and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= 8 * _LinearSplitK.SLAB
-            and x.shape[0] % _LinearSplitK.SLAB == 0 and torch.is_autocast_enabled() and lin.weight.requires_grad):
+            and x.shape[0] % _LinearSplitK.SLAB == 0 and _bf16_autocast() and lin.weight.requires_grad
+            and lin.weight.dtype == torch.float32):
         return _LinearSplitK.apply(x, lin.weight, lin.bias)
     return lin(x)
+
+
+def _bf16_autocast():
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
 def _slab(rows):
@@ -189,17 +197,19 @@ class _Conv1x1SplitK(Function):
     and transposes, and the zero-fills in front of its data-gradient kernels, took ~6 ms of the train step."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight):
-        ctx.save_for_backward(x, weight)
+        xb, wb = x.to(torch.bfloat16), weight.to(torch.bfloat16)   # autocast's rounding, done here (see _LinearSplitK)
+        ctx.save_for_backward(xb, wb)
+        ctx.xdtype = x.dtype
         cout, cin = weight.shape[0], weight.shape[1]
-        w2 = weight.view(cout, cin)
-        ctx.cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        w2 = wb.view(cout, cin)
+        ctx.cl = xb.dim() == 4 and xb.is_contiguous(memory_format=torch.channels_last) and not xb.is_contiguous()
         if ctx.cl:
-            B, _, H, W = x.shape
-            return (x.permute(0, 2, 3, 1).reshape(-1, cin) @ w2.t()).view(B, H, W, cout).permute(0, 3, 1, 2)
-        xb = x.contiguous().reshape(x.shape[0], cin, -1)
-        return torch.matmul(w2, xb).view(x.shape[0], cout, *x.shape[2:])
+            B, _, H, W = xb.shape
+            return (xb.permute(0, 2, 3, 1).reshape(-1, cin) @ w2.t()).view(B, H, W, cout).permute(0, 3, 1, 2)
+        xr = xb.contiguous().reshape(xb.shape[0], cin, -1)
+        return torch.matmul(w2, xr).view(xb.shape[0], cout, *xb.shape[2:])
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -207,30 +217,32 @@ class _Conv1x1SplitK(Function):
         x, weight = ctx.saved_tensors
         cout, cin = weight.shape[0], weight.shape[1]
         w2 = weight.view(cout, cin)
+        dy = dy.to(torch.bfloat16)
         dx = None
         if ctx.cl:
             B, _, H, W = x.shape
             xv = x.permute(0, 2, 3, 1).reshape(-1, cin)                       # views: positions x channels
             gv = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cout)
             if ctx.needs_input_grad[0]:
-                dx = (gv @ w2).view(B, H, W, cin).permute(0, 3, 1, 2)
+                dx = (gv @ w2).view(B, H, W, cin).permute(0, 3, 1, 2).to(ctx.xdtype)
             s = _slab(xv.shape[0])
             if s:
-                dw = torch.bmm(gv.view(-1, s, cout).transpose(1, 2), xv.view(-1, s, cin)).float().sum(0)
+                dw = torch.bmm(gv.view(-1, s, cout).transpose(1, 2), xv.view(-1, s, cin)).sum(0, dtype=torch.float32)
             else:
                 dw = (gv.t() @ xv).float()
         else:                                                                   # (B, C, L...) position fastest: one GEMM per sample
-            xb = x.contiguous().reshape(x.shape[0], cin, -1)
+            xr = x.contiguous().reshape(x.shape[0], cin, -1)
             gb = dy.contiguous().reshape(x.shape[0], cout, -1)
             if ctx.needs_input_grad[0]:
-                dx = torch.matmul(w2.t(), gb).view(x.shape)
-            dw = torch.bmm(gb, xb.transpose(1, 2)).float().sum(0)
-        return dx, dw.to(weight.dtype).view_as(weight)
+                dx = torch.matmul(w2.t(), gb).view(x.shape).to(ctx.xdtype)
+            dw = torch.bmm(gb, xr.transpose(1, 2)).sum(0, dtype=torch.float32)
+        return dx, dw.view(cout, cin, *([1] * (x.dim() - 2)))
 
 
 def conv1x1(x, conv):
     """conv(x) for a plain 1x1 convolution, with the split-K weight gradient under bf16 autocast on the GPU."""
-    if (ENABLED and x.is_cuda and torch.is_autocast_enabled() and conv.bias is None and conv.weight.requires_grad
+    if (ENABLED and x.is_cuda and _bf16_autocast() and conv.bias is None and conv.weight.requires_grad
+            and conv.weight.dtype == torch.float32
             and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride) and all(v == 0 for v in conv.padding)
             and all(v == 1 for v in conv.dilation) and conv.groups == 1 and isinstance(conv.padding, tuple)
             and x.dim() == conv.weight.dim() and x.numel() >= (1 << 20)):
