@@ -420,6 +420,10 @@ int pdm_tune_fused_wg_per_cu(int n);    /* grid cap = 256 CUs x n workgroups */
 int pdm_tune_fused_lds_cap(int bytes);  /* LDS a two-tile workgroup may take (<= 160 KB) */
 int pdm_tune_fused_reg(int on);         /* register-resident SA form for small scales */
 int pdm_tune_fused_gemm(int on);        /* LDS-tiled GEMM for single-layer rows / two-layer FP with tiny skip */
+int pdm_tune_fused_chain(int on);       /* register-resident chain kernels (rows_chain.hip) for many-row MLPs and FP modules 1-2 */
+int pdm_tune_fused_swz(int on);         /* XOR-swizzled LDS tiles in the general chain kernels */
+int pdm_tune_bq_quad(int on);           /* four centres per wave in the grid ball query */
+int pdm_tune_fp_chain_pad_lds(int bytes); /* diagnostic: extra LDS per workgroup of the FP chain kernel (occupancy experiments) */
 
 /* count device-to-device copies dst[k] <- src[k] (bytes[k] each; host arrays) in one launch per 48 buffers.
  * Plumbing for the stream pipeline's hand-over buffers, not a reference operator. */
