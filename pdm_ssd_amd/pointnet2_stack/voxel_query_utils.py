@@ -40,35 +40,32 @@ voxel_query = VoxelQuery.apply
 
 
 class VoxelQueryAndGrouping(nn.Module):
+    """Voxel-window query followed by the stacked grouping operator (ref :50-101)."""
+
     def __init__(self, max_range, radius: float, nsample: int):
-        """max_range: (z, y, x) half-widths of the voxel window; radius / nsample as in the ball query (ref :52-60)."""
+        """max_range: (z, y, x) half-widths of the voxel window; radius / nsample as in the ball query."""
         super().__init__()
         self.max_range, self.radius, self.nsample = max_range, radius, nsample
 
     def forward(self, new_coords: torch.Tensor, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor,
                 new_xyz: torch.Tensor, new_xyz_batch_cnt: torch.Tensor,
                 features: torch.Tensor, voxel2point_indices: torch.Tensor):
-        """ref :62-101.
-        new_coords (M1+M2.., 4) [batch, z, y, x] voxel coordinates of the key points; xyz (N1+N2.., 3); features (N1+N2.., C);
-        voxel2point_indices (B, Z, Y, X) index of the point recorded in each voxel or -1.
+        """new_coords (M1+M2.., 4) [batch, z, y, x] voxel coordinates of the key points; xyz (N1+N2.., 3); features
+        (N1+N2.., C); voxel2point_indices (B, Z, Y, X) index of the point recorded in each voxel or -1.
         -> (grouped_features (M, C, nsample), grouped_xyz (M, 3, nsample), empty_ball_mask (M,)).
-        As upstream, the samples must hold the same number of key points (the (batch_size, -1, nsample) view, ref :85)."""
-        assert xyz.shape[0] == xyz_batch_cnt.sum(), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
-        assert new_coords.shape[0] == new_xyz_batch_cnt.sum(), \
-            'new_coords: %s, new_xyz_batch_cnt: %s' % (str(new_coords.shape), str(new_xyz_batch_cnt))
-        batch_size = xyz_batch_cnt.shape[0]
+        As upstream, every sample must hold the same number of key points (its (batch_size, -1, nsample) view, ref :85)."""
+        n_pts, n_keys = int(xyz_batch_cnt.sum()), int(new_xyz_batch_cnt.sum())
+        assert xyz.shape[0] == n_pts, f'xyz: {tuple(xyz.shape)}, xyz_batch_cnt sums to {n_pts}'
+        assert new_coords.shape[0] == n_keys, f'new_coords: {tuple(new_coords.shape)}, new_xyz_batch_cnt sums to {n_keys}'
+        B = xyz_batch_cnt.shape[0]
+        assert n_keys % B == 0, 'the samples must hold equally many key points'
 
-        idx1, empty_ball_mask1 = voxel_query(self.max_range, self.radius, self.nsample, xyz, new_xyz, new_coords, voxel2point_indices)
+        found, nothing_found = voxel_query(self.max_range, self.radius, self.nsample, xyz, new_xyz, new_coords, voxel2point_indices)
+        # the query answers with indices into the stacked xyz; the grouping operator wants them per sample (ref :85-91):
+        # one broadcast subtraction of each sample's first index instead of a python loop over samples
+        first_of_sample = (torch.cumsum(xyz_batch_cnt, 0) - xyz_batch_cnt).to(found.dtype)
+        local = (found.view(B, n_keys // B, self.nsample) - first_of_sample.view(B, 1, 1)).view(n_keys, self.nsample)
+        local[nothing_found] = 0
 
-        # global -> per-sample indices for the grouping operator (ref :85-91); one device subtraction instead of a loop
-        starts = torch.cumsum(xyz_batch_cnt, 0) - xyz_batch_cnt
-        idx1 = idx1.view(batch_size, -1, self.nsample) - starts.view(-1, 1, 1).to(idx1.dtype)
-        idx1 = idx1.view(-1, self.nsample)
-        idx1[empty_ball_mask1] = 0
-
-        idx = idx1
-        empty_ball_mask = empty_ball_mask1
-
-        grouped_xyz = pointnet2_utils.grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-        grouped_features = pointnet2_utils.grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-        return grouped_features, grouped_xyz, empty_ball_mask
+        grouped = [pointnet2_utils.grouping_operation(t, xyz_batch_cnt, local, new_xyz_batch_cnt) for t in (features, xyz)]
+        return grouped[0], grouped[1], nothing_found
