@@ -90,6 +90,34 @@ __global__ __launch_bounds__(TI_THREADS) void three_interpolate_kernel(
     }
 }
 
+// The same with the known rows of `tc` channels staged in LDS (tc * m floats): the three scattered reads per output are
+// LDS reads instead of L1 line fetches (the global form runs at the L1 line rate, ~1 TB/s of output).  Workgroup =
+// (channel group, cloud); a thread keeps a point's indices and weights across the group's channels.
+constexpr int TIF_THREADS = 512;
+__global__ __launch_bounds__(TIF_THREADS) void three_interpolate_lds_kernel(int c, int m, int n, int tc,
+                                                                            const float *__restrict__ points,
+                                                                            const int *__restrict__ idx,
+                                                                            const float *__restrict__ weight,
+                                                                            float *__restrict__ out) {
+    extern __shared__ float ti_rows[];   // [tc][m]
+    const int b = blockIdx.y, c0 = blockIdx.x * tc, nc = min(tc, c - c0);
+    const float *__restrict__ src = points + ((size_t)b * c + c0) * m;
+    for (int i = threadIdx.x; i < nc * m; i += TIF_THREADS) ti_rows[i] = src[i];   // the group's rows are contiguous
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += TIF_THREADS) {
+        const int *id = idx + ((size_t)b * n + j) * 3;
+        const float *w = weight + ((size_t)b * n + j) * 3;
+        const int i0 = id[0], i1 = id[1], i2 = id[2];
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        for (int ci = 0; ci < nc; ++ci) {
+            const float *row = ti_rows + (size_t)ci * m;
+            float t = __fmul_rn(w0, row[i0]);
+            t = __fmaf_rn(w1, row[i1], t);
+            out[((size_t)b * c + c0 + ci) * n + j] = __fmaf_rn(w2, row[i2], t);
+        }
+    }
+}
+
 __global__ __launch_bounds__(TI_THREADS) void three_interpolate_grad_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ grad_points) {
@@ -364,6 +392,17 @@ extern "C" int pdm_three_interpolate(void *stream, int b, int c, int m, int n, c
     if (b == 0 || c == 0 || n == 0) return 0;
     PDM_REQUIRE(points && idx && weight && out, PDM_E_BADARG, "three_interpolate: null pointer");
     PDM_REQUIRE(b <= 65535 && divup(c, TI_CG) <= 65535, PDM_E_TOOLARGE, "three_interpolate: exceeds grid");
+    if (m >= 1 && m <= 8192 && n >= 4 * TIF_THREADS && c >= 2) {
+        // rows of up to 64 KB of known points per workgroup (>= 2 workgroups per CU), enough groups to fill the chip
+        int tc = 16384 / m;
+        tc = tc > 16 ? 16 : tc;
+        tc = tc > c ? c : tc;
+        while (tc > 1 && (long long)divup(c, tc) * b < 512) tc >>= 1;
+        dim3 grid(divup(c, tc), b);
+        hipLaunchKernelGGL(three_interpolate_lds_kernel, grid, dim3(TIF_THREADS), (size_t)tc * m * sizeof(float), as_stream(stream),
+                           c, m, n, tc, points, idx, weight, out);
+        return check_launch("three_interpolate");
+    }
     dim3 grid(divup(n, TI_THREADS), divup(c, TI_CG), b);
     hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(TI_THREADS), 0, as_stream(stream), c, m,
                        n, points, idx, weight, out);
