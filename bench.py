@@ -193,11 +193,11 @@ def reference_op_section(backbone, points, B, iters=5):
         for it in range(iters + 1):
             if it == 1:
                 t.records.clear()  # first pass = warm-up
-            ext.GRID_CACHE.entries.clear()   # every pass is a new batch: one grid build per SA level, shared by its two radii
-            for radius, ns, x, nx, f, xt in plan:
-                idx = pu.ball_query(radius, ns, x, nx)
-                pu.grouping_operation(xt, idx)
-                pu.grouping_operation(f, idx)
+            with pu.shared_search_grids():   # every pass is a new batch: one grid build per SA level, shared by its two radii
+                for radius, ns, x, nx, f, xt in plan:
+                    idx = pu.ball_query(radius, ns, x, nx)
+                    pu.grouping_operation(xt, idx)
+                    pu.grouping_operation(f, idx)
         ops = t.summary(iters)
     ms = sum(o["ms_per_step"] for o in ops)
     mb = sum(o["alg_MB_per_step"] for o in ops)

@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "common.h"
 
 namespace pdm {
@@ -21,6 +25,19 @@ int check_launch(const char *what) {
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) return 0;
     set_error("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+int grant_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
     return (int)e;
 }
 

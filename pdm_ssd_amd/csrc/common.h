@@ -12,6 +12,10 @@ namespace pdm {
 // Thread-local error text behind pdm_last_error().
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+// More than 64 KB of dynamic LDS has to be granted per kernel function AND per device (hipFuncSetAttribute acts on the
+// CURRENT device's copy of the function; entry points may be called for any device).  Remembers (function, device)
+// pairs, thread-safe; returns hipSuccess (0) or the runtime's error code.
+int grant_lds(const void *fn, size_t bytes);
 
 // Scatter-add backward through an inverted (CSR) index, shared by three_interpolate and group_points (interpolate.hip)
 size_t csr_workspace_bytes(int b, long long ne, int m);

@@ -1214,12 +1214,7 @@ extern "C" int pdm_tune_fused_waves(int w) { const int old = g_fused_waves; g_fu
 
 // more than 64 KB of dynamic LDS has to be granted per kernel function (once)
 static void allow_lds(const void *fn, size_t bytes) {
-    if (bytes <= 64 * 1024) return;
-    static std::mutex mu;
-    static std::set<const void *> done;
-    std::lock_guard<std::mutex> lock(mu);
-    if (done.count(fn)) return;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) done.insert(fn);
+    if (bytes > 64 * 1024) (void)grant_lds(fn, 160 * 1024);   // per function and per device (common.h)
 }
 extern "C" int pdm_tune_fused_lds_cap(int bytes) { const int old = g_fused_lds_cap; if (bytes >= 16 * 1024 && bytes <= 160 * 1024) g_fused_lds_cap = bytes; return old; }
 extern "C" int pdm_tune_fused_swz(int on) { const int old = g_fused_swz; g_fused_swz = on != 0; return old; }

@@ -466,14 +466,9 @@ extern "C" int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c
     int *start = reinterpret_cast<int *>(p);
     int *el = start + (size_t)b * (n + 1);
     if ((size_t)n * sizeof(int) + 1024 > 64 * 1024) {   // dynamic + static LDS above the default 64 KB (n near 16384)
-        static bool granted = false;
-        if (!granted) {
-            // (the kernel also holds a small static block: dynamic + static must stay within the 160 KB of a CU)
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pdm::gcl_csr_build_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "group_concat_cl_grad: cannot obtain %zu bytes of LDS", (size_t)n * sizeof(int));
-            granted = true;
-        }
+        // (the kernel also holds a small static block: dynamic + static must stay within the 160 KB of a CU)
+        const int e = pdm::grant_lds(reinterpret_cast<const void *>(&pdm::gcl_csr_build_kernel), 128 * 1024);
+        PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "group_concat_cl_grad: cannot obtain %zu bytes of LDS", (size_t)n * sizeof(int));
     }
     hipLaunchKernelGGL(pdm::gcl_csr_build_kernel, dim3(b), dim3(pdm::GCL_THREADS), (size_t)n * sizeof(int), pdm::as_stream(stream), ne,
                        n, idx, start, el);

@@ -190,13 +190,10 @@ extern "C" int pdm_sample_points(void *stream, int B, int num_points, unsigned s
     int p2 = 2;
     while (p2 < num_points) p2 <<= 1;
     const size_t lds = (size_t)p2 * sizeof(unsigned long long);
-    static bool granted = false;   // > 64 KB of dynamic LDS has to be granted once
-    if (lds > 64 * 1024 && !granted) {
+    if (lds > 64 * 1024) {   // > 64 KB of dynamic LDS has to be granted, per device
         // (the kernel also has ~1.2 KB of static LDS: dynamic + static must stay within the CU's 160 KB)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sample_points_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "sample_points: cannot obtain %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-        granted = true;
+        const int e = grant_lds(reinterpret_cast<const void *>(&sample_points_kernel), 156 * 1024);
+        PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "sample_points: cannot obtain %zu bytes of LDS: %s", lds, hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(sample_points_kernel, dim3(B), dim3(IP_THREADS), lds, as_stream(stream), B, num_points, seed, C, raw, counts,
                        out, choice);

@@ -308,14 +308,9 @@ int csr_scatter_grad_launch(void *stream, const char *who, int b, int c, int row
     p += ((size_t)b * ne * sizeof(unsigned short) + 15) / 16 * 16;
     float *ew = reinterpret_cast<float *>(p);
     if ((size_t)m * sizeof(int) + 1024 > 64 * 1024) {   // dynamic + static LDS above the default 64 KB (m near 16384)
-        static bool granted_build = false;
-        if (!granted_build) {
-            // (the kernel also holds a small static block: dynamic + static must stay within the 160 KB of a CU)
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_csr_build_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "%s: cannot obtain %zu bytes of LDS", who, (size_t)m * sizeof(int));
-            granted_build = true;
-        }
+        // (the kernel also holds a small static block: dynamic + static must stay within the 160 KB of a CU)
+        const int e = grant_lds(reinterpret_cast<const void *>(&interp_csr_build_kernel), 128 * 1024);
+        PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "%s: cannot obtain %zu bytes of LDS", who, (size_t)m * sizeof(int));
     }
     hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(TIC_THREADS), (size_t)m * sizeof(int), as_stream(stream), ne, per, m,
                        idx, weight, start, ej, ew);
@@ -323,15 +318,12 @@ int csr_scatter_grad_launch(void *stream, const char *who, int b, int c, int row
     if (rc) return rc;
     // channel rows staged per workgroup: as many as fit 128 KB of LDS, at most 8
     const int tc = row_len <= 4096 ? 8 : row_len <= 8192 ? 4 : row_len <= 16384 ? 2 : 1;
-    static bool granted[4] = {false, false, false, false};
 #define PDM_TIC_LAUNCH(TCV, SLOT)                                                                                      \
     do {                                                                                                               \
         const size_t lds = (size_t)TCV * row_len * sizeof(float);                                                      \
-        if (lds > 64 * 1024 && !granted[SLOT]) {                                                                       \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_grad_csr_kernel<TCV>),     \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);          \
-            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "%s: cannot obtain %zu bytes of LDS", who, lds);              \
-            granted[SLOT] = true;                                                                                      \
+        if (lds > 64 * 1024) {   /* granted per function and per device (common.h) */                                  \
+            const int e = grant_lds(reinterpret_cast<const void *>(&interp_grad_csr_kernel<TCV>), 160 * 1024);         \
+            PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "%s: cannot obtain %zu bytes of LDS", who, lds);                       \
         }                                                                                                              \
         hipLaunchKernelGGL(interp_grad_csr_kernel<TCV>, dim3(divup(c, TCV), b), dim3(TIC_THREADS), lds, as_stream(stream), \
                            c, row_len, ne, m, grad_out, start, ej, ew, grad_points);                                   \

@@ -264,12 +264,9 @@ extern "C" int pdm_nms(void *stream, int n, const float *boxes, float thresh, in
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, as_stream(stream), n, cb, mask, keep, num_out);
     } else {
         const size_t lds = (size_t)cb * sizeof(unsigned long long);
-        static bool granted = false;
-        if (lds > 64 * 1024 - 256 && !granted) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_scan_lds_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "nms: cannot obtain %zu bytes of LDS", lds);
-            granted = true;
+        if (lds > 64 * 1024 - 256) {   // granted per device (common.h)
+            const int e = grant_lds(reinterpret_cast<const void *>(&nms_scan_lds_kernel), 160 * 1024);
+            PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "nms: cannot obtain %zu bytes of LDS", lds);
         }
         hipLaunchKernelGGL(nms_scan_lds_kernel, dim3(1), dim3(64), lds, as_stream(stream), n, cb, mask, keep, num_out);
     }

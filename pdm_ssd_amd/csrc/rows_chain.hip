@@ -484,7 +484,7 @@ int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *
     if (grid >= 8) grid &= ~7;   // a multiple of the 8 XCDs (the tile loop covers the rest)
 #define FC_TRY(K0, K1, K2, COND)                                                                                      \
     if ((COND) && dims[1] == 16 * K1 && dims[2] == 16 * K2) {                                                        \
-        if (g_fpc_pad_lds > 65536 - 50000) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_chain_kernel<K0, K1, K2>), hipFuncAttributeMaxDynamicSharedMemorySize, g_fpc_pad_lds); \
+        if (g_fpc_pad_lds > 65536 - 50000) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_chain_kernel<K0, K1, K2>), hipFuncAttributeMaxDynamicSharedMemorySize, g_fpc_pad_lds); /* a tuning knob: set on every call */ \
         hipLaunchKernelGGL((fp_chain_kernel<K0, K1, K2>), dim3(grid), dim3(RC_THREADS), g_fpc_pad_lds, as_stream(stream), a);    \
         *launched = 1;                                                                                               \
         return check_launch("fp_mlp_fused_pre(chain)");                                                              \

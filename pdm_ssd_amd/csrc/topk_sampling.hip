@@ -126,12 +126,9 @@ extern "C" int pdm_topk_sampling(void *stream, int b, int n, int k, const float 
     int k2 = 2;
     while (k2 < k) k2 <<= 1;
     const size_t lds = (size_t)k2 * sizeof(unsigned long long);
-    static bool granted = false;   // > 64 KB of dynamic LDS has to be granted once (static LDS comes on top: 156 KB)
-    if (lds > 64 * 1024 && !granted) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sampling_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        PDM_REQUIRE(e == hipSuccess, PDM_E_TOOLARGE, "topk_sampling: cannot obtain %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-        granted = true;
+    if (lds > 64 * 1024) {   // > 64 KB of dynamic LDS has to be granted, per device (static LDS comes on top: 156 KB)
+        const int e = grant_lds(reinterpret_cast<const void *>(&topk_sampling_kernel), 156 * 1024);
+        PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "topk_sampling: cannot obtain %zu bytes of LDS: %s", lds, hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(topk_sampling_kernel, dim3(b), dim3(TK_THREADS), lds, as_stream(stream), n, k, scores, idx);
     return check_launch("topk_sampling");

@@ -61,7 +61,8 @@ class PointHeadBox(PointHeadTemplate):
         ).view(batch_size, -1, gt_boxes.shape[-1])
         return self.assign_stack_targets(points=point_coords, gt_boxes=gt_boxes, extend_gt_boxes=extend_gt_boxes,
                                          set_ignore_flag=True, use_ball_constraint=False,
-                                         ret_part_labels=False, ret_box_labels=True)
+                                         ret_part_labels=False, ret_box_labels=True,
+                                         equal_counts=True if input_dict.get('points_per_sample_checked', False) else None)
 
     def get_loss(self, tb_dict=None):
         tb_dict = {} if tb_dict is None else tb_dict

@@ -53,7 +53,7 @@ class PointHeadTemplate(nn.Module):
     # ------------------------------------------------------------------ targets
 
     def assign_stack_targets(self, points, gt_boxes, extend_gt_boxes=None, ret_box_labels=False, ret_part_labels=False,
-                             set_ignore_flag=True, use_ball_constraint=False, central_radius=2.0):
+                             set_ignore_flag=True, use_ball_constraint=False, central_radius=2.0, equal_counts=None):
         """points (N1 + N2 + ..., 4) [bs_idx, x, y, z], gt_boxes (B, M, 8) [box7, class] (zero rows = padding),
         extend_gt_boxes (B, M, 8) -> point_cls_labels (long; 0 background, -1 ignored, else class),
         point_box_labels (.., code_size) of the foreground points' boxes, point_part_labels (.., 3).
@@ -66,7 +66,16 @@ class PointHeadTemplate(nn.Module):
         assert set_ignore_flag != use_ball_constraint, 'Choose one only!'
         B = gt_boxes.shape[0]
         n_total = points.shape[0]
-        if n_total % B != 0 or not bool((points[:: max(n_total // B, 1), 0] == torch.arange(B, device=points.device)).all()):
+        # One batched call when every sample has the same point count.  equal_counts=True: the caller has checked that
+        # already (PointNet2MSG.forward asserts it; batch_dict['points_per_sample_checked']) — no host sync here.
+        # Otherwise test it: with the batch column sorted, the first AND the last row of every n-sized block carrying
+        # the block's id is exact (the first row alone lets counts like (3, 5) through).
+        n_blk = max(n_total // B, 1)
+        if equal_counts is None:
+            ids = torch.arange(B, device=points.device)
+            equal_counts = n_total % B == 0 and n_total > 0 and bool(
+                ((points[::n_blk, 0] == ids) & (points[n_blk - 1::n_blk, 0] == ids)).all())
+        if not equal_counts or n_total % B != 0:
             return self._assign_ragged(points, gt_boxes, extend_gt_boxes, ret_box_labels, ret_part_labels, set_ignore_flag,
                                        use_ball_constraint, central_radius)
         n = n_total // B

@@ -158,9 +158,15 @@ class Detector3DTemplate(nn.Module):
         return pred_dicts, {}
 
     def load_params_from_state_dict(self, model_state_disk, strict=True):
-        """Copy every entry whose key and shape match (ref :330-359, without the spconv weight re-layout)."""
+        """Copy every entry whose key and shape match (ref :330-359, without the spconv weight re-layout).  As in the
+        reference (:354-358): strict=True loads ONLY the matching entries, strictly — a checkpoint that lacks a
+        parameter of this model (or holds it with another shape) raises; strict=False keeps this model's own values
+        for those.  Returns the keys that were not taken from the checkpoint."""
         state = self.state_dict()
         update = {k: v for k, v in model_state_disk.items() if k in state and state[k].shape == v.shape}
-        state.update(update)
-        self.load_state_dict(state) if strict else self.load_state_dict(update, strict=False)
+        if strict:
+            self.load_state_dict(update)
+        else:
+            state.update(update)
+            self.load_state_dict(state)
         return [k for k in state if k not in update]

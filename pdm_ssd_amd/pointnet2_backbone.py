@@ -12,7 +12,7 @@ PDM neck (extra keys; nothing upstream reads them).
 import torch
 import torch.nn as nn
 
-from .pointnet2_batch import pointnet2_modules
+from .pointnet2_batch import pointnet2_modules, pointnet2_utils
 
 
 def _get(cfg, key, default=None):
@@ -76,13 +76,16 @@ class PointNet2MSG(nn.Module):
         Lists indexed by level.  first_idx = FPS indices of level `first` computed elsewhere (pipeline.py)."""
         out = {'sampled_xyz': [], 'ball_idx': [], 'fp_interp': []}
         src = xyz_in
-        for k in range(first, last):
-            sa = self.SA_modules[k]
-            new_xyz = sa.sample(src) if (k > first or first_idx is None) else sa.sample_from_idx(src, first_idx)
-            out['sampled_xyz'].append(new_xyz)
-            out['ball_idx'].append(sa.query(src, new_xyz))
-            out['fp_interp'].append(pointnet2_modules.PointnetFPModule.interpolation(src.contiguous(), new_xyz))
-            src = new_xyz
+        # a level's sampled set is the known set of its three_nn AND the source of the next level's ball queries: one
+        # search grid serves all three.  Nothing in this block rewrites a point set (xyz_in is only read).
+        with pointnet2_utils.shared_search_grids():
+            for k in range(first, last):
+                sa = self.SA_modules[k]
+                new_xyz = sa.sample(src) if (k > first or first_idx is None) else sa.sample_from_idx(src, first_idx)
+                out['sampled_xyz'].append(new_xyz)
+                out['ball_idx'].append(sa.query(src, new_xyz))
+                out['fp_interp'].append(pointnet2_modules.PointnetFPModule.interpolation(src.contiguous(), new_xyz))
+                src = new_xyz
         return out
 
     @torch.no_grad()
@@ -137,6 +140,7 @@ class PointNet2MSG(nn.Module):
         if not batch_dict.get('points_per_sample_checked', False):
             counts = torch.bincount(batch_idx.long(), minlength=batch_size)
             assert counts.min() == counts.max(), 'PointNet2MSG needs the same point count in every sample'
+            batch_dict['points_per_sample_checked'] = True   # later modules (the point head's targets) need not re-check
         xyz = xyz.view(batch_size, -1, 3)
         if features is not None:
             features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
@@ -145,6 +149,10 @@ class PointNet2MSG(nn.Module):
         presampled = batch_dict.get('sampled_xyz', None)
         ball_idx = batch_dict.get('ball_idx', None)      # optional, from coordinate_levels()
         fp_interp = batch_dict.get('fp_interp', None)
+        with pointnet2_utils.shared_search_grids():
+            return self._forward_levels(batch_dict, batch_idx, l_xyz, l_features, presampled, ball_idx, fp_interp)
+
+    def _forward_levels(self, batch_dict, batch_idx, l_xyz, l_features, presampled, ball_idx, fp_interp):
         for k, sa in enumerate(self.SA_modules):
             li_xyz, li_features = sa(l_xyz[-1], l_features[-1],
                                      new_xyz=None if presampled is None else presampled[k],

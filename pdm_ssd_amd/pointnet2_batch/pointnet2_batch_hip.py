@@ -9,6 +9,9 @@ Differences from the reference wrappers (all stricter): every tensor is checked 
 and contiguity and a Python exception is raised (the reference checks only ball_query and calls
 exit(-1): ball_query.cpp:14-26); a failed launch raises instead of exiting.
 """
+import contextlib
+import weakref
+
 import torch
 
 from .. import _native
@@ -48,27 +51,48 @@ NN_GRID_MIN_M = 512
 
 
 class _GridCache:
-    """Search grids of recently seen point sets (pdm_grid_build), so the calls that search the same set share one
-    build: the two radii of an SA level's ball queries and the three_nn whose known set it is (SURVEY.md section 7:
-    "both MSG radii in one pass").  An entry belongs to one tensor OBJECT (weak reference) at one version: a new tensor
-    that happens to reuse the address, or an in-place write, misses.  Any grid gives exact results — the cell size
-    only decides how many candidates a query visits — so the first caller's radius sizes it."""
-    SIZE = 6
+    """Search grids shared between the calls that search the SAME point set (pdm_grid_build): the two radii of an SA
+    level's ball queries and the three_nn whose known set it is ("both MSG radii in one pass").
+    Any grid gives exact results — the cell size only decides how many candidates a query visits — so the first
+    caller's radius sizes it.
+
+    Sharing is EXPLICIT: grids are kept only inside a `with GRID_CACHE.scope():` block, and every entry is dropped
+    when the outermost scope ends.  Whoever opens a scope promises that the point sets searched inside it are not
+    rewritten inside it.  (Round 2 kept entries across calls, keyed on the tensor object and its `_version`; this
+    library's own writers — pdm_copy_many into the pipeline's static hand-over buffers, hipGraph replays into static
+    outputs — go through raw device pointers and never change `_version`, so a later batch could be searched on the
+    previous batch's grid.  pdm_ball_query_grid_prebuilt takes no xyz pointer: the coordinates it searches are the
+    ones stored in the grid.)  Outside a scope every call builds a grid of its own.  Scopes are opened by the code
+    that owns the point sets for the duration: PointNet2MSG.coordinate_levels / forward and the SA module's
+    query / forward.  Under hipGraph capture the build is captured with its queries and the workspace belongs to
+    the graph's private pool, so dropping the entry at scope exit leaves the graph intact."""
 
     def __init__(self):
-        self.entries = []   # (weakref, version, b, n, stream, workspace)
+        self.entries = []   # (weakref, version, data_ptr, b, n, stream, workspace, nbytes)
+        self.depth = 0
+
+    @contextlib.contextmanager
+    def scope(self):
+        self.depth += 1
+        try:
+            yield self
+        finally:
+            self.depth -= 1
+            if self.depth == 0:
+                self.entries.clear()
 
     def get(self, pts, b, n, radius_hint):
-        import weakref
         stream = torch.cuda.current_stream(pts.device).cuda_stream
-        for e in self.entries:
-            if e[0]() is pts and e[1] == pts._version and e[2] == b and e[3] == n and e[4] == stream:
-                return e[5], e[6]
+        if self.depth > 0:
+            for e in self.entries:
+                if (e[0]() is pts and e[1] == pts._version and e[2] == pts.data_ptr() and e[3] == b and e[4] == n
+                        and e[5] == stream):
+                    return e[6], e[7]
         nbytes = _native.lib().pdm_ball_query_grid_workspace_bytes(b, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
         _run("pdm_grid_build", pts, b, n, float(radius_hint), pts.data_ptr(), ws.data_ptr(), nbytes)
-        self.entries.insert(0, (weakref.ref(pts), pts._version, b, n, stream, ws, nbytes))
-        del self.entries[self.SIZE:]
+        if self.depth > 0:
+            self.entries.insert(0, (weakref.ref(pts), pts._version, pts.data_ptr(), b, n, stream, ws, nbytes))
         return ws, nbytes
 
 

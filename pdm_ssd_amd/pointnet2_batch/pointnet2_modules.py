@@ -79,8 +79,9 @@ class _PointnetSAModuleBase(nn.Module):
         """Neighbour indices of every scale, [(B,M,nsample) int32]: coordinate-only, so a caller may compute them
         ahead of time (pdm_ssd_amd/pipeline.py) and pass them to forward(..., idx_list=)."""
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
-        return [self._maybe_pack(pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
-                for g in self.groupers]
+        with pointnet2_utils.shared_search_grids():   # one grid of `xyz` for every radius
+            return [self._maybe_pack(pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
+                    for g in self.groupers]
 
     def _maybe_pack(self, idx, n):
         """Compact the neighbour list for the fused kernels (fused.sa_pack) when the module takes its fused inference
@@ -128,6 +129,10 @@ class _PointnetSAModuleBase(nn.Module):
         In eval mode without autograd each scale runs as one fused HIP kernel (gather + MLP on fp32 MFMA
         + max-pool); the returned features are then a (B,C,M) VIEW of point-major (B,M,C) storage.
         """
+        with pointnet2_utils.shared_search_grids():   # the scales search the same `xyz`, which nothing here rewrites
+            return self._forward(xyz, features, new_xyz, idx_list)
+
+    def _forward(self, xyz, features, new_xyz, idx_list):
         if new_xyz is None:
             new_xyz = self.sample(xyz)
         packs = self._fused_packs(xyz, features)

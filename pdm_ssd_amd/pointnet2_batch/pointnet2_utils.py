@@ -18,6 +18,13 @@ from torch.autograd import Function
 
 from . import pointnet2_batch_hip as pointnet2
 
+
+def shared_search_grids():
+    """`with shared_search_grids():` — the ball queries / three_nn calls inside the block that search the same point
+    set share one search grid (pointnet2_batch_hip.GRID_CACHE).  The caller promises not to rewrite those point sets
+    inside the block; every grid is dropped when the outermost block ends."""
+    return pointnet2.GRID_CACHE.scope()
+
 _FP32_FWD = dict(device_type="cuda", cast_inputs=torch.float32)
 
 

@@ -27,13 +27,17 @@ def gaussian_radius(height, width, min_overlap=0.5):
 def draw_gaussians(heatmap, cls_idx, centers_int, radius, valid, max_radius=8):
     """heatmap (B, C, H, W) zero-initialised, updated in place; per box: batch index / class channel in `cls_idx`
     (B, M, 2) long, integer centre cell (B, M, 2) = (x, y), integer radius (B, M), valid (B, M) bool.
-    Window half-width is capped at `max_radius` cells (the gaussian is ~1e-8 there for any smaller radius)."""
+    The batched window is (2 max_radius + 1)^2 cells: a box of radius <= max_radius gets exactly the reference's window;
+    a larger one keeps the reference's sigma = (2 r + 1) / 6 (from the UNCLAMPED radius) and loses only the part of its
+    window beyond max_radius cells — pass max_radius >= the largest radius (PDMHeatmapHead derives it from MAX_RADIUS
+    in the target config) for exact targets."""
     B, C, H, W = heatmap.shape
     dev = heatmap.device
     k = torch.arange(-max_radius, max_radius + 1, device=dev)
     dy, dx = torch.meshgrid(k, k, indexing="ij")                                     # (K, K)
-    r = radius.clamp(min=0, max=max_radius).float()[..., None, None]                  # (B, M, 1, 1)
-    sigma = (2 * r + 1) / 6
+    r_true = radius.clamp(min=0).float()[..., None, None]                            # (B, M, 1, 1)
+    r = r_true.clamp(max=max_radius)
+    sigma = (2 * r_true + 1) / 6
     g = torch.exp(-(dx * dx + dy * dy).float() / (2 * sigma * sigma))                # (B, M, K, K)
     inside = (dx.abs() <= r) & (dy.abs() <= r)
     g = torch.where(g < torch.finfo(torch.float32).eps, torch.zeros_like(g), g)       # h[h < eps * h.max()] = 0, max = 1

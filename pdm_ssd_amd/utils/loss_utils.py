@@ -7,33 +7,37 @@ Code weights follow the device of the input instead of being moved to the GPU at
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 class SigmoidFocalClassificationLoss(nn.Module):
+    """Focal loss on logits: balance(t) * miss(t, p)^gamma * BCE(x, t) per element, where p = sigmoid(x),
+    miss = the probability mass on the wrong side, balance = alpha for positives and 1 - alpha for negatives."""
+
     def __init__(self, gamma: float = 2.0, alpha: float = 0.25):
         super().__init__()
         self.alpha, self.gamma = alpha, gamma
 
     @staticmethod
     def sigmoid_cross_entropy_with_logits(input, target):
-        """max(x, 0) - x z + log(1 + exp(-|x|)) — the numerically stable form (:26-43)."""
-        return torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
+        """Binary cross entropy of logits in its overflow-free form (kept under the reference's name, :26-43)."""
+        return F.binary_cross_entropy_with_logits(input, target, reduction='none')
 
     def forward(self, input, target, weights):
         """input / target (B, #anchors, #classes) logits / one-hot, weights (B, #anchors) -> unreduced loss."""
-        pred_sigmoid = torch.sigmoid(input)
-        alpha_weight = target * self.alpha + (1 - target) * (1 - self.alpha)
-        pt = target * (1.0 - pred_sigmoid) + (1.0 - target) * pred_sigmoid
-        focal_weight = alpha_weight * torch.pow(pt, self.gamma)
-        loss = focal_weight * self.sigmoid_cross_entropy_with_logits(input, target)
-        if weights.dim() == 2 or (weights.dim() == 1 and target.dim() == 2):
-            weights = weights.unsqueeze(-1)
-        assert weights.dim() == loss.dim()
-        return loss * weights
+        p = torch.sigmoid(input)
+        miss = torch.lerp(p, 1.0 - p, target)                   # t (1 - p) + (1 - t) p
+        balance = (1.0 - self.alpha) + target * (2.0 * self.alpha - 1.0)
+        per_elem = balance * miss.pow(self.gamma) * self.sigmoid_cross_entropy_with_logits(input, target)
+        if weights.dim() + 1 == per_elem.dim():                  # one weight per anchor: broadcast over the classes
+            weights = weights[..., None]
+        assert weights.dim() == per_elem.dim()
+        return per_elem * weights
 
 
 class WeightedSmoothL1Loss(nn.Module):
-    """smooth-L1 with change point beta = 1/9, code-wise weights, anchor-wise weights; NaN targets are ignored."""
+    """Huber-style regression loss with the knee at beta (default 1/9): quadratic inside, linear outside; residuals are
+    scaled per code before the loss and per anchor after it; a NaN target switches its element off."""
 
     def __init__(self, beta: float = 1.0 / 9.0, code_weights: list = None):
         super().__init__()
@@ -42,43 +46,38 @@ class WeightedSmoothL1Loss(nn.Module):
 
     @staticmethod
     def smooth_l1_loss(diff, beta):
-        if beta < 1e-5:
-            return torch.abs(diff)
-        n = torch.abs(diff)
-        return torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+        mag = diff.abs()
+        if beta < 1e-5:          # degenerate knee: plain L1
+            return mag
+        return torch.where(mag < beta, mag * mag * (0.5 / beta), mag - 0.5 * beta)
 
     def forward(self, input, target, weights=None):
         """input / target (B, #anchors, #codes), weights (B, #anchors) -> (B, #anchors, #codes) unreduced."""
-        target = torch.where(torch.isnan(target), input, target)
-        diff = input - target
+        residual = torch.where(torch.isnan(target), torch.zeros_like(input), input - target)
         if self.code_weights is not None:
-            if self.code_weights.device != diff.device:
-                self.code_weights = self.code_weights.to(diff.device)
-            diff = diff * self.code_weights.view(1, 1, -1)
-        loss = self.smooth_l1_loss(diff, self.beta)
+            self.code_weights = self.code_weights.to(residual.device)
+            residual = residual * self.code_weights
+        out = self.smooth_l1_loss(residual, self.beta)
         if weights is not None:
-            assert weights.shape[0] == loss.shape[0] and weights.shape[1] == loss.shape[1]
-            loss = loss * weights.unsqueeze(-1)
-        return loss
+            assert weights.shape[:2] == out.shape[:2]
+            out = out * weights[..., None]
+        return out
 
 
 def neg_loss_cornernet(pred, gt, mask=None):
-    """pred / gt (B, C, H, W) in (0, 1) / [0, 1]: -(sum over gt == 1 of log(p)(1-p)^2 + sum over gt < 1 of
-    log(1-p) p^2 (1-gt)^4) / #positives (the negative term alone when there is no positive)."""
-    pos_inds = gt.eq(1).float()
-    neg_inds = gt.lt(1).float()
-    neg_weights = torch.pow(1 - gt, 4)
-    pos_loss = torch.log(pred) * torch.pow(1 - pred, 2) * pos_inds
-    neg_loss = torch.log(1 - pred) * torch.pow(pred, 2) * neg_weights * neg_inds
+    """Penalty-reduced pixel focal loss of the heat-map head.  pred / gt (B, C, H, W) in (0, 1) / [0, 1]: peaks
+    (gt == 1) contribute (1-p)^2 log p, every other cell (1-gt)^4 p^2 log(1-p); the sum is negated and divided by the
+    number of peaks (by 1 when there is none, which leaves the negative term alone)."""
+    peak = gt == 1
+    zero = torch.zeros_like(pred)
+    at_peaks = torch.where(peak, (1 - pred).square() * pred.log(), zero)
+    elsewhere = torch.where(peak, zero, (1 - gt).pow(4) * pred.square() * (1 - pred).log())
+    peaks = peak.to(pred.dtype)
     if mask is not None:
-        mask = mask[:, None, :, :].float()
-        pos_loss, neg_loss = pos_loss * mask, neg_loss * mask
-        num_pos = (pos_inds * mask).sum()
-    else:
-        num_pos = pos_inds.sum()
-    pos_loss, neg_loss = pos_loss.sum(), neg_loss.sum()
+        keep = mask[:, None].to(pred.dtype)
+        at_peaks, elsewhere, peaks = at_peaks * keep, elsewhere * keep, peaks * keep
     # (the reference branches on the host, `if num_pos == 0`: a device->host sync per step; same value here)
-    return -(pos_loss + neg_loss) / torch.clamp(num_pos, min=1.0)
+    return -(at_peaks.sum() + elsewhere.sum()) / peaks.sum().clamp(min=1.0)
 
 
 class FocalLossCenterNet(nn.Module):

@@ -172,3 +172,15 @@ def test_detector_registry_and_module_slots():
         build_pdm_ssd(bad)
     missing = model.load_params_from_state_dict({k: v for k, v in model.state_dict().items() if 'point_head' not in k}, strict=False)
     assert missing and all('point_head' in k for k in missing)
+    # strict (the default, ref detector3d_template.py:354-358): a checkpoint that lacks parameters of the model raises,
+    # one whose entry has another shape raises too (the entry is dropped, hence missing); a complete one loads
+    partial = {k: v for k, v in model.state_dict().items() if 'point_head' not in k}
+    with pytest.raises(RuntimeError, match="Missing key"):
+        model.load_params_from_state_dict(partial)
+    reshaped = dict(model.state_dict())
+    reshaped['point_head.box_layers.6.bias'] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="Missing key"):
+        model.load_params_from_state_dict(reshaped)
+    full = {k: v.clone() + (1.0 if v.is_floating_point() else 0) for k, v in model.state_dict().items()}
+    assert model.load_params_from_state_dict(full) == []
+    assert torch.equal(model.state_dict()['point_head.box_layers.6.bias'], full['point_head.box_layers.6.bias'])

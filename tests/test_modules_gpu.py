@@ -152,6 +152,28 @@ def test_pipelined_hot_path_equals_serial(dev, depth):
             assert torch.equal(bd['spatial_features'], ref[i][1]), f"batch {i}"
 
 
+def test_pipelined_depth2_large_level1_uses_fresh_grids(dev):
+    """depth 2 hands level 1's sampled set over in a STATIC buffer (pdm_copy_many rewrites it every step without
+    touching the tensor's _version) and searches it with the grid kernels once it has >= 2048 points: every batch of a
+    sequence of different batches must still equal the serial path (a search grid kept from the previous step would
+    return the previous batch's neighbours)."""
+    from pdm_ssd_amd.pipeline import PipelinedHotPath
+    torch.manual_seed(0)
+    cfg = {'SA_CONFIG': {'NPOINTS': [2048, 256], 'RADIUS': [[0.5, 1.0], [1.0, 2.0]], 'NSAMPLE': [[16, 32], [16, 32]],
+                         'MLPS': [[[16, 16], [16, 32]], [[32, 32], [32, 64]]]}, 'FP_MLPS': [[32, 32], [64, 64]]}
+    backbone = PointNet2MSG(cfg, input_channels=4).to(dev).eval()
+    B, N = 2, 8192
+    batches = [torch.from_numpy(synthetic.to_batch_points(synthetic.lidar_like_clouds(B, N, 500 + i))).to(dev) for i in range(8)]
+    with torch.no_grad():
+        ref = [backbone({'batch_size': B, 'points': p})['point_features'].clone() for p in batches[:6]]
+        pipe = PipelinedHotPath(backbone, None, depth=2)
+        pipe.prime(batches[0], B, points_next=batches[1])
+        for i in range(6):
+            bd = pipe.step(batches[i], batches[i + 1], B, points_next2=batches[i + 2])
+            torch.cuda.synchronize()
+            assert torch.equal(bd['point_features'], ref[i]), f"batch {i}"
+
+
 @pytest.mark.parametrize("depth", [3, 4])
 def test_segmented_fps_pipeline_equals_serial(dev, depth):
     """depth >= 3: the level-1 FPS is cut into depth - 1 resumable segments that run for different batches side by side;

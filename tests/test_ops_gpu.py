@@ -537,14 +537,17 @@ def test_group_points_grad_csr_form(oracle, dev, c, n, m, ns):
     np.testing.assert_allclose(gp.cpu().numpy() + 1.0, want, rtol=1e-4, atol=1e-5 * max(scale, 1.0) + 1e-4)
 
 
-def test_shared_search_grid_cache_is_safe(oracle, dev):
-    """One grid per point set serves both MSG radii and the three_nn over it (pointnet2_batch_hip.GRID_CACHE); the
-    cache must miss after an in-place write and for a NEW tensor that reuses the freed address."""
+def test_shared_search_grid_scope_is_safe(oracle, dev):
+    """Inside `with pu.shared_search_grids():` one grid per point set serves both MSG radii and the three_nn over it
+    (pointnet2_batch_hip.GRID_CACHE); outside a scope nothing is kept, so a point set rewritten through a raw pointer
+    (pdm_copy_many, a hipGraph replay — neither bumps the tensor's `_version`) is searched on a grid of its CURRENT
+    coordinates; inside a scope an in-place torch write and a new tensor at a recycled address still miss."""
     from pdm_ssd_amd import _native
     from pdm_ssd_amd.pointnet2_batch import pointnet2_batch_hip as ext
     xyz_np = clouds("lidar", 2, 4096, seed=201)
     xyz = T(xyz_np, dev)
     new_xyz = xyz[:, :512].contiguous()
+    new_np = xyz_np[:, :512].copy()
     builds = []
     orig = _native.call
 
@@ -554,26 +557,39 @@ def test_shared_search_grid_cache_is_safe(oracle, dev):
         return orig(name, *a)
     _native.call = counting
     try:
-        ext.GRID_CACHE.entries.clear()
-        for r, ns in ((0.3, 16), (1.2, 32)):
-            got = pu.ball_query(r, ns, xyz, new_xyz)
-            np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(r, ns, xyz_np, xyz_np[:, :512].copy()))
-        d, i = pu.three_nn(new_xyz, xyz)                      # known set = the same tensor: third user of the grid
-        rd, ri = oracle.three_nn(xyz_np[:, :512].copy(), xyz_np)
-        np.testing.assert_array_equal(i.cpu().numpy(), ri)
-        assert len(builds) == 1
-        xyz.add_(0.25)                                        # in-place write: version changes, the grid is rebuilt
-        moved = xyz_np + np.float32(0.25)
-        got = pu.ball_query(0.3, 16, xyz, new_xyz)
-        np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.3, 16, moved, xyz_np[:, :512].copy()))
-        assert len(builds) == 2
-        ptr = xyz.data_ptr()
-        del xyz, got
-        other_np = clouds("uniform", 2, 4096, seed=202)
-        other = T(other_np, dev)                              # usually lands on the address just freed
-        got = pu.ball_query(0.8, 16, other, new_xyz)
-        np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.8, 16, other_np, xyz_np[:, :512].copy()))
-        assert len(builds) == 3, (ptr, other.data_ptr())
+        assert ext.GRID_CACHE.depth == 0 and not ext.GRID_CACHE.entries
+        with pu.shared_search_grids():
+            for r, ns in ((0.3, 16), (1.2, 32)):
+                got = pu.ball_query(r, ns, xyz, new_xyz)
+                np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(r, ns, xyz_np, new_np))
+            d, i = pu.three_nn(new_xyz, xyz)                  # known set = the same tensor: third user of the grid
+            rd, ri = oracle.three_nn(new_np, xyz_np)
+            np.testing.assert_array_equal(i.cpu().numpy(), ri)
+            assert len(builds) == 1
+            xyz.add_(0.25)                                    # in-place write: version changes, the grid is rebuilt
+            moved = xyz_np + np.float32(0.25)
+            got = pu.ball_query(0.3, 16, xyz, new_xyz)
+            np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.3, 16, moved, new_np))
+            assert len(builds) == 2
+            ptr = xyz.data_ptr()
+            del xyz, got
+            other_np = clouds("uniform", 2, 4096, seed=202)
+            other = T(other_np, dev)                          # usually lands on the address just freed
+            got = pu.ball_query(0.8, 16, other, new_xyz)
+            np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.8, 16, other_np, new_np))
+            assert len(builds) == 3, (ptr, other.data_ptr())
+        assert not ext.GRID_CACHE.entries                     # nothing survives the scope
+        # a static buffer rewritten through a raw pointer between two calls: _version does not move
+        static = T(xyz_np, dev)
+        got = pu.ball_query(0.3, 16, static, new_xyz)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.3, 16, xyz_np, new_np))
+        v = static._version
+        _native.copy_many([static], [T(other_np, dev)])
+        assert static._version == v
+        n0 = len(builds)
+        got = pu.ball_query(0.8, 16, static, new_xyz)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(0.8, 16, other_np, new_np))
+        assert len(builds) == n0 + 1 and not ext.GRID_CACHE.entries
     finally:
         _native.call = orig
 
