@@ -342,3 +342,91 @@ def test_bf16_train_step_matches_fp32_cpu_autograd(train_reference, dev):
     flat_g = torch.cat([grads[k].reshape(-1) for k in want])
     flat_w = torch.cat([want[k].reshape(-1) for k in want])
     assert float((flat_g - flat_w).norm() / flat_w.norm()) <= 0.5
+
+
+# ------------------------------------------------------------------ configs[3]: the FULL detector's training step
+# backbone + PDM neck + hybrid head with the detector's real losses (point focal + smooth-L1 over points_in_boxes
+# targets, heat-map focal: dense_heads/point_head_template.py:82-89,127-183, utils/loss_utils.py:335-345,
+# detectors/point_rcnn.py:13-30 of the reference), against oracle/cpu_detector.py.
+
+@pytest.fixture(scope="module")
+def detector_reference():
+    from detector_case import build_case
+    from oracle import cpu_detector
+    model, clouds, gt = build_case()
+    return {'model': model, 'clouds': clouds, 'gt': gt,
+            'fp32': cpu_detector.detector_train_step(model, clouds, gt, bf16=False),
+            'bf16': cpu_detector.detector_train_step(model, clouds, gt, bf16=True)}
+
+
+def _gpu_detector_step(ref, dev, autocast):
+    from pdm_ssd_amd import detectors
+    model = copy.deepcopy(ref['model']).to(dev).train()
+    batch = {'batch_size': ref['clouds'].shape[0], 'points': T(synthetic.to_batch_points(ref['clouds']), dev),
+             'gt_boxes': T(ref['gt'], dev)}
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        ret = detectors.model_fn_decorator()(model, batch)
+    ret.loss.backward()
+    grads = {k: p.grad.float().cpu() for k, p in model.named_parameters()}
+    fr = model.point_head.forward_ret_dict
+    return float(ret.loss), {k: float(v) for k, v in ret.tb_dict.items()}, grads, fr, model
+
+
+def _dump_grad_table(name, err, extra=None):
+    """per-parameter error table under gpurun_out/ (travels back from the GPU box): what the stated bounds rest on"""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), "w") as f:
+        json.dump({'errors': dict(sorted(err.items(), key=lambda kv: -kv[1])), 'extra': extra}, f, indent=1)
+
+
+def test_fp32_detector_train_step_matches_cpu_graph(detector_reference, dev):
+    """fp32 GPU step of the whole detector (HIP operators and their backward kernels, fused BatchNorm kernels,
+    points_in_boxes targets, MIOpen / rocBLAS layers) against the CPU graph on the oracle operators: loss and every
+    loss term to 1e-4, labels identical, every parameter gradient to 2e-3 relative L2 (fp32 summation order only)."""
+    from detector_case import grad_errors
+    want = detector_reference['fp32']
+    loss, tb, grads, fr, _ = _gpu_detector_step(detector_reference, dev, autocast=False)
+    assert abs(loss - want['loss']) <= 1e-4 * abs(want['loss']), (loss, want['loss'])
+    for k, v in want['tb'].items():
+        assert abs(tb[k] - v) <= 1e-4 * max(abs(v), 1.0), (k, tb[k], v)
+    assert torch.equal(fr['point_cls_labels'].cpu(), want['point_cls_labels'])
+    np.testing.assert_allclose(fr['point_cls_preds'].detach().float().cpu().numpy(), want['point_cls_preds'].numpy(), rtol=1e-3, atol=1e-3)
+    assert set(grads) == set(want['grads'])
+    err = grad_errors(grads, want['grads'])
+    _dump_grad_table("detector_step_fp32_grad_errors.json", err)
+    worst = max(err, key=err.get)
+    assert err[worst] <= 2e-3, (worst, err[worst])
+
+
+# Stated bf16 tolerance of the detector step against the bf16-EMULATING CPU graph (measured values in
+# profiles/r03_detector_step_bf16_grad_errors.json): see the asserts.
+BF16_LOSS_TOL = 5e-3
+BF16_GRAD_TOL = 5e-2
+
+
+def test_bf16_detector_train_step_matches_bf16_emulating_cpu_graph(detector_reference, dev):
+    """BASELINE configs[3]: the bf16-autocast training step of the whole detector against a CPU graph that rounds to
+    bf16 at the same points, forward and backward (oracle/cpu_detector.py), so the comparison is bf16 against bf16.
+    Against the fp32 graph the same gradients sit at 0.2-0.9 relative L2 (also recorded in the table), which is why the
+    round-2 test needed a 0.5 whole-vector bound."""
+    from detector_case import grad_errors
+    want, want32 = detector_reference['bf16'], detector_reference['fp32']
+    loss, tb, grads, fr, model = _gpu_detector_step(detector_reference, dev, autocast=True)
+    assert fr['point_cls_preds'].dtype == torch.bfloat16          # the layers really ran under autocast
+    assert torch.equal(fr['point_cls_labels'].cpu(), want['point_cls_labels'])
+    for k, g in grads.items():
+        assert torch.isfinite(g).all(), k
+    err = grad_errors(grads, want['grads'])
+    err32 = grad_errors(grads, want32['grads'])
+    emu_vs_32 = grad_errors(want['grads'], want32['grads'])
+    _dump_grad_table("detector_step_bf16_grad_errors.json", err,
+                     {'loss_gpu': loss, 'loss_emulated': want['loss'], 'loss_fp32': want32['loss'], 'tb_gpu': tb, 'tb_emulated': want['tb'],
+                      'gpu_vs_fp32_graph': err32, 'emulation_vs_fp32_graph': emu_vs_32,
+                      'median_gpu_vs_emulation': float(np.median(list(err.values()))),
+                      'median_gpu_vs_fp32': float(np.median(list(err32.values())))})
+    assert abs(loss - want['loss']) <= BF16_LOSS_TOL * abs(want['loss']), (loss, want['loss'], want32['loss'])
+    worst = max(err, key=err.get)
+    assert err[worst] <= BF16_GRAD_TOL, (worst, err[worst], float(np.median(list(err.values()))))

@@ -96,3 +96,61 @@ def test_neck_gradient_matches_central_differences(oracle):
             fd = (up - dn) / (2 * h)
             an = float(p.grad.view(-1)[j])
             assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 1e-3 * float(loss.detach().abs()) * 1e-2, (name, j, fd, an)
+
+
+def test_detector_step_emulating_graph_equals_torch_layers_when_unrounded():
+    """oracle/cpu_detector.py holds two statements of the full-detector training step: the model's own torch layers
+    (fp32) and a hand-written graph (matmul / BatchNorm + ReLU / BatchNorm + ReLU + max-pool with the arithmetic of the
+    GPU kernels) that rounds to bf16 where the GPU path holds bf16.  With the roundings switched off the second must
+    reproduce the first: loss, every loss term and every parameter gradient, to fp32 summation order.  With them on it
+    must stay a bf16-sized distance away (and not be the same computation)."""
+    from detector_case import build_case, grad_errors
+    from oracle import cpu_detector
+    model, cl, gt = build_case()
+    ref = cpu_detector.detector_train_step(model, cl, gt, bf16=False)
+    unr = cpu_detector.detector_train_step(model, cl, gt, bf16='unrounded')
+    emu = cpu_detector.detector_train_step(model, cl, gt, bf16=True)
+    assert ref['tb']['point_pos_num'] > 50 and set(ref['tb']) == {'point_loss_cls', 'point_loss_box', 'point_pos_num', 'hm_loss'}
+    assert set(ref['grads']) == set(dict(model.named_parameters())) == set(unr['grads']) == set(emu['grads'])
+    assert abs(unr['loss'] - ref['loss']) <= 1e-5 * abs(ref['loss'])
+    for k in ref['tb']:
+        assert abs(unr['tb'][k] - ref['tb'][k]) <= 1e-5 * max(abs(ref['tb'][k]), 1.0), k
+    assert torch.equal(unr['point_cls_labels'], ref['point_cls_labels'])
+    err = grad_errors(unr['grads'], ref['grads'])
+    worst = max(err, key=err.get)
+    assert err[worst] <= 2e-3, (worst, err[worst])
+    # rounded: bf16-sized, not fp32-sized
+    assert 1e-4 * abs(ref['loss']) < abs(emu['loss'] - ref['loss']) <= 2e-2 * abs(ref['loss'])
+    e2 = grad_errors(emu['grads'], ref['grads'])
+    assert float(np.median(list(e2.values()))) > 1e-2
+    for g in emu['grads'].values():
+        assert torch.isfinite(g).all()
+
+
+def test_bf16_emulation_primitives():
+    """The emulating graph's building blocks against direct statements: rounding is round-to-nearest-even to 8
+    significant bits; the matmul rounds operands and result but accumulates in fp32; the pooled BatchNorm picks the
+    first neighbour attaining the max of x (min under a negative scale) and routes the gradient to it alone."""
+    from oracle import cpu_detector as cd
+    x = torch.tensor([1.0, 1.00390625, 1.005859375, 1.01171875, 3.0e38, -2.5])
+    assert cd.bf16r(x).tolist() == [1.0, 1.0, 1.0078125, 1.015625, float(torch.tensor(3.0e38).bfloat16()), -2.5]
+    a = torch.tensor([[1.00390625, 256.0]])       # rounds to [1.0, 256.0]
+    w = torch.tensor([[1.0, 2.0 ** -9]])          # 1 + 0.5: fp32 accumulation keeps it, the result rounds to 1.5
+    assert float(cd._MatmulBf16.apply(a, w, None)) == 1.5
+    xg = torch.tensor([[[0.5, 2.0], [3.0, -1.0], [3.0, -1.0], [1.0, 0.0]]], requires_grad=True)   # (G=1, ns=4, C=2)
+    gamma = torch.tensor([1.0, -1.0], requires_grad=True)
+    beta = torch.tensor([0.25, 0.5], requires_grad=True)
+    y = cd._BnReluPool.apply(xg, gamma, beta, 1e-5, False)
+    mean = xg.detach().mean(1)[0]
+    invstd = 1.0 / torch.sqrt(xg.detach().var(1, unbiased=False)[0] + 1e-5)
+    want = torch.clamp((torch.tensor([3.0, -1.0]) - mean) * torch.tensor([1.0, -1.0]) * invstd + torch.tensor([0.25, 0.5]), min=0)
+    torch.testing.assert_close(y[0], want)
+    y.sum().backward()
+    ref_x = xg.detach().clone().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(2).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.tensor([1.0, -1.0])); bn.bias.copy_(torch.tensor([0.25, 0.5]))
+    torch.relu(bn(ref_x[0])).max(0)[0].sum().backward()       # torch: ties also go to the first index
+    torch.testing.assert_close(xg.grad, ref_x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gamma.grad, bn.weight.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(beta.grad, bn.bias.grad, rtol=1e-4, atol=1e-5)
