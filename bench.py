@@ -215,7 +215,8 @@ def reference_op_section(backbone, points, B, iters=5):
             build_ms = sum(x["ms_per_step"] for x in ops if x["op"] == "pdm_grid_build") if "grid" in o["op"] else 0.0
             rate = evals[o["op"]] / ((o["ms_per_step"] + build_ms) * 1e-3)
             bq[o["op"]] = {"reference_form_evals_per_step": evals[o["op"]], "Gevals_per_s": round(rate / 1e9, 1),
-                           "frac_of_valu_peak_at_8_flop_per_eval": round(rate * 8 / 1e12 / VALU_F32_PEAK_TFLOPS, 4),
+                           # a fraction of the vector peak only where every evaluation is executed; the grid form skips most
+                           "frac_of_valu_peak_at_8_flop_per_eval": None if "grid" in o["op"] else round(rate * 8 / 1e12 / VALU_F32_PEAK_TFLOPS, 4),
                            "kind": "effective (grid-pruned incl. its share of pdm_grid_build, same indices)" if "grid" in o["op"] else "executed (exhaustive scan)"}
     return {"ops": ops, "ms_per_step": round(ms, 4), "alg_MB_per_step": round(mb, 2),
             "GBps": round(mb / ms, 1), "frac_of_hbm_peak": round(mb / ms / HBM_PEAK_GBS, 4),
@@ -270,12 +271,14 @@ def synthetic_gt_boxes(B, M, seed, device):
     return torch.from_numpy(gt).to(device)
 
 
-def train_bench(args, model, points, B, N, rank, world, local_rank, device):
+def train_bench(args, model, points, B, N, rank, world, local_rank, device, steps=None, warmup=None, scaling="weak"):
     """Training step (BASELINE configs[3]): the detector in train mode — autograd graph over the HIP operators (fused
     QueryAndGroup forward, inverted-index backward kernels, PDM scatter + its gather-form backward), torch modules
     for the MLPs under bf16 autocast, coordinates and indices in fp32, the hybrid head's losses (point focal +
     smooth-L1 over points_in_boxes targets, heat-map focal) — AdamW, one gradient all-reduce per step (DDP, single
     bucket) when world > 1."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-3)
@@ -332,7 +335,7 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device):
             state["sampled"] = nxt
         return loss
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         step()
     dist_utils.barrier()
     if args.train_profile:
@@ -348,23 +351,20 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device):
                 f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=110))
         return
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     dist_utils.barrier()
     elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
-    if rank == 0:
-        print(json.dumps({
-            "metric": f"train frames/sec ({N}-pt clouds, bs={B}/GPU, bf16 autocast)", "value": round(world * B * args.steps / elapsed, 2),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
-            "config": {"workload": f"configs[3]: PDM-SSD train step (PointNet2MSG + PDM neck + hybrid head losses), bs={B}/GPU x {N} "
-                                   "pts, 12 synthetic boxes per cloud, AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
-                       "overlap": "none" if args.serial else "FPS chain of the next batch on a side stream"},
-            "final_loss": float(loss.detach())}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return {
+        "metric": f"train frames/sec ({N}-pt clouds, bs={B}/GPU, bf16 autocast)", "value": round(world * B * steps / elapsed, 2),
+        "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
+        "config": {"workload": f"configs[3]: PDM-SSD train step (PointNet2MSG + PDM neck + hybrid head losses), bs={B}/GPU x {N} "
+                               "pts, 12 synthetic boxes per cloud, AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
+                   "global_batch": world * B,
+                   "overlap": "none" if args.serial else "FPS chain of the next batch on a side stream"},
+        "final_loss": float(loss.detach())}
 
 
 # ----------------------------------------------------------------------------- launcher
@@ -590,6 +590,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling (SURVEY D2): a fixed global batch sharded over the ranks, G / N whole clouds per GPU "
+                         "(the reference's DistributedSampler over a fixed dataset, pcdet/datasets/__init__.py:69-74); "
+                         "0 = weak scaling with --batch clouds on every GPU")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--clouds", choices=["uniform", "lidar"], default="uniform")
     ap.add_argument("--pipeline-depth", type=int, default=4, choices=[1, 2, 3, 4, 5],
@@ -633,10 +637,21 @@ def main():
     _native.lib()  # fail loudly now if the HIP library is missing
 
     B, N = args.batch, args.points
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            sys.exit(f"[bench] --global-batch {args.global_batch} does not divide over {world} ranks (whole clouds per rank)")
+        B, scaling = args.global_batch // world, "strong"
     model = build_detector(device)
     if args.train:
         _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
-        return train_bench(args, model, points, B, N, rank, world, local_rank, device)
+        line = train_bench(args, model, points, B, N, rank, world, local_rank, device, scaling=scaling)
+        if rank == 0 and line is not None:
+            print(json.dumps(line))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     backbone, neck = model.backbone_3d, model.map_to_bev_module
 
     bench = Bench(model, B, N, args.clouds, args.pipeline_depth, device, seed0=1234 + rank * B, serial=args.serial,
@@ -715,11 +730,23 @@ def main():
     except Exception:
         pass
 
-    def pmc_traffic(*prefixes):
-        rows = [v for k, v in pmc.items() if k.startswith(prefixes) and v["launches"] > 0]
+    def pmc_rows(name):
+        """PMC rows of one kernel: a full instantiation ('pdm::rows_chain_kernel<8, 16, 16, 1, false>') matches only itself,
+        a bare template / function name matches every instantiation of THAT name (not names it is a prefix of)."""
+        return [v for k, v in pmc.items() if v["launches"] > 0 and (k == name or ("<" not in name and k.split("<")[0] == name))]
+
+    def pmc_traffic(alternatives, together=()):
+        """HBM bytes per CALL of an entry point.  `alternatives`: kernels of which each call launches ONE (the mean over
+        their launches); `together`: kernels every call launches in addition (each one's per-launch mean is added)."""
+        rows = [v for name in alternatives for v in pmc_rows(name)]
         if not rows:
             return None
-        return int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
+        total = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows)
+        for name in together:
+            extra = pmc_rows(name)
+            if extra:
+                total += sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in extra) / sum(v["launches"] for v in extra)
+        return int(total)
 
     # FLOPs: `executed` = what each entry point actually contracts (2 * real cin * cout per position and layer).
     sa_gf, fp_gf = model_flops(backbone, B, N)
@@ -753,7 +780,10 @@ def main():
             layers = int(op.split("[")[1].split(" ")[0])
             rows = int(op.split(" in, ")[1].split(" ")[0])
             if layers == 3 and rows >= 8192:
-                return ("pdm::rows_chain_kernel",)
+                # the chain's instantiation carries the widths / 16: only the ones with this input width, no depthwise prologue
+                cin = int(op.split(" layers, ")[1].split(" ")[0])
+                inst = tuple(k for k in pmc if k.startswith(f"pdm::rows_chain_kernel<{cin // 16}, ") and k.endswith(", false>"))
+                return inst or ("pdm::rows_chain_kernel",)
             return ("pdm::rows_gemm_kernel<false>",) if layers == 1 and rows >= 16384 else ("pdm::fp_mlp_fused_kernel",)
         return KERNELS_OF.get(base, ())
 
@@ -765,7 +795,7 @@ def main():
         kernels = kernels_of(o["op"])
         return {"bound": "mfma", "kernel": " + ".join(kernels) + f" (all launches of {o['op']})",
                 "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(*kernels) if kernels else None,
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kernels) if kernels else None,
                 "traffic_unit": "HBM bytes per launch (PMC)", "launches_per_step": calls,
                 "avg_launch_us": round(per_launch_s * 1e6, 2), "alg_flop_per_launch": int(per_launch_flop),
                 "ms_per_step": o["ms_per_step"], "flops_counted": "executed (hoisted first layer), unpadded"}
@@ -785,7 +815,7 @@ def main():
                 "pdm_furthest_point_sampling: the four levels' chains, whole calls; the pipelined step runs level 1 as "
                 "resumable jobs of the same kernel)",
                 "achieved": round(ach, 3), "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / VALU_F32_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic("pdm::fps_pruned_kernel", "pdm::fps_reg_kernel"), "traffic_unit": "HBM bytes per launch (PMC)",
+                "traffic": pmc_traffic(("pdm::fps_pruned_kernel", "pdm::fps_reg_kernel")), "traffic_unit": "HBM bytes per launch (PMC)",
                 "launches_per_step": fo[0]["calls_per_step"], "avg_launch_us": round(ms * 1e3 / fo[0]["calls_per_step"], 2),
                 "alg_flop_per_launch": int(flop / fo[0]["calls_per_step"]), "ms_per_step": ms,
                 "serial_iterations_per_step": iters, "us_per_iteration": round(ms * 1e3 / iters, 3),
@@ -813,7 +843,7 @@ def main():
         ach = flop / (mine["ms_per_step"] * 1e-3) / 1e12
         roofline = {"bound": "valu/latency", "kernel": f"pdm::fps_pruned_kernel (all launches of {top['op']})", "achieved": round(ach, 3),
                     "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / VALU_F32_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic("pdm::fps_pruned_kernel"), "launches_per_step": mine["calls_per_step"],
+                    "traffic": pmc_traffic(("pdm::fps_pruned_kernel",)), "launches_per_step": mine["calls_per_step"],
                     "avg_launch_us": round(mine["ms_per_step"] * 1e3 / mine["calls_per_step"], 2),
                     "alg_flop_per_launch": int(flop / mine["calls_per_step"]), "ms_per_step": mine["ms_per_step"],
                     "measured": "in situ: HIP events on the launch stream inside the pipelined step"}
@@ -830,7 +860,7 @@ def main():
                     "pdm_group_points, the API-exact operator)",
                     "achieved": round(gp_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gp_gbs / HBM_PEAK_GBS, 4),
                     "frac_of_measured_copy": round(gp_gbs / copy_gbs, 4),
-                    "traffic": pmc_traffic("pdm::group_points_v4_kernel", "pdm::group_points_lds_kernel"),
+                    "traffic": pmc_traffic(("pdm::group_points_v4_kernel", "pdm::group_points_lds_kernel", "pdm::group_points_rows_kernel")),
                     "launches_per_step": gp["calls_per_step"], "avg_launch_us": round(gp_launch_s * 1e6, 2),
                     "alg_bytes_per_launch": int(gp_launch_bytes)}
     pg = [o for o in ops if o["op"] == "pdm_gather_bev"]
@@ -841,7 +871,8 @@ def main():
         roofline_pdm = {"bound": "hbm", "kernel": "pdm::pdm_bin_kernel + pdm::pdm_gather_reg_kernel (pdm_gather_bev, the inference "
                         "form of the PDM scatter; atomics form under pdm_neck_forms)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_gbs, 4),
-                        "traffic": pmc_traffic("pdm::pdm_gather_reg_kernel", "pdm::pdm_bin_kernel"),
+                        "traffic": pmc_traffic(("pdm::pdm_gather_reg_kernel",), together=("pdm::pdm_bin_kernel",)),
+                        "traffic_unit": "HBM bytes per call (PMC): bin kernel + gather kernel",
                         "launches_per_step": o["calls_per_step"], "avg_launch_us": round(o["ms_per_step"] * 1e3 / o["calls_per_step"], 2),
                         "alg_bytes_per_launch": int(o["alg_MB_per_step"] * 1e6 / o["calls_per_step"])}
     refops["frac_of_measured_copy"] = round(refops["GBps"] / copy_gbs, 4)
@@ -879,16 +910,41 @@ def main():
                     "pdm_neck_forms": pdm_atomics_section(model, bd5)}
                 del b5, bd5
                 torch.cuda.empty_cache()
+            if (B, N) == (32, 16384):
+                # configs[1]'s shape (bs = 8 x 16384 points) through the same full forward: the step is bound by the FPS
+                # chain's latency there, not by throughput
+                b8 = Bench(model, 8, N, args.clouds, args.pipeline_depth, device, seed0=2468, graph=not args.no_graph,
+                           autotune=not args.no_autotune)
+                n = max(10, args.steps)
+                t = b8.timed(n, 3)
+                extras["bs8"] = {"workload": f"configs[1] shape: bs=8 x {N} pts, {args.clouds} clouds, same full forward, depth "
+                                             f"{b8.depth}", "ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(8 * n / t, 1),
+                                 "launch": b8.mode}
+                del b8
+                torch.cuda.empty_cache()
+        if world == 1 and (B, N) == (32, 16384):
+            # configs[3] on this GPU: the bf16-autocast training step of the whole detector (real losses, AdamW), 5 steps
+            # after 3 warm-up steps, on a fresh copy of the model (the timed inference model stays in eval mode)
+            import copy
+            tm = copy.deepcopy(model)
+            try:
+                tl = train_bench(args, tm, points, B, N, rank, world, local_rank, device, steps=5, warmup=3)
+                extras["train_step_bf16"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "final_loss")}
+                extras["train_step_bf16"]["workload"] = tl["config"]["workload"]
+            except Exception as e:   # the inference line must not be lost to a training-side failure: say so instead
+                extras["train_step_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+            del tm
+            torch.cuda.empty_cache()
 
     # rebuilt if deleted above: only its attributes are needed for the line
     line = {
         "metric": f"frames/sec ({N}-pt clouds, bs={B})", "value": round(frames_per_s, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[2]: full PDM-SSD forward (PointNet2MSG backbone + PDM neck + hybrid head: BEV heat-map "
                                f"head + point box head with decoded boxes), bs={B}/GPU x {N} pts, {args.clouds} KITTI-range clouds, "
                                f"fp32 inference, inputs resident in HBM, {Bench.NBATCH} distinct batches in rotation",
-                   "launch": LAUNCH_MODE[0], "parallelism": f"dp{world}",
+                   "launch": LAUNCH_MODE[0], "parallelism": f"dp{world}", "global_batch": world * B,
                    "overlap": "none" if args.serial else
                               ("FPS chain of batch i+1 on a side stream under the feature half of batch i "
                                "(pdm_ssd_amd/pipeline.py)" if args.pipeline_depth == 1 else

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "pdm_tune_fused_lds_cap": None,
     "pdm_tune_fused_reg": None,
     "pdm_tune_bq_quad": None,
+    "pdm_tune_group_rows": None,
     "pdm_tune_fused_gemm": None,
     "pdm_tune_fused_chain": None,
     "pdm_tune_fp_chain_pad_lds": None,

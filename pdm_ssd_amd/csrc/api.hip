@@ -65,9 +65,17 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
         const unsigned long long n16 = n >> 4;
-        for (unsigned long long i = tid; i < n16; i += stride)
-            reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(s)[i];
-        for (unsigned long long i = (n16 << 4) + tid; i < n; i += stride) d[i] = s[i];
+        const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(s);
+        uint4 *__restrict__ d4 = reinterpret_cast<uint4 *>(d);
+        // four 16-byte loads in flight per lane before the first store (one load per iteration left the memory system
+        // a quarter of the requests it needs: 4.7 TB/s on a 1 GiB copy, round 2)
+        unsigned long long i = tid;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const uint4 a = s4[i], b = s4[i + stride], c = s4[i + 2 * stride], e = s4[i + 3 * stride];
+            d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c; d4[i + 3 * stride] = e;
+        }
+        for (; i < n16; i += stride) d4[i] = s4[i];
+        for (unsigned long long j = (n16 << 4) + tid; j < n; j += stride) d[j] = s[j];
     } else {
         for (unsigned long long i = tid; i < n; i += stride) d[i] = s[i];
     }
@@ -110,8 +118,9 @@ static int copy_many_impl(void *stream, int count, void *const *dst, const void 
             ++n;
         }
         if (n == 0) continue;
-        const unsigned long long want = (largest / 16 + 255) / 256;
-        const unsigned gx = (unsigned)(want < 1 ? 1 : want > 512 ? 512 : want);
+        // a lane moves four 16-byte pieces per pass; up to 8 workgroups per CU
+        const unsigned long long want = (largest / 64 + 255) / 256;
+        const unsigned gx = (unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want);
         hipLaunchKernelGGL(copy_many_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), t);
         const int rc = check_launch("copy_many");
         if (rc) return rc;

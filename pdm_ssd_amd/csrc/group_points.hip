@@ -183,6 +183,83 @@ __global__ __launch_bounds__(GPL_THREADS) void group_points_grad_lds_kernel(
     for (long long i = threadIdx.x; i < tot; i += GPL_THREADS) dst[i] += rows[i];  // caller-zeroed, accumulated
 }
 
+// Round 3 form of the LDS-staged gather.  What round 2's kernel lost (4.2-4.5 TB/s on every large launch) was not
+// bandwidth per workgroup but GRANULARITY: one workgroup = (sample, row group) streaming the whole L axis, 1536 such
+// units over 1280 resident slots is one full round plus a round that fills a fifth of the chip.  Here
+//   * the grid is one-dimensional and a unit is (sample, row group, part of L): `lsplit` parts re-stage the same rows
+//     (from L2: the sibling parts run on the same XCD) and make the units short enough for the last round to matter less;
+//   * blockIdx -> unit is XCD-aware (workgroups w and w + 8 share an XCD's L2): XCD x works through samples x, x + 8, ...
+//     so a sample's index list and rows are fetched into ONE L2;
+//   * a lane holds UQ index quads per pass: UQ x 16 bytes of index loads in flight, then per row UQ x 4 LDS reads and
+//     UQ 16-byte stores (a wave instruction stores 1 KB contiguous);
+//   * the first pass's indices are requested BEFORE the rows are staged, so the two latencies overlap.
+// Same values as every other form (pure data movement).
+constexpr int GPR_UQ = 4;
+template <int T>
+__global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long long L, int rpw, int nrg, int lsplit, int B,
+                                                              const float *__restrict__ points, const int *__restrict__ idx,
+                                                              float *__restrict__ out) {
+    extern __shared__ float rows[];  // rpw x n
+    const int per_b = nrg * lsplit;
+    int b, rem;
+    if ((B & 7) == 0) {
+        const int x = blockIdx.x & 7, t = blockIdx.x >> 3;
+        b = (t / per_b) * 8 + x;
+        rem = t % per_b;
+    } else {
+        b = blockIdx.x / per_b;
+        rem = blockIdx.x % per_b;
+    }
+    const int rg = rem / lsplit, lp = rem % lsplit;
+    const int c0 = rg * rpw;
+    const int nr = min(rpw, c - c0);
+    const long long nq = L >> 2;
+    const long long qper = (nq + lsplit - 1) / lsplit;
+    const long long q_begin = (long long)lp * qper;
+    const long long q_end = min(nq, q_begin + qper);
+    const int4 *__restrict__ ib = reinterpret_cast<const int4 *>(idx + (size_t)b * L);
+    int4 id[GPR_UQ];
+    long long q0 = q_begin + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < GPR_UQ; ++u) {
+        const long long q = q0 + (long long)u * T;
+        id[u] = q < q_end ? ib[q] : make_int4(0, 0, 0, 0);
+    }
+    const float *__restrict__ src = points + ((size_t)b * c + c0) * n;
+    const long long tot = (long long)nr * n;
+    if ((tot & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        for (long long i = (long long)threadIdx.x * 4; i < tot; i += T * 4)
+            *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+    } else {
+        for (long long i = threadIdx.x; i < tot; i += T) rows[i] = src[i];
+    }
+    __syncthreads();
+    float4 *__restrict__ ob = reinterpret_cast<float4 *>(out + ((size_t)b * c + c0) * L);
+    while (q0 < q_end) {
+        for (int r = 0; r < nr; ++r) {
+            const float *row = rows + (size_t)r * n;
+#pragma unroll
+            for (int u = 0; u < GPR_UQ; ++u) {
+                const long long q = q0 + (long long)u * T;
+                if (q < q_end) {
+                    float4 v;
+                    v.x = row[id[u].x]; v.y = row[id[u].y]; v.z = row[id[u].z]; v.w = row[id[u].w];
+                    ob[(size_t)r * nq + q] = v;
+                }
+            }
+        }
+        q0 += (long long)GPR_UQ * T;
+#pragma unroll
+        for (int u = 0; u < GPR_UQ; ++u) {
+            const long long q = q0 + (long long)u * T;
+            if (q < q_end) id[u] = ib[q];
+        }
+    }
+}
+
+// tuning knob (tools/diag/group_sweep.py): 0 = heuristics; else variant | rpw << 4 | lsplit << 8 | (threads / 256) << 16
+static int g_gp_tune = 0;
+
 // rows of n floats per workgroup: up to `budget` bytes of LDS (several workgroups per CU overlap one's staging
 // with another's streaming), at most 8 (index registers reused across them); 0 = a row does not fit 64 KB
 static inline int lds_rows_per_wg(int n, int c, size_t budget) {
@@ -198,6 +275,8 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 using namespace pdm;
 
+extern "C" int pdm_tune_group_rows(int packed) { const int old = g_gp_tune; g_gp_tune = packed; return old; }
+
 extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, int nsample,
                                 const float *points, const int *idx, float *out) {
     PDM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, PDM_E_BADARG,
@@ -206,8 +285,38 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
     if (b == 0 || c == 0 || L == 0) return 0;
     PDM_REQUIRE(points && idx && out, PDM_E_BADARG, "group_points: null pointer");
     PDM_REQUIRE(b <= 65535 && divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_points: b=%d c=%d exceed grid", b, c);
-    const int rpw = lds_rows_per_wg(n, c, 32 * 1024);
+    int rpw = lds_rows_per_wg(n, c, 32 * 1024);
+    const int variant = g_gp_tune ? (g_gp_tune & 15) : 1;
     // LDS staging pays when a row is re-used by many outputs and there are enough (b, c) rows to fill the chip
+    if (variant == 1 && rpw > 0 && L >= 4 * n && L % 4 == 0 && aligned16(idx) && aligned16(out) && aligned16(points)
+        && (long long)b * divup(c, rpw) >= 512) {
+        int lsplit = 0, threads = 256;
+        if (g_gp_tune) {
+            const int r = (g_gp_tune >> 4) & 15, ls = (g_gp_tune >> 8) & 255, th = (g_gp_tune >> 16) & 7;
+            if (r > 0 && (size_t)r * n * sizeof(float) <= 64 * 1024) rpw = r > c ? c : r;
+            lsplit = ls;
+            if (th == 1 || th == 2 || th == 4) threads = 256 * th;
+        }
+        const int nrg = divup(c, rpw);
+        const long long nq = L / 4;
+        if (lsplit <= 0) {
+            // units per resident slot >= ~4 where the L axis allows it (a part keeps >= 2 passes of a workgroup)
+            const long long slots = 256ll * (160 * 1024 / ((size_t)rpw * n * sizeof(float) > 16 * 1024 ? (size_t)rpw * n * sizeof(float) : 16 * 1024));
+            lsplit = 1;
+            while ((long long)b * nrg * lsplit < 4 * slots && nq / (lsplit * 2) >= 2ll * threads * GPR_UQ) lsplit *= 2;
+        }
+        if ((long long)lsplit > nq) lsplit = (int)nq;
+        const long long wgs = (long long)b * nrg * lsplit;
+        PDM_REQUIRE(wgs <= 0x7fffffffll, PDM_E_TOOLARGE, "group_points: %lld workgroups", wgs);
+        const size_t lds = (size_t)rpw * n * sizeof(float);
+        if (threads == 256)
+            hipLaunchKernelGGL(group_points_rows_kernel<256>, dim3((unsigned)wgs), dim3(256), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out);
+        else if (threads == 512)
+            hipLaunchKernelGGL(group_points_rows_kernel<512>, dim3((unsigned)wgs), dim3(512), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out);
+        else
+            hipLaunchKernelGGL(group_points_rows_kernel<1024>, dim3((unsigned)wgs), dim3(1024), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out);
+        return check_launch("group_points");
+    }
     if (rpw > 0 && L >= 4 * n && (long long)b * divup(c, rpw) >= 512) {
         dim3 grid(divup(c, rpw), b);
         hipLaunchKernelGGL(group_points_lds_kernel, grid, dim3(GPL_THREADS), (size_t)rpw * n * sizeof(float),
