@@ -330,6 +330,7 @@ def _step(model, clouds, gt_boxes, bf16, B):
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     return {'loss': float(loss.detach()), 'tb': {k: float(v) for k, v in tb.items()}, 'grads': grads,
             'point_features': out['point_features'].detach(), 'spatial_features': out['spatial_features'].detach(),
+            'sa_features': [None if t is None else t.detach() for t in out['sa_features']],
             'point_cls_preds': ph.forward_ret_dict['point_cls_preds'].detach(),
             'point_box_preds': ph.forward_ret_dict['point_box_preds'].detach(),
             'hm_logits': dh.forward_ret_dict['hm_logits'].detach(),

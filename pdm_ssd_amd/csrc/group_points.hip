@@ -194,15 +194,14 @@ __global__ __launch_bounds__(GPL_THREADS) void group_points_grad_lds_kernel(
 //     UQ 16-byte stores (a wave instruction stores 1 KB contiguous);
 //   * the first pass's indices are requested BEFORE the rows are staged, so the two latencies overlap.
 // Same values as every other form (pure data movement).
-constexpr int GPR_UQ = 4;
-template <int T>
+template <int T, int GPR_UQ, bool XCD>
 __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long long L, int rpw, int nrg, int lsplit, int B,
                                                               const float *__restrict__ points, const int *__restrict__ idx,
                                                               float *__restrict__ out) {
     extern __shared__ float rows[];  // rpw x n
     const int per_b = nrg * lsplit;
     int b, rem;
-    if ((B & 7) == 0) {
+    if (XCD && (B & 7) == 0) {
         const int x = blockIdx.x & 7, t = blockIdx.x >> 3;
         b = (t / per_b) * 8 + x;
         rem = t % per_b;
@@ -257,7 +256,8 @@ __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long
     }
 }
 
-// tuning knob (tools/diag/group_sweep.py): 0 = heuristics; else variant | rpw << 4 | lsplit << 8 | (threads / 256) << 16
+// tuning knob (tools/diag/group_sweep.py): 0 = heuristics; else variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel without
+// the XCD unit order) | rpw << 4 | lsplit << 8 | (threads / 256) << 16 | quads per lane and pass << 20
 static int g_gp_tune = 0;
 
 // rows of n floats per workgroup: up to `budget` bytes of LDS (several workgroups per CU overlap one's staging
@@ -286,37 +286,51 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
     PDM_REQUIRE(points && idx && out, PDM_E_BADARG, "group_points: null pointer");
     PDM_REQUIRE(b <= 65535 && divup(c, GP_CG) <= 65535, PDM_E_TOOLARGE, "group_points: b=%d c=%d exceed grid", b, c);
     int rpw = lds_rows_per_wg(n, c, 32 * 1024);
-    const int variant = g_gp_tune ? (g_gp_tune & 15) : 1;
-    // LDS staging pays when a row is re-used by many outputs and there are enough (b, c) rows to fill the chip
-    if (variant == 1 && rpw > 0 && L >= 4 * n && L % 4 == 0 && aligned16(idx) && aligned16(out) && aligned16(points)
+    // LDS staging pays when a row is re-used by many outputs and there are enough (b, c) rows to fill the chip.
+    // Which form / decomposition: profiles/r03_group_points_sweep.txt (tools/diag/group_sweep.py, bs = 32).  The rows
+    // kernel wins where a unit of round 2's kernel was long (rows of 16 KB: N = 4096) or very short (N = 256); for 4 KB
+    // rows with L = 8192 round 2's kernel stays ahead (6.2 TB/s) and is kept.
+    int variant = 1, lsplit = 1, threads = 256, uq = 4;
+    const size_t row_bytes = (size_t)n * sizeof(float);
+    if (row_bytes > 8 * 1024) {            // long rows: few rows fit, units are long -> big workgroups, L in two parts
+        if (L >= 32768) { threads = 1024; rpw = (int)(64 * 1024 / row_bytes); lsplit = 2; }
+        else { threads = 512; rpw = (int)(48 * 1024 / row_bytes); }
+    } else if (row_bytes > 2 * 1024) {
+        if (L >= 8192) variant = 2;
+        else threads = 512;
+    }
+    rpw = rpw < 1 ? 1 : rpw > 8 ? 8 : rpw > c ? c : rpw;
+    if (g_gp_tune) {
+        variant = g_gp_tune & 15;
+        const int r = (g_gp_tune >> 4) & 15, ls = (g_gp_tune >> 8) & 255, th = (g_gp_tune >> 16) & 7, u = (g_gp_tune >> 20) & 7;
+        rpw = lds_rows_per_wg(n, c, 32 * 1024);
+        if (r > 0 && (size_t)r * row_bytes <= 64 * 1024) rpw = r > c ? c : r;
+        lsplit = ls > 0 ? ls : 1;
+        threads = (th == 2 || th == 4) ? 256 * th : 256;
+        uq = (u == 1 || u == 2) ? u : 4;
+    }
+    if ((variant == 1 || variant == 3) && rpw > 0 && L >= 4 * n && L % 4 == 0 && aligned16(idx) && aligned16(out) && aligned16(points)
         && (long long)b * divup(c, rpw) >= 512) {
-        int lsplit = 0, threads = 256;
-        if (g_gp_tune) {
-            const int r = (g_gp_tune >> 4) & 15, ls = (g_gp_tune >> 8) & 255, th = (g_gp_tune >> 16) & 7;
-            if (r > 0 && (size_t)r * n * sizeof(float) <= 64 * 1024) rpw = r > c ? c : r;
-            lsplit = ls;
-            if (th == 1 || th == 2 || th == 4) threads = 256 * th;
-        }
         const int nrg = divup(c, rpw);
         const long long nq = L / 4;
-        if (lsplit <= 0) {
-            // units per resident slot >= ~4 where the L axis allows it (a part keeps >= 2 passes of a workgroup)
-            const long long slots = 256ll * (160 * 1024 / ((size_t)rpw * n * sizeof(float) > 16 * 1024 ? (size_t)rpw * n * sizeof(float) : 16 * 1024));
-            lsplit = 1;
-            while ((long long)b * nrg * lsplit < 4 * slots && nq / (lsplit * 2) >= 2ll * threads * GPR_UQ) lsplit *= 2;
-        }
         if ((long long)lsplit > nq) lsplit = (int)nq;
         const long long wgs = (long long)b * nrg * lsplit;
         PDM_REQUIRE(wgs <= 0x7fffffffll, PDM_E_TOOLARGE, "group_points: %lld workgroups", wgs);
-        const size_t lds = (size_t)rpw * n * sizeof(float);
-        if (threads == 256)
-            hipLaunchKernelGGL(group_points_rows_kernel<256>, dim3((unsigned)wgs), dim3(256), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out);
-        else if (threads == 512)
-            hipLaunchKernelGGL(group_points_rows_kernel<512>, dim3((unsigned)wgs), dim3(512), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out);
-        else
-            hipLaunchKernelGGL(group_points_rows_kernel<1024>, dim3((unsigned)wgs), dim3(1024), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out);
+        const size_t lds = (size_t)rpw * row_bytes;
+#define GPR_LAUNCH(T, U, X) hipLaunchKernelGGL((group_points_rows_kernel<T, U, X>), dim3((unsigned)wgs), dim3(T), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out)
+        if (variant == 3) {            // diagnostic: plain unit order (no XCD grouping)
+            if (threads == 256) GPR_LAUNCH(256, 4, false); else if (threads == 512) GPR_LAUNCH(512, 4, false); else GPR_LAUNCH(1024, 4, false);
+        } else if (uq == 1) {
+            if (threads == 256) GPR_LAUNCH(256, 1, true); else if (threads == 512) GPR_LAUNCH(512, 1, true); else GPR_LAUNCH(1024, 1, true);
+        } else if (uq == 2) {
+            if (threads == 256) GPR_LAUNCH(256, 2, true); else if (threads == 512) GPR_LAUNCH(512, 2, true); else GPR_LAUNCH(1024, 2, true);
+        } else {
+            if (threads == 256) GPR_LAUNCH(256, 4, true); else if (threads == 512) GPR_LAUNCH(512, 4, true); else GPR_LAUNCH(1024, 4, true);
+        }
+#undef GPR_LAUNCH
         return check_launch("group_points");
     }
+    rpw = lds_rows_per_wg(n, c, 32 * 1024);   // round 2's kernel and its decomposition
     if (rpw > 0 && L >= 4 * n && (long long)b * divup(c, rpw) >= 512) {
         dim3 grid(divup(c, rpw), b);
         hipLaunchKernelGGL(group_points_lds_kernel, grid, dim3(GPL_THREADS), (size_t)rpw * n * sizeof(float),

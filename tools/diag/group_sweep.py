@@ -16,8 +16,8 @@ def t(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-def pack(variant, rpw=0, ls=0, th=1):
-    return variant | rpw << 4 | ls << 8 | th << 16
+def pack(variant, rpw=0, ls=0, th=1, uq=0):
+    return variant | rpw << 4 | ls << 8 | th << 16 | uq << 20
 shapes = [(96, 4096, 1024, 16), (96, 4096, 1024, 32), (256, 1024, 256, 16), (256, 1024, 256, 32), (512, 256, 64, 16), (512, 256, 64, 32)]
 tot = {}
 for (C, N, M, ns) in shapes:
@@ -37,6 +37,10 @@ for (C, N, M, ns) in shapes:
                 for ls in (1, 2, 4, 8, 16):
                     if M * ns // 4 // ls < 256 * th: continue
                     cands.append((f"T{256*th} rpw{rpw} ls{ls}", pack(1, rpw, ls, th)))
+        for v, u, tag in ((3, 0, "noxcd"), (1, 1, "uq1"), (1, 2, "uq2")):     # what in the rows kernel matters
+            for th, rpw, ls in ((1, min(8, 32768 // (N * 4)), 1), (4, min(8, 65536 // (N * 4)), 2), (2, min(8, 49152 // (N * 4)), 1)):
+                if rpw >= 1 and M * ns // 4 // ls >= 256 * th:
+                    cands.append((f"{tag} T{256*th} rpw{rpw} ls{ls}", pack(v, rpw, ls, th, u)))
         cands.append(("auto", 0))
         for name, p in cands:
             lib.pdm_tune_group_rows(p)
