@@ -199,9 +199,42 @@ def reference_op_section(backbone, points, B, iters=5):
                     pu.grouping_operation(xt, idx)
                     pu.grouping_operation(f, idx)
         ops = t.summary(iters)
-    ms = sum(o["ms_per_step"] for o in ops)
+    ms_events = sum(o["ms_per_step"] for o in ops)
     mb = sum(o["alg_MB_per_step"] for o in ops)
     gp = [o for o in ops if o["op"] == "pdm_group_points"][0]
+
+    # The same 26 API calls (+ the 2 shared grid builds) as ONE hipGraph, replayed: the device time of the sequence with
+    # nothing of the host between the launches (a per-call event pair costs 2-4 us of stream time per call, ~75 us over
+    # the sequence, and Python needs ~14 us per call: the eager loop is host-bound).  This is the figure the fraction of
+    # the HBM peak is taken from; the per-call event sums stay in `ops`.
+    def sequence():
+        with pu.shared_search_grids():
+            for radius, ns, x, nx, f, xt in plan:
+                idx = pu.ball_query(radius, ns, x, nx)
+                pu.grouping_operation(xt, idx)
+                pu.grouping_operation(f, idx)
+    ms, how = ms_events, "sum of per-call HIP-event times (graph capture failed)"
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sequence()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            sequence()
+        graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms, how = e0.elapsed_time(e1) / reps, "hipGraph replay of the whole sequence (device time incl. the 27 launch boundaries)"
+    except Exception as e:
+        print(f"[bench] API-exact sequence: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
     # ball query is not bandwidth-bound as the reference states it: N * M distance evaluations of 8 flop per call
     # (SURVEY D3); the grid form visits only the cells a ball can reach, so its rate is quoted in reference-form
     # evaluations per second ("effective") next to the exhaustive scan's real rate
@@ -218,8 +251,15 @@ def reference_op_section(backbone, points, B, iters=5):
                            # a fraction of the vector peak only where every evaluation is executed; the grid form skips most
                            "frac_of_valu_peak_at_8_flop_per_eval": None if "grid" in o["op"] else round(rate * 8 / 1e12 / VALU_F32_PEAK_TFLOPS, 4),
                            "kind": "effective (grid-pruned incl. its share of pdm_grid_build, same indices)" if "grid" in o["op"] else "executed (exhaustive scan)"}
-    return {"ops": ops, "ms_per_step": round(ms, 4), "alg_MB_per_step": round(mb, 2),
+    launches = sum(o["calls_per_step"] for o in ops)
+    floor_ms = mb / 6200.0 + launches * 1.5e-3     # bytes at the 6.2 TB/s a streaming kernel reaches + 1.5 us per launch boundary
+    return {"ops": ops, "ms_per_step": round(ms, 4), "timed_as": how, "ms_per_step_sum_of_event_pairs": round(ms_events, 4),
+            "alg_MB_per_step": round(mb, 2),
             "GBps": round(mb / ms, 1), "frac_of_hbm_peak": round(mb / ms / HBM_PEAK_GBS, 4),
+            "frac_of_hbm_peak_sum_of_event_pairs": round(mb / ms_events / HBM_PEAK_GBS, 4),
+            "floor": {"ms": round(floor_ms, 4), "frac_of_hbm_peak": round(mb / floor_ms / HBM_PEAK_GBS, 4),
+                      "how": f"{mb:.0f} MB / 6.2 TB/s (MI355X_MICROARCH.md: what plain 256-byte stores and a float4 copy reach) + "
+                             f"{launches} launches x 1.5 us (dependent-launch boundary)"},
             "ball_query_distance_evals": bq,
             "note": "8 ball_query (+ 2 grid builds, one per level that uses the grid) + 16 group_points launches at bs=%d; "
                     "target >= 0.60" % B}, gp

@@ -410,6 +410,25 @@ int pdm_points_in_boxes(void *stream, int B, int T, int M, const float *boxes, c
 int pdm_sample_points(void *stream, int B, int num_points, unsigned seed, int C, const float *raw,
                       const int *counts, float *out, int *choice);
 
+/* ---- bf16 contractions of the training path (csrc/train_gemm.hip) ---------------------------------------------------
+ * The shared MLPs' 1x1 convolutions / Linear layers in TRAINING (reference: torch Conv2d / Linear inside
+ * pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:91-97 and models/dense_heads/point_head_template.py:35-48)
+ * over channels-last rows: bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, ONE rounding of the result.
+ * All strides in elements and multiples of 8, K and N multiples of 8, pointers 16-byte aligned. */
+int pdm_tg_row_tiles(long long rows);            /* row tiles of pdm_tg_gemm_nt: the leading extent of its `stats` output */
+/* Y (R, N) bf16 = X (R, K) . W (N, K)^T [+ bias (N) fp32, rounded to bf16 first].  stats: null, or
+ * [pdm_tg_row_tiles(R)][N][2] fp32 = per row tile the column sums of y and y^2 of the ROUNDED outputs (BatchNorm statistics
+ * without another pass over Y).  The data gradient is the same call on the transposed weights. */
+int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                   void *Y, long long ldy, const float *bias, float *stats);
+size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N);
+/* dW (N, K) fp32 (+)= dY (R, N)^T . X (R, K): row slabs summed in a fixed order (bit-reproducible) */
+int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,
+                 int accumulate, void *workspace, size_t workspace_bytes);
+/* W (N, K) fp32 -> bf16 Wb (N, ldb) and / or its transpose Wt (K, ldt); either may be null; pad columns zero */
+int pdm_tg_pack_weight(void *stream, int N, int K, const float *W, void *Wb, int ldb, void *Wt, int ldt);
+
+
 /* ---- diagnostics (process-global tuning switches used by tools/diag/ A/B measurements; every setting gives
  * identical results; each returns the previous value; not for production callers) ------------------------- */
 int pdm_tune_fps_variant(int v);        /* 8192 < n <= 16384: 0 pruned 1024x16 (default), 3 pruned 512x32, 1 / 2 unpruned */

@@ -17,9 +17,13 @@
 namespace pdm {
 
 constexpr int BQ_WAVES = 4;
-constexpr int BQ_CPW = 4;      // centres per wave
 constexpr int BQ_TILE = 2048;  // points per LDS tile (24 KB)
 
+// BQ_CPW = centres per wave.  A wave walks its tile steps one after the other (ballot -> count -> branch: a latency
+// chain of ~150 cycles per step and centre), so four centres per wave quadruple that chain; with few centres in the
+// call (the deeper SA levels: 32 x 256 and 32 x 64) one centre per wave gives four times the waves and a quarter of the
+// chain: 13.7 -> measured in profiles/r03_api_ops_device.txt.  Many centres: four per wave share each staged point.
+template <int BQ_CPW>
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
     int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx) {
@@ -101,8 +105,14 @@ extern "C" int pdm_ball_query(void *stream, int b, int n, int m, float radius, i
     PDM_REQUIRE(new_xyz && xyz && idx, PDM_E_BADARG, "ball_query: null pointer");
     PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "ball_query: b=%d exceeds grid", b);
     const float radius2 = radius * radius;  // ball_query_gpu.cu:29 (fp32 product)
-    dim3 grid(divup(m, BQ_WAVES * BQ_CPW), b);
-    hipLaunchKernelGGL(ball_query_wave_kernel, grid, dim3(BQ_WAVES * 64), 0, as_stream(stream), n,
-                       m, radius2, nsample, new_xyz, xyz, idx);
+    if ((long long)b * m <= 32768) {
+        dim3 grid(divup(m, BQ_WAVES), b);
+        hipLaunchKernelGGL(ball_query_wave_kernel<1>, grid, dim3(BQ_WAVES * 64), 0, as_stream(stream), n,
+                           m, radius2, nsample, new_xyz, xyz, idx);
+    } else {
+        dim3 grid(divup(m, BQ_WAVES * 4), b);
+        hipLaunchKernelGGL(ball_query_wave_kernel<4>, grid, dim3(BQ_WAVES * 64), 0, as_stream(stream), n,
+                           m, radius2, nsample, new_xyz, xyz, idx);
+    }
     return check_launch("ball_query");
 }

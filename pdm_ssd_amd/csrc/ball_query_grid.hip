@@ -22,6 +22,11 @@ namespace pdm {
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
 // workspace layout per call: [B headers][B * (CAP+1) cell starts][B * n float4 sorted points]
+// CACHED (n <= 16 * 1024): a thread keeps its <= 16 points in registers from the bounding-box pass on — the histogram
+// pass(es) and the scatter pass re-read nothing (round 2 read the cloud three times through strided 4-byte loads; the
+// build is one workgroup per cloud, i.e. a latency chain, and was 30 us of the 100 us of an SA level's neighbour search).
+constexpr int BQG_PPT = 16;
+template <bool CACHED>
 __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float radius, int max_cells,
                                                                     const float *__restrict__ xyz_all,
                                                                     float *__restrict__ hdr_all,
@@ -40,12 +45,27 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
 
     // ---- bounding box
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = tid; k < n; k += BQG_BUILD_T) {
+    float px[CACHED ? BQG_PPT : 1], py[CACHED ? BQG_PPT : 1], pz[CACHED ? BQG_PPT : 1];
+    if constexpr (CACHED) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = xyz[(size_t)k * 3 + a];
-            mn[a] = fminf(mn[a], v);
-            mx[a] = fmaxf(mx[a], v);
+        for (int i = 0; i < BQG_PPT; ++i) {
+            const int k = tid + i * BQG_BUILD_T;
+            px[i] = py[i] = pz[i] = 0.0f;
+            if (k < n) {
+                px[i] = xyz[(size_t)k * 3 + 0]; py[i] = xyz[(size_t)k * 3 + 1]; pz[i] = xyz[(size_t)k * 3 + 2];
+                mn[0] = fminf(mn[0], px[i]); mx[0] = fmaxf(mx[0], px[i]);
+                mn[1] = fminf(mn[1], py[i]); mx[1] = fmaxf(mx[1], py[i]);
+                mn[2] = fminf(mn[2], pz[i]); mx[2] = fmaxf(mx[2], pz[i]);
+            }
+        }
+    } else {
+        for (int k = tid; k < n; k += BQG_BUILD_T) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = xyz[(size_t)k * 3 + a];
+                mn[a] = fminf(mn[a], v);
+                mx[a] = fmaxf(mx[a], v);
+            }
         }
     }
 #pragma unroll
@@ -100,11 +120,23 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
         for (int c = tid; c < H.ncells; c += BQG_BUILD_T) hist[c] = 0;
         if (tid == 0) s_nonempty = 0;
         __syncthreads();
-        for (int k = tid; k < n; k += BQG_BUILD_T) {
-            const int cx = cell_of(xyz[(size_t)k * 3 + 0], H.minx, H.inv_h, H.gx);
-            const int cy = cell_of(xyz[(size_t)k * 3 + 1], H.miny, H.inv_h, H.gy);
-            const int cz = cell_of(xyz[(size_t)k * 3 + 2], H.minz, H.inv_h, H.gz);
-            atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+        if constexpr (CACHED) {
+#pragma unroll
+            for (int i = 0; i < BQG_PPT; ++i) {
+                if (tid + i * BQG_BUILD_T < n) {
+                    const int cx = cell_of(px[i], H.minx, H.inv_h, H.gx);
+                    const int cy = cell_of(py[i], H.miny, H.inv_h, H.gy);
+                    const int cz = cell_of(pz[i], H.minz, H.inv_h, H.gz);
+                    atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+                }
+            }
+        } else {
+            for (int k = tid; k < n; k += BQG_BUILD_T) {
+                const int cx = cell_of(xyz[(size_t)k * 3 + 0], H.minx, H.inv_h, H.gx);
+                const int cy = cell_of(xyz[(size_t)k * 3 + 1], H.miny, H.inv_h, H.gy);
+                const int cz = cell_of(xyz[(size_t)k * 3 + 2], H.minz, H.inv_h, H.gz);
+                atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+            }
         }
         __syncthreads();
         if (radius != 0.0f || pass >= 8) break;      // kernel argument: uniform
@@ -179,13 +211,27 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
     __syncthreads();
 
     // ---- scatter into cell order (order inside a cell is arbitrary; the query does not depend on it)
-    for (int k = tid; k < n; k += BQG_BUILD_T) {
-        const float x = xyz[(size_t)k * 3 + 0], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
-        const int cx = cell_of(x, H.minx, H.inv_h, H.gx);
-        const int cy = cell_of(y, H.miny, H.inv_h, H.gy);
-        const int cz = cell_of(z, H.minz, H.inv_h, H.gz);
-        const int slot = atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
-        sorted[slot] = make_float4(x, y, z, __int_as_float(k));
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int i = 0; i < BQG_PPT; ++i) {
+            const int k = tid + i * BQG_BUILD_T;
+            if (k < n) {
+                const int cx = cell_of(px[i], H.minx, H.inv_h, H.gx);
+                const int cy = cell_of(py[i], H.miny, H.inv_h, H.gy);
+                const int cz = cell_of(pz[i], H.minz, H.inv_h, H.gz);
+                const int slot = atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+                sorted[slot] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+            }
+        }
+    } else {
+        for (int k = tid; k < n; k += BQG_BUILD_T) {
+            const float x = xyz[(size_t)k * 3 + 0], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
+            const int cx = cell_of(x, H.minx, H.inv_h, H.gx);
+            const int cy = cell_of(y, H.miny, H.inv_h, H.gy);
+            const int cz = cell_of(z, H.minz, H.inv_h, H.gz);
+            const int slot = atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
+            sorted[slot] = make_float4(x, y, z, __int_as_float(k));
+        }
     }
 }
 
@@ -445,8 +491,12 @@ int launch_grid_build(hipStream_t stream, int b, int n, float radius, int max_ce
                       const GridWs &ws) {
     if (max_cells > BQG_CAP) max_cells = BQG_CAP;
     if (max_cells < 1) max_cells = 1;
-    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
-                       ws.hdr, ws.cell_start, ws.sorted);
+    if (n <= BQG_PPT * BQG_BUILD_T)
+        hipLaunchKernelGGL(bq_grid_build_kernel<true>, dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
+                           ws.hdr, ws.cell_start, ws.sorted);
+    else
+        hipLaunchKernelGGL(bq_grid_build_kernel<false>, dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
+                           ws.hdr, ws.cell_start, ws.sorted);
     return check_launch("grid_build");
 }
 

@@ -1,0 +1,71 @@
+"""Python side of csrc/train_gemm.hip: the bf16 contractions of the training path on this library's own MFMA kernels.
+
+Rows layout throughout: a channels-last activation tensor IS a (rows, channels) matrix.  No fallback: the calls raise
+when the HIP library is missing or an argument does not fit (callers test `usable()` first and otherwise keep torch)."""
+import torch
+
+from . import _native
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def usable(rows, k, n):
+    """shapes the kernels take: channel counts multiples of 8 (16-byte rows)"""
+    return rows > 0 and k > 0 and n > 0 and k % 8 == 0 and n % 8 == 0
+
+
+def row_view(x):
+    """(rows, C) view of a bf16 tensor whose storage is rows x C with the channel fastest: a contiguous (R, C) matrix, a
+    channels-last (B, C, H, W) tensor or a (B, C, L) tensor stored (B, L, C).  None when the layout is something else."""
+    if x.dim() == 2:
+        return x if x.stride(1) == 1 and x.stride(0) >= x.shape[1] else None
+    if x.dim() >= 3:
+        xm = x.movedim(1, -1)
+        if xm.is_contiguous():
+            return xm.reshape(-1, x.shape[1])
+    return None
+
+
+def pack_weight(w, transposed=False, pad_to=None):
+    """fp32 (N, K) parameter -> bf16 (N, ld) copy (round to nearest even), or its transpose (K, ld); ld = the row length
+    rounded up to a multiple of 8 (pad_to overrides), pad columns zero."""
+    assert w.dim() == 2 and w.is_cuda and w.dtype == torch.float32
+    w = w.detach().contiguous()
+    N, K = w.shape
+    inner = N if transposed else K
+    ld = (inner + 7) // 8 * 8 if pad_to is None else pad_to
+    out = torch.empty((K if transposed else N, ld), dtype=torch.bfloat16, device=w.device)
+    _native.call("pdm_tg_pack_weight", _stream(w), N, K, w.data_ptr(), 0 if transposed else out.data_ptr(), 0 if transposed else ld,
+                 out.data_ptr() if transposed else 0, ld if transposed else 0)
+    return out
+
+
+def gemm_nt(x, w, bias=None, stats=False, out=None):
+    """x (R, K) bf16 rows (row stride a multiple of 8), w (N, K') bf16 with K' >= K zero padded -> y (R, N) bf16 =
+    x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the per-row-tile column sums
+    [tiles][N][2] (sum y, sum y^2 of the rounded y)."""
+    R, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1
+    y = torch.empty((R, N), dtype=torch.bfloat16, device=x.device) if out is None else out
+    st = None
+    if stats:
+        st = torch.empty((_native.lib().pdm_tg_row_tiles(R), N, 2), dtype=torch.float32, device=x.device)
+    _native.call("pdm_tg_gemm_nt", _stream(x), R, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
+                 0 if bias is None else bias.data_ptr(), 0 if st is None else st.data_ptr())
+    return (y, st) if stats else y
+
+
+def wgrad(dy, x, out=None, accumulate=False):
+    """dy (R, N) bf16, x (R, K) bf16 -> dW (N, K) fp32 = dy^T . x (fp32 accumulation, deterministic)."""
+    R, N = dy.shape
+    K = x.shape[1]
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and x.shape[0] == R and dy.stride(1) == 1 and x.stride(1) == 1
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device) if out is None else out
+    nbytes = _native.lib().pdm_tg_wgrad_ws_bytes(R, K, N)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _native.call("pdm_tg_wgrad", _stream(x), R, K, N, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
+                 1 if accumulate else 0, ws.data_ptr(), nbytes)
+    return dw
