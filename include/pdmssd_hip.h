@@ -67,6 +67,12 @@ int pdm_group_concat_cl(void *stream, int b, int n, int m, int c, int nsample, c
 size_t pdm_group_concat_cl_grad_ws_bytes(int b, int n, int m, int nsample);
 int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16,
                              const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes);
+/* Both with a row stride ld >= 3 + C: out / grad are (B, M, nsample, ld); the forward writes the channels 3 + C .. ld - 1 as
+ * ZEROS (padding to 16-byte rows for the bf16 contractions of csrc/train_gemm.hip, ld = 3 + C rounded up to 8). */
+int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                           const float *feat_pm, const int *idx, void *out, int out_bf16, int ld);
+int pdm_group_concat_cl_grad_ld(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16, int ld,
+                                const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes);
 
 /* The same backward with a caller-provided workspace (pdm_group_points_grad_ws_bytes bytes): scatter inverted into CSR lists,
  * accumulated without atomics (as pdm_three_interpolate_grad_ws).  Forwards to the plain entry point when a grad_out row
@@ -342,6 +348,11 @@ int pdm_bn_parts(int layout, long long n, int C, long long L);
 int pdm_bn_relu_forward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, void *y,
                         const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
                         float *running_var, float *coef, float *partial, int relu);
+/* the same forward with the statistics already taken by the producer of x (pdm_tg_gemm_nt's `stats`: [parts][C][2] column sums
+ * of x and x^2): finalize + apply only, rows x C layout */
+int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, int C, const void *x, void *y, const float *gamma,
+                              const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                              float *coef, const float *partial, int parts, int relu);
 int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                          void *dx, const float *coef, float *grads, float *partial, int relu);
 

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "pdm_group_concat": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_group_concat_cl": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i],
     "pdm_group_concat_cl_grad": [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_group_concat_cl_ld": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i],
+    "pdm_group_concat_cl_grad_ld": [_i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_copy_many": [_i, _vp, _vp, _vp],
@@ -69,6 +71,7 @@ _SIGNATURES = {
     "pdm_bn_relu_pool_forward": [_i, ctypes.c_longlong, _i, _i] + [_vp] * 8 + [_f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_bn_relu_pool_backward": [_i, ctypes.c_longlong, _i, _i] + [_vp] * 10 + [_i],
     "pdm_bn_relu_forward": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
+    "pdm_bn_relu_forward_stats": [_i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_bn_relu_backward": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "pdm_stack_voxel_query": [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_stack_local_neighbor_count": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i],

@@ -50,10 +50,35 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
     for (int base = 0; base < n; base += BQ_TILE) {
         const int tile = min(BQ_TILE, n - base);
         __syncthreads();  // previous tile fully consumed
-        for (int i = threadIdx.x; i < tile * 3; i += BQ_WAVES * 64) {
-            const float v = pts[(size_t)base * 3 + i];
-            const int pnt = i / 3, comp = i - pnt * 3;
-            (comp == 0 ? sx : comp == 1 ? sy : sz)[pnt] = v;
+        if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(xyz) & 15) == 0) {
+            // 16-byte loads, all of a thread's requests in flight before the first LDS write (the scalar loop below was a
+            // chain of up to 24 dependent round trips for a tile: most of the 8 us this kernel took on a 1024-point cloud)
+            const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(pts + (size_t)base * 3);
+            const int nq = tile * 3 / 4;            // tile % 4 == 0 here (n % 4 == 0, BQ_TILE % 4 == 0)
+            float4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = threadIdx.x + u * BQ_WAVES * 64;
+                if (q < nq) v[u] = p4[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = threadIdx.x + u * BQ_WAVES * 64;
+                if (q < nq) {
+                    const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = q * 4 + j, pnt = i / 3, comp = i - pnt * 3;
+                        (comp == 0 ? sx : comp == 1 ? sy : sz)[pnt] = e[j];
+                    }
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < tile * 3; i += BQ_WAVES * 64) {
+                const float v = pts[(size_t)base * 3 + i];
+                const int pnt = i / 3, comp = i - pnt * 3;
+                (comp == 0 ? sx : comp == 1 ? sy : sz)[pnt] = v;
+            }
         }
         __syncthreads();
         bool wave_done = true;
@@ -85,11 +110,13 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
         // every wave of the block done -> stop staging tiles
         if (__syncthreads_and(wave_done)) break;
     }
-    // ball_query_gpu.cu:41-45 — slots beyond the hit count hold the first hit
+    // ball_query_gpu.cu:41-45 — slots beyond the hit count hold the first hit; the row of an EMPTY ball is all zeros: the
+    // reference leaves it as its caller zero-filled it (pointnet2_utils.py:218) — written here, so the result does not
+    // depend on a fill pass in front of the call (this library's BallQuery allocates without one)
 #pragma unroll
     for (int c = 0; c < BQ_CPW; ++c) {
-        if (j0 + c < m && first[c] >= 0 && cnt[c] < nsample)
-            for (int l = cnt[c] + lane; l < nsample; l += 64) out[(size_t)c * nsample + l] = first[c];
+        if (j0 + c < m && cnt[c] < nsample)
+            for (int l = cnt[c] + lane; l < nsample; l += 64) out[(size_t)c * nsample + l] = first[c] >= 0 ? first[c] : 0;
     }
 }
 

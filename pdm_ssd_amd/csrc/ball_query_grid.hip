@@ -316,7 +316,11 @@ __device__ __forceinline__ void bq_centre_wave(const BqGrid &G, float cx, float 
             }
         }
     }
-    if (!used_bitmap || hits == 0) return;  // empty ball: row stays as the caller zero-filled it (pointnet2_utils.py:218)
+    if (hits == 0) {   // empty ball: an all-zero row (what the reference's caller-side zero fill leaves, pointnet2_utils.py:218)
+        for (int l = lane; l < nsample; l += 64) out[l] = 0;
+        return;
+    }
+    if (!used_bitmap) return;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // LDS atomics of this wave are done before it reads them back
 
@@ -469,10 +473,11 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query4_kernel(
         BQ_RANK(0) BQ_RANK(1) BQ_RANK(2) BQ_RANK(3) BQ_RANK(4) BQ_RANK(5) BQ_RANK(6) BQ_RANK(7)
         BQ_RANK(8) BQ_RANK(9) BQ_RANK(10) BQ_RANK(11) BQ_RANK(12) BQ_RANK(13) BQ_RANK(14) BQ_RANK(15)
 #undef BQ_RANK
-        if (fast && hits > 0) {
+        if (fast) {
             int *out = idx + ((size_t)b * m + j) * nsample;
             if (k != 0x7FFFFFFF && pos < nsample) out[pos] = k;
-            for (int l = hits + li; l < nsample; l += 16) out[l] = kmin;   // ball_query_gpu.cu:41-45
+            // ball_query_gpu.cu:41-45: pad with the first hit; an empty ball's row is all zeros (the reference's caller-side fill)
+            for (int l = hits + li; l < nsample; l += 16) out[l] = hits > 0 ? kmin : 0;
         }
         // centres that did not fit a DPP row: whole-wave path, one after the other
         unsigned long long slow = __ballot(live && !fast) & 0x0001000100010001ull;

@@ -492,6 +492,29 @@ extern "C" int pdm_bn_relu_forward(void *stream, int dtype, int layout, long lon
     return check_launch("bn_relu_forward");
 }
 
+// The same forward when the statistics pass has already been done by the producer of x: pdm_tg_gemm_nt (train_gemm.hip)
+// leaves per-row-tile column sums of y and y^2 of its ROUNDED outputs, exactly the two sums bn_cl_reduce_kernel<MODE 0> forms
+// (with pivot 0) — `partial` = [parts][C][2].  One pass over x (the apply) instead of two.  rows x C layout only.
+extern "C" int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, int C, const void *x, void *y, const float *gamma,
+                                         const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                         float *coef, const float *partial, int parts, int relu) {
+    if (int rc = bn_check("bn_relu_forward_stats", dtype, 0, n, C, 1, x, y)) return rc;
+    PDM_REQUIRE(coef && partial && parts >= 1, PDM_E_BADARG, "bn_relu_forward_stats: null workspace");
+    if (n == 0) return 0;
+    const hipError_t e = hipMemsetAsync(coef + 3 * (size_t)C, 0, sizeof(float) * (size_t)C, as_stream(stream));   // the sums' pivot: 0
+    PDM_REQUIRE(e == hipSuccess, PDM_E_BADARG, "bn_relu_forward_stats: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n, gamma, beta, eps,
+                       momentum, running_mean, running_var, coef);
+    const BnCoef k = coef_of(coef, nullptr, C);
+    const int V = dtype ? 8 : 4;
+    const long long nvec = n * C / V;
+    const long long ag = (nvec + 255) / 256;
+    const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
+    if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, k, relu);
+    else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, (float *)y, nvec, C, k, relu);
+    return check_launch("bn_relu_forward_stats");
+}
+
 // Backward: dx, and grads (4, C) = [dgamma | dbeta | k1 | k2] (the caller reads the first two rows).
 extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                                     void *dx, const float *coef, float *grads, float *partial, int relu) {

@@ -450,19 +450,20 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void group_concat_cl_kernel(long long total, int n, int m, int c, int ns,
+__global__ __launch_bounds__(256) void group_concat_cl_kernel(long long total, int n, int m, int c, int ns, int ld,
                                                               const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                               const float *__restrict__ feat_pm, const int *__restrict__ idx,
                                                               void *__restrict__ out) {
-    const int w = 3 + c;
+    const int w = 3 + c;     // ld >= w: row stride of the output; the channels w .. ld - 1 are written as zeros (padding)
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long row = e / w;                 // (b, centre, slot)
-        const int ch = (int)(e - row * w);
+        const long long row = e / ld;                // (b, centre, slot)
+        const int ch = (int)(e - row * ld);
         const long long bm = row / ns;               // b * m + centre
         const int b = (int)(bm / m);
         const int src = idx[row];
         float v;
         if (ch < 3) v = xyz[((size_t)b * n + src) * 3 + ch] - new_xyz[bm * 3 + ch];   // pointnet2_utils.py:252
+        else if (ch >= w) v = 0.0f;
         else v = feat_pm[((size_t)b * n + src) * c + (ch - 3)];
         if constexpr (BF16) static_cast<unsigned short *>(out)[e] = f32_to_bf16_rne(v);
         else static_cast<float *>(out)[e] = v;
@@ -472,20 +473,29 @@ __global__ __launch_bounds__(256) void group_concat_cl_kernel(long long total, i
 }  // namespace pdm
 
 // out (B, M, ns, 3+C) fp32 (out_bf16 = 0) or bf16 (1); feat_pm (B, N, C) point-major, may be null when c == 0; idx (B, M, ns).
+extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                                      const float *feat_pm, const int *idx, void *out, int out_bf16, int ld);
 extern "C" int pdm_group_concat_cl(void *stream, int b, int n, int m, int c, int nsample, const float *xyz,
                                    const float *new_xyz, const float *feat_pm, const int *idx, void *out, int out_bf16) {
-    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0, PDM_E_BADARG, "group_concat_cl: negative size");
-    const long long total = (long long)b * m * nsample * (3 + c);
+    return pdm_group_concat_cl_ld(stream, b, n, m, c, nsample, xyz, new_xyz, feat_pm, idx, out, out_bf16, 3 + c);
+}
+
+// The same with a row stride: out (B, M, ns, ld), ld >= 3 + C; the channels 3 + C .. ld - 1 are written as ZEROS, so the tensor
+// can feed a contraction over ld channels (16-byte rows for the bf16 MFMA kernels of train_gemm.hip: ld = round8(3 + C)).
+extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                                      const float *feat_pm, const int *idx, void *out, int out_bf16, int ld) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0 && ld >= 3 + c, PDM_E_BADARG, "group_concat_cl: negative size or ld < 3 + c");
+    const long long total = (long long)b * m * nsample * ld;
     if (total == 0) return 0;
     PDM_REQUIRE(xyz && new_xyz && idx && out && (c == 0 || feat_pm), PDM_E_BADARG, "group_concat_cl: null pointer");
     const long long want = (total + 255) / 256;
     const int blocks = (int)(want < 256 * 64 ? want : 256 * 64);
     if (out_bf16)
         hipLaunchKernelGGL(pdm::group_concat_cl_kernel<true>, dim3(blocks), dim3(256), 0, pdm::as_stream(stream), total, n, m, c,
-                           nsample, xyz, new_xyz, feat_pm, idx, out);
+                           nsample, ld, xyz, new_xyz, feat_pm, idx, out);
     else
         hipLaunchKernelGGL(pdm::group_concat_cl_kernel<false>, dim3(blocks), dim3(256), 0, pdm::as_stream(stream), total, n, m, c,
-                           nsample, xyz, new_xyz, feat_pm, idx, out);
+                           nsample, ld, xyz, new_xyz, feat_pm, idx, out);
     return pdm::check_launch("group_concat_cl");
 }
 
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(GCL_THREADS) void gcl_csr_build_kernel(int ne, int 
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void gcl_grad_kernel(int n, int c, int ne, const void *__restrict__ grad,
+__global__ __launch_bounds__(256) void gcl_grad_kernel(int n, int c, int ne, int w, const void *__restrict__ grad,
                                                        const int *__restrict__ start_all, const int *__restrict__ el_all,
                                                        float *__restrict__ out_pm) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
@@ -550,8 +560,7 @@ __global__ __launch_bounds__(256) void gcl_grad_kernel(int n, int c, int ne, con
     if (k >= n) return;
     const int *__restrict__ start = start_all + (size_t)b * (n + 1);
     const int *__restrict__ el = el_all + (size_t)b * ne;
-    const int s = start[k], e = start[k + 1];
-    const int w = 3 + c;
+    const int s = start[k], e = start[k + 1];   // w = row stride of grad (>= 3 + c)
     for (int c0 = 0; c0 < c; c0 += 64) {
         const int ch = c0 + lane;
         float acc = 0.0f;
@@ -574,9 +583,17 @@ extern "C" size_t pdm_group_concat_cl_grad_ws_bytes(int b, int n, int m, int nsa
 }
 
 // grad (B, M, ns, 3+C) fp32 / bf16 (grad_bf16) -> grad_feat_pm (B, N, C) fp32, fully written.  n <= 16384.
+extern "C" int pdm_group_concat_cl_grad_ld(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16, int ld,
+                                           const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes);
 extern "C" int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16,
                                         const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes) {
-    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0, PDM_E_BADARG, "group_concat_cl_grad: negative size");
+    return pdm_group_concat_cl_grad_ld(stream, b, n, m, c, nsample, grad, grad_bf16, 3 + c, idx, grad_feat_pm, workspace, workspace_bytes);
+}
+
+// the same for a gradient with row stride ld >= 3 + C (the padded form of pdm_group_concat_cl_ld)
+extern "C" int pdm_group_concat_cl_grad_ld(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16, int ld,
+                                           const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0 && ld >= 3 + c, PDM_E_BADARG, "group_concat_cl_grad: negative size or ld < 3 + c");
     if (b == 0 || n == 0 || c == 0) return 0;
     PDM_REQUIRE(n <= 16384 && b <= 65535 && (long long)m * nsample < (1ll << 30), PDM_E_TOOLARGE,
                 "group_concat_cl_grad: n=%d (<= 16384), b=%d", n, b);
@@ -599,8 +616,8 @@ extern "C" int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c
     if (rc) return rc;
     const dim3 grid((unsigned)((n + 3) / 4), (unsigned)b);
     if (grad_bf16)
-        hipLaunchKernelGGL(pdm::gcl_grad_kernel<true>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, grad, start, el, grad_feat_pm);
+        hipLaunchKernelGGL(pdm::gcl_grad_kernel<true>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, ld, grad, start, el, grad_feat_pm);
     else
-        hipLaunchKernelGGL(pdm::gcl_grad_kernel<false>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, grad, start, el, grad_feat_pm);
+        hipLaunchKernelGGL(pdm::gcl_grad_kernel<false>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, ld, grad, start, el, grad_feat_pm);
     return pdm::check_launch("group_concat_cl_grad");
 }

@@ -99,7 +99,9 @@ class PDMHeatmapHead(nn.Module):
                 layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.BatchNorm2d(width), nn.ReLU()]
             c = width
         self.shared_conv = TrainSequential(*layers)
-        self.hm = nn.Sequential(nn.Conv2d(c, width, 1, bias=True), nn.ReLU(), nn.Conv2d(width, num_class, 1, bias=True))
+        # (a TrainSequential: an nn.Sequential — same state_dict keys — whose 1x1 convolutions run on the bf16 MFMA row
+        # kernels in training, fused_bn.py)
+        self.hm = TrainSequential(nn.Conv2d(c, width, 1, bias=True), nn.ReLU(), nn.Conv2d(width, num_class, 1, bias=True))
         self.hm[-1].bias.data.fill_(-2.19)   # CenterPoint's prior: sigmoid(-2.19) = 0.1 (center_head.py:47)
         self.add_module('hm_loss_func', loss_utils.FocalLossCenterNet())
         self.forward_ret_dict = {}

@@ -29,6 +29,9 @@ def _layout(x):
     if x.dim() == 2:
         return (0, x.shape[0], 1) if x.is_contiguous() and C % v == 0 and C // v <= 256 else None
     L = x.numel() // (x.shape[0] * C)
+    if x.dim() == 3 and not x.is_contiguous() and x.transpose(1, 2).is_contiguous():
+        # (B, C, L) view of point-major (B, L, C) storage (the rows layout of the training path): rows x C
+        return (0, x.shape[0] * x.shape[2], 1) if C % v == 0 and C // v <= 256 else None
     if x.is_contiguous():
         if L == 1:
             return (0, x.shape[0], 1) if C % v == 0 and C // v <= 256 else None
@@ -41,17 +44,25 @@ def _layout(x):
 class _BnRelu(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L, stats=None):
         C = x.shape[1]
         dtype = 1 if x.dtype == torch.bfloat16 else 0
         y = torch.empty_like(x)
         coef = torch.empty((4, C), dtype=torch.float32, device=x.device)
         parts = _native.lib().pdm_bn_parts(layout, n, C, L)
-        partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
-        _native.call("pdm_bn_relu_forward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
-                     y.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), float(momentum),
-                     0 if running_mean is None else running_mean.data_ptr(), 0 if running_var is None else running_var.data_ptr(),
-                     coef.data_ptr(), partial.data_ptr(), int(relu))
+        if stats is not None and layout == 0:
+            # the producing GEMM left the column sums of x and x^2 (train_gemm.gemm_nt(..., stats=True)): no statistics pass
+            assert stats.shape[1:] == (C, 2) and stats.dtype == torch.float32 and stats.is_contiguous()
+            _native.call("pdm_bn_relu_forward_stats", torch.cuda.current_stream(x.device).cuda_stream, dtype, n, C, x.data_ptr(),
+                         y.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), float(momentum),
+                         0 if running_mean is None else running_mean.data_ptr(), 0 if running_var is None else running_var.data_ptr(),
+                         coef.data_ptr(), stats.data_ptr(), stats.shape[0], int(relu))
+        else:
+            partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
+            _native.call("pdm_bn_relu_forward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
+                         y.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), float(momentum),
+                         0 if running_mean is None else running_mean.data_ptr(), 0 if running_var is None else running_var.data_ptr(),
+                         coef.data_ptr(), partial.data_ptr(), int(relu))
         ctx.save_for_backward(x, coef)
         ctx.meta = (dtype, layout, n, C, L, int(relu), parts)
         return y
@@ -68,7 +79,7 @@ class _BnRelu(Function):
         partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
         _native.call("pdm_bn_relu_backward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
                      dy.data_ptr(), dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), relu)
-        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None
+        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None, None
 
 
 class _BnReluPool(Function):
@@ -126,15 +137,122 @@ def applies(x, bn):
             and x.dim() >= 2 and x.shape[1] == bn.num_features and _layout(x) is not None)
 
 
-def batch_norm_relu(x, bn, relu=True):
-    """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch."""
+def batch_norm_relu(x, bn, relu=True, stats=None):
+    """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch.
+    stats: the column sums the producing GEMM took of x ([tiles][C][2], rows_linear(..., want_stats=True)) or None."""
     if not applies(x, bn):
         y = bn(x)
         return torch.relu(y) if relu else y
     layout, n, L = _layout(x)
     with torch.no_grad():
         bn.num_batches_tracked += 1
-    return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L)
+    return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L,
+                         stats if layout == 0 else None)
+
+
+def _round8(v):
+    return (v + 7) // 8 * 8
+
+
+class _RowsGemm(Function):
+    """1x1 convolution / Linear over channels-last rows on this library's bf16 MFMA kernels (csrc/train_gemm.hip):
+    forward y = x W^T [+ b], data gradient dx = dy W, weight gradient dW = dy^T x — no vendor GEMM, no layout or dtype
+    copy of an activation that is already bf16 rows.  Numerics: operands rounded to bf16 (what autocast does), fp32
+    accumulation, y and dx rounded once to bf16, dW / db fp32 straight into the fp32 parameters.
+
+    x: (R, K) rows, a channels-last (B, K, H, W) tensor or a (B, K, L) tensor stored (B, L, K).  K may exceed the layer's
+    in_channels up to the next multiple of 8: those channels are ZERO PADDING by contract (the grouping operator writes
+    them) and meet zero weight columns.  Returns (y, stats): y in x's layout with N channels (a view of (R, round8(N))
+    storage), stats = the per-row-tile column sums of y and y^2 for the BatchNorm that follows (or None)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, want_stats):
+        from . import train_gemm as tg
+        xr = tg.row_view(x)
+        assert xr is not None
+        if xr.dtype != torch.bfloat16:
+            xr = xr.to(torch.bfloat16)                       # autocast's rounding of an fp32 activation
+        R, K = xr.shape
+        N = weight.shape[0]
+        w2 = weight.reshape(N, -1)
+        Kw, Np = w2.shape[1], _round8(N)
+        assert Kw <= K < Kw + 8 and K % 8 == 0
+        if Np == N:
+            wb = tg.pack_weight(w2, pad_to=K)
+        else:                                                # a narrow last layer (3 class logits): zero rows up to 8
+            wb = torch.zeros((Np, K), dtype=torch.bfloat16, device=x.device)
+            tg.pack_weight_into(w2, wb)
+        if bias is not None and Np != N:
+            bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
+        y, stats = tg.gemm_nt(xr, wb, bias=bias, stats=True) if want_stats else (tg.gemm_nt(xr, wb, bias=bias), None)
+        ctx.save_for_backward(xr, weight)
+        ctx.geom = (tuple(x.shape), x.dim(), N, Np, K, Kw, bias is not None, x.dtype)
+        out = _rows_to_layout(y, x, N)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy, _dstats=None):
+        from . import train_gemm as tg
+        xr, weight = ctx.saved_tensors
+        xshape, xdim, N, Np, K, Kw, has_bias, xdtype = ctx.geom
+        R = xr.shape[0]
+        dyr = tg.row_view(dy)
+        if dyr is None or dyr.dtype != torch.bfloat16 or dyr.shape[1] != Np or dyr.stride(0) % 8:
+            # a gradient that does not arrive as bf16 rows of the padded width: one copy into that form
+            src = dy.movedim(1, -1).reshape(R, N) if xdim > 2 else dy
+            dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != N else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
+            dyr[:, :N].copy_(src)
+        w2 = weight.reshape(N, -1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.zeros((K, Np), dtype=torch.bfloat16, device=dy.device) if (K != Kw or Np != N) else \
+                torch.empty((K, Np), dtype=torch.bfloat16, device=dy.device)
+            tg.pack_weight_into(w2, wt, transposed=True)     # (Kw, N) block of a (K, Np) matrix; the rest stays zero
+            dxr = tg.gemm_nt(dyr, wt)                        # (R, K) bf16: the pad channels come out zero
+            dx = _rows_to_layout(dxr, None, K, xshape, xdim)
+            if xdtype != torch.bfloat16:
+                dx = dx.to(xdtype)
+        dw = tg.wgrad(dyr, xr)                               # (Np, K) fp32
+        dw = dw[:N, :Kw].reshape(weight.shape)
+        db = dyr[:, :N].sum(0, dtype=torch.float32) if has_bias else None
+        return dx, dw, db, None
+
+
+def _rows_to_layout(rows, like, channels, shape=None, dim=None):
+    """(R, ld) row storage -> the logical tensor of `like`'s layout with `channels` channels (a view)."""
+    shape = tuple(like.shape) if shape is None else shape
+    dim = like.dim() if dim is None else dim
+    if dim == 2:
+        return rows[:, :channels]
+    lead = (shape[0],) + tuple(shape[2:])
+    return rows.view(*lead, rows.shape[1])[..., :channels].movedim(-1, 1)
+
+
+def rows_linear(x, layer, want_stats=False):
+    """layer(x) for a 1x1 convolution / Linear through _RowsGemm when x is (castable to) bf16 rows on the GPU under bf16
+    autocast; returns (y, stats) — stats None when not requested or not taken; (None, None) when the form does not apply."""
+    from . import train_gemm as tg
+    if not (ENABLED and ROWS_GEMM and x.is_cuda and _bf16_autocast() and layer.weight.dtype == torch.float32 and x.dim() in (2, 3, 4)):
+        return None, None
+    if isinstance(layer, nn.Linear):
+        kin = layer.in_features
+    else:
+        if not (all(k == 1 for k in layer.kernel_size) and all(v == 1 for v in layer.stride) and all(v == 0 for v in layer.padding)
+                and all(v == 1 for v in layer.dilation) and layer.groups == 1 and isinstance(layer.padding, tuple)
+                and x.dim() == layer.weight.dim()):
+            return None, None
+        kin = layer.in_channels
+    K = x.shape[1]
+    if x.dtype not in (torch.bfloat16, torch.float32) or K != _round8(kin) or tg.row_view(x) is None:
+        return None, None
+    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats))
+
+
+ROWS_GEMM = os.environ.get("PDM_ROWS_GEMM", "1") != "0"   # 0: the round-2 path (vendor GEMMs) for A/B measurements
 
 
 class _LinearSplitK(Function):
@@ -281,17 +399,27 @@ class TrainSequential(nn.Sequential):
     @staticmethod
     def _run(x, mods):
         i = 0
+        stats = None      # column sums of x taken by the GEMM that produced it, for the BatchNorm right behind it
         while i < len(mods):
             m = mods[i]
             if isinstance(m, _BN) and applies(x, m):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = batch_norm_relu(x, m, relu)
+                x = batch_norm_relu(x, m, relu, stats)
+                stats = None
                 i += 2 if relu else 1
-            elif isinstance(m, nn.Linear):
-                x = tall_linear(x, m)
-                i += 1
-            elif type(m) in (nn.Conv1d, nn.Conv2d):
-                x = conv1x1(x, m)
+                continue
+            stats = None
+            if isinstance(m, nn.Linear) or type(m) in (nn.Conv1d, nn.Conv2d):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                want = isinstance(nxt, _BN) and nxt.training and nxt.num_features % 8 == 0 and nxt.num_features // 8 <= 256
+                y, st = rows_linear(x, m, want)
+                if y is not None:
+                    x, stats = y, st
+                else:
+                    kin = m.in_features if isinstance(m, nn.Linear) else m.in_channels
+                    if x.shape[1] != kin and x.shape[1] == _round8(kin):
+                        x = x[:, :kin]               # zero-padded channels (see _RowsGemm) the torch layer does not know about
+                    x = tall_linear(x, m) if isinstance(m, nn.Linear) else conv1x1(x, m)
                 i += 1
             else:
                 x = m(x)

@@ -97,6 +97,9 @@ class _GridCache:
 
 
 GRID_CACHE = _GridCache()
+# every ball-query kernel of libpdmssd_hip.so writes ALL nsample slots of every centre (an empty ball: zeros), so a caller
+# need not zero `idx` first; code written for the reference (which does, pointnet2_utils.py:218) works unchanged
+BALL_QUERY_DEFINES_EVERY_ROW = True
 SHARE_GRIDS = True   # False: every call builds its own grid (round 1's behaviour; A/B measurements)
 
 

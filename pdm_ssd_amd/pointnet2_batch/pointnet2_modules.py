@@ -138,12 +138,16 @@ class _PointnetSAModuleBase(nn.Module):
         packs = self._fused_packs(xyz, features)
         if packs is not None and all(pk.cout % 4 == 0 for pk in packs):
             return self._forward_fused(packs, xyz, features, new_xyz, idx_list)
-        if features is not None:
+        from .. import fused_bn
+        rows_path = (CHANNELS_LAST_TRAINING and fused_bn.ENABLED and fused_bn.ROWS_GEMM and xyz.is_cuda
+                     and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+        if features is not None and not rows_path:
             features = features.contiguous()
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             if CHANNELS_LAST_TRAINING and isinstance(grouper, pointnet2_utils.QueryAndGroup):
                 grouper.channels_last = True   # the grouped tensor is born NHWC (bf16 under autocast): no copies
+                grouper.pad_to_8 = rows_path   # 16-byte rows for the bf16 MFMA layers (zero channels up to a multiple of 8)
             x = grouper(xyz, new_xyz, features)
             if CHANNELS_LAST_TRAINING:
                 x = x.contiguous(memory_format=torch.channels_last)
@@ -157,6 +161,10 @@ class _PointnetSAModuleBase(nn.Module):
             else:
                 raise NotImplementedError
             pooled.append(x.squeeze(-1))
+        if rows_path and all(p.dim() == 3 and p.transpose(1, 2).is_contiguous() for p in pooled):
+            # every scale's pooled output is a (B, C, M) view of point-major (B, M, C) storage: concatenate THERE, so the result
+            # is again such a view — the next level's grouping and the FP modules read rows without a transposing copy
+            return new_xyz, torch.cat([p.transpose(1, 2) for p in pooled], dim=2).transpose(1, 2)
         return new_xyz, torch.cat(pooled, dim=1)
 
 

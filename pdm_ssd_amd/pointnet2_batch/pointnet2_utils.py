@@ -242,7 +242,10 @@ class BallQuery(Function):
         xyz, new_xyz = xyz.float(), new_xyz.float()
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
-        idx = _new(xyz, (B, npoint, nsample), torch.int32, fill=0)
+        # the reference zero-fills idx here (ref :218) because its kernel leaves the rows of empty balls untouched; this
+        # library's kernels write those all-zero rows themselves (pointnet2_batch_hip.BALL_QUERY_DEFINES_EVERY_ROW), so
+        # the fill pass — a launch per call — is not needed for the same result
+        idx = _new(xyz, (B, npoint, nsample), torch.int32, fill=None if pointnet2.BALL_QUERY_DEFINES_EVERY_ROW else 0)
         pointnet2.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
         ctx.mark_non_differentiable(idx)
         return idx
@@ -290,48 +293,52 @@ class _FusedQueryAndGroup(Function):
 
 class _FusedQueryAndGroupCL(Function):
     """_FusedQueryAndGroup with the result in channels-last memory, bf16 when `out_bf16` (autocast): the logical
-    (B, 3+C, M, ns) tensor the reference returns, stored as (B, M, ns, 3+C) — what the NHWC convolutions of the training
-    path consume, without the layout copy and the dtype copy over the largest tensor of the step.  Values: the fp32
-    result, rounded to nearest even when bf16 (= what the autocast cast produces).  Gradient to `features` only."""
+    (B, 3+C, M, ns) tensor the reference returns, stored as (B, M, ns, ld) — what the rows kernels of the training path
+    consume (csrc/train_gemm.hip), without the layout copy and the dtype copy over the largest tensor of the step.  Values:
+    the fp32 result, rounded to nearest even when bf16 (= what the autocast cast produces).  Gradient to `features` only.
+    pad_to_8: ld = 3 + C rounded up to a multiple of 8 (16-byte bf16 rows) and the returned tensor HAS ld channels, the
+    extra ones zero — by contract with fused_bn.rows_linear, whose first layer meets them with zero weight columns."""
 
     @staticmethod
     @torch.amp.custom_fwd(**_FP32_FWD)
-    def forward(ctx, radius, nsample, xyz, new_xyz, features, out_bf16):
+    def forward(ctx, radius, nsample, xyz, new_xyz, features, out_bf16, pad_to_8=False):
         from .. import _native
         B, N, _ = xyz.size()
         M = new_xyz.size(1)
         C = 0 if features is None else features.size(1)
+        ld = (3 + C + 7) // 8 * 8 if pad_to_8 else 3 + C
         idx = ball_query(radius, nsample, xyz, new_xyz)
         feat_pm = None if features is None else features.transpose(1, 2).contiguous()
-        out = torch.empty((B, M, nsample, 3 + C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=xyz.device)
-        _native.call("pdm_group_concat_cl", torch.cuda.current_stream(xyz.device).cuda_stream, B, N, M, C, nsample,
+        out = torch.empty((B, M, nsample, ld), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=xyz.device)
+        _native.call("pdm_group_concat_cl_ld", torch.cuda.current_stream(xyz.device).cuda_stream, B, N, M, C, nsample,
                      xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat_pm is None else feat_pm.data_ptr(), idx.data_ptr(),
-                     out.data_ptr(), 1 if out_bf16 else 0)
-        ctx.for_backwards = (idx, N, C)
+                     out.data_ptr(), 1 if out_bf16 else 0, ld)
+        ctx.for_backwards = (idx, N, C, ld)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
-        idx, N, C = ctx.for_backwards
+        idx, N, C, ld = ctx.for_backwards
         if C == 0 or not ctx.needs_input_grad[4]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         from .. import _native
         B, _, M, ns = grad_out.size()
         if N > 16384 or grad_out.dtype not in (torch.float32, torch.bfloat16):
-            g = grad_out[:, 3:].float().contiguous()
+            g = grad_out[:, 3:3 + C].float().contiguous()
             grad_features = _new(grad_out, (B, C, N), torch.float32, fill=0)
             pointnet2.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
-            return None, None, None, None, grad_features, None
-        g = grad_out.permute(0, 2, 3, 1)          # (B, M, ns, 3+C): a view when the gradient arrives channels-last
+            return None, None, None, None, grad_features, None, None
+        g = grad_out.permute(0, 2, 3, 1)          # (B, M, ns, ld): a view when the gradient arrives channels-last
         if not g.is_contiguous():
             g = g.contiguous()
         grad_pm = torch.empty((B, N, C), dtype=torch.float32, device=grad_out.device)
         nbytes = _native.lib().pdm_group_concat_cl_grad_ws_bytes(B, N, M, ns)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=grad_out.device)
-        _native.call("pdm_group_concat_cl_grad", torch.cuda.current_stream(grad_out.device).cuda_stream, B, N, M, C, ns,
-                     g.data_ptr(), 1 if g.dtype == torch.bfloat16 else 0, idx.data_ptr(), grad_pm.data_ptr(), ws.data_ptr(), nbytes)
-        return None, None, None, None, grad_pm.transpose(1, 2).contiguous(), None
+        _native.call("pdm_group_concat_cl_grad_ld", torch.cuda.current_stream(grad_out.device).cuda_stream, B, N, M, C, ns,
+                     g.data_ptr(), 1 if g.dtype == torch.bfloat16 else 0, ld, idx.data_ptr(), grad_pm.data_ptr(), ws.data_ptr(), nbytes)
+        # (B, C, N) view of point-major storage: the source features of the training path are themselves such views
+        return None, None, None, None, grad_pm.transpose(1, 2), None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -342,16 +349,22 @@ class QueryAndGroup(nn.Module):
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.fused = fused
         self.channels_last = False   # True: the result is stored (B, M, ns, 3+C), bf16 under autocast (training path)
+        self.pad_to_8 = False        # with channels_last: the tensor gets round8(3+C) channels, the extra ones zero
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
         """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) -> (B, 3+C, npoint, nsample)."""
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        rows_feat = features is not None and features.dim() == 3 and features.transpose(1, 2).is_contiguous()
+        if self.fused and self.use_xyz and xyz.is_contiguous() and new_xyz.is_contiguous() and self.channels_last and rows_feat:
+            # features arrive as a (B, C, N) view of point-major storage: exactly what the channels-last kernel reads
+            bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            return _FusedQueryAndGroupCL.apply(self.radius, self.nsample, xyz, new_xyz, features, bf16, bool(self.pad_to_8 and bf16))
         if self.fused and self.use_xyz and xyz.is_contiguous() and new_xyz.is_contiguous() and (
                 features is None or features.is_contiguous()):
             if self.channels_last:   # set by the SA module on its training path
                 bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-                return _FusedQueryAndGroupCL.apply(self.radius, self.nsample, xyz, new_xyz, features, bf16)
+                return _FusedQueryAndGroupCL.apply(self.radius, self.nsample, xyz, new_xyz, features, bf16, bool(self.pad_to_8 and bf16))
             return _FusedQueryAndGroup.apply(self.radius, self.nsample, xyz, new_xyz, features)
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)

@@ -42,6 +42,20 @@ def pack_weight(w, transposed=False, pad_to=None):
     return out
 
 
+def pack_weight_into(w, out, transposed=False):
+    """the same into the top-left block of an existing bf16 matrix `out` (rows >= N or K, row stride = out.stride(0)); what
+    lies outside the block is left as it is (callers that need zero padding allocate zeros)"""
+    assert w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    w = w.detach().contiguous()
+    N, K = w.shape
+    assert out.shape[0] >= (K if transposed else N) and out.shape[1] >= (N if transposed else K)
+    ld = out.stride(0)
+    # the kernel writes ld columns per row: rows of the block are rewritten whole (pad columns zero)
+    _native.call("pdm_tg_pack_weight", _stream(w), N, K, w.data_ptr(), 0 if transposed else out.data_ptr(), 0 if transposed else ld,
+                 out.data_ptr() if transposed else 0, ld if transposed else 0)
+    return out
+
+
 def gemm_nt(x, w, bias=None, stats=False, out=None):
     """x (R, K) bf16 rows (row stride a multiple of 8), w (N, K') bf16 with K' >= K zero padded -> y (R, N) bf16 =
     x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the per-row-tile column sums
