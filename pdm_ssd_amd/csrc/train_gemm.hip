@@ -11,8 +11,9 @@
 // far under the bf16 MFMA ridge), so the kernels are built around full-line coalesced 16-byte traffic and LDS-staged
 // fragments, not around MFMA occupancy:
 //   tg_nt_kernel     Y[R,N]  = X[R,K] . W[N,K]^T   (forward; data gradient with the transposed weights)
-//                    128 x 128 output tile per 256-thread workgroup, K in steps of 64 through ONE 32 KB LDS stage with the
-//                    next step's 16-byte loads already in registers (4 workgroups per CU overlap each other's latency);
+//                    128 x 128 (wide layers) or 256 x 64 / 256 x 32 (narrow ones) output tile per 256-thread workgroup, K in
+//                    steps of 64 through ONE LDS stage with the next step's 16-byte loads already in registers (3 - 4
+//                    workgroups per CU overlap each other's latency);
 //                    A / B fragments by ds_read_b128 from XOR-swizzled 128-byte rows (conflict-free);
 //                    v_mfma_f32_32x32x16_bf16, fp32 accumulation; the epilogue rounds to bf16 (RNE), transposes through
 //                    LDS and stores whole 256-byte row pieces; optionally it also leaves per-column sums of y and y^2 of
@@ -33,7 +34,7 @@ typedef short tg_s16x8 __attribute__((ext_vector_type(8)));
 typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TG_T = 256;
-constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 64;
+constexpr int TG_BK = 64;
 constexpr int TG_WR = 64;            // rows per stage of the weight-gradient kernel
 constexpr int TG_WPITCH = 320;       // bytes per LDS row there: 256 of data + 64 of pad (transposed reads conflict-free)
 
@@ -60,74 +61,97 @@ struct TgNtArgs {
 // (half, chunk) slots
 __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// Tile shapes (4 waves, each 64 rows x JT * 32 columns): WN x JT = 2 x 2 -> 128 rows x 128 columns (wide layers),
+// 1 x 2 -> 256 x 64, 1 x 1 -> 256 x 32 (the narrow first SA levels: no MFMA work and no LDS traffic on absent columns,
+// twice the rows per workgroup behind one latency chain).
+template <int WN, int JT>
 __global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[32768 + 4096];
-    unsigned char *Xs = smem, *Ws = smem + 16384;
+    constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
+    constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
+    constexpr int XI = BM * 8 / TG_T, WI = (BN * 8 + TG_T - 1) / TG_T;   // 16-byte chunks per thread
+    constexpr int CH = BN / 8;                                   // 16-byte chunks per output row
+    constexpr int YB = BM * BN * 2;
+    constexpr int MAIN = (XB + WB) > YB ? (XB + WB) : YB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 4 * BN * 2 * 4];
+    unsigned char *Xs = smem, *Ws = smem + XB;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ncol = (a.N + TG_BN - 1) / TG_BN;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+    const int ncol = (a.N + BN - 1) / BN;
     const long long row_tile = blockIdx.x / ncol;
     const int col_tile = blockIdx.x % ncol;
-    const long long row0 = row_tile * TG_BM;
-    const int col0 = col_tile * TG_BN;
+    const long long row0 = row_tile * BM;
+    const int col0 = col_tile * BN;
     const int nk = (a.K + TG_BK - 1) / TG_BK;
 
-    uint4 xr[4], wr[4];
+    uint4 xr[XI], wr[WI];
     auto load = [&](int kt) {
         const int k0 = kt * TG_BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XI; ++i) {
             const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
             const int k = k0 + chunk * 8;
             const long long r = row0 + row;
             xr[i] = (r < a.R && k < a.K) ? *reinterpret_cast<const uint4 *>(a.X + r * a.ldx + k) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+            const int k = k0 + chunk * 8;
             const int n = col0 + row;
-            wr[i] = (n < a.N && k < a.K) ? *reinterpret_cast<const uint4 *>(a.W + (long long)n * a.ldw + k) : make_uint4(0, 0, 0, 0);
+            wr[i] = (row < BN && n < a.N && k < a.K) ? *reinterpret_cast<const uint4 *>(a.W + (long long)n * a.ldw + k) : make_uint4(0, 0, 0, 0);
         }
     };
-    tg_f32x16 acc[2][2];
+    tg_f32x16 acc[2][JT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XI; ++i) {
             const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
             *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = xr[i];
-            *reinterpret_cast<uint4 *>(Ws + tg_off(row, chunk)) = wr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+            if (row < BN) *reinterpret_cast<uint4 *>(Ws + tg_off(row, chunk)) = wr[i];
         }
         __syncthreads();
         if (kt + 1 < nk) load(kt + 1);     // in flight behind the MFMAs of this step
-#pragma unroll
-        for (int s = 0; s < TG_BK / 16; ++s) {
+        const int rem = a.K - kt * TG_BK;
+        const int ksteps = rem >= TG_BK ? TG_BK / 16 : (rem + 15) / 16;   // 16-deep steps that hold data (K = 8: one, not four)
+        for (int s = 0; s < ksteps; ++s) {
             const int chunk = 2 * s + (lane >> 5);
-            tg_bf16x8 af[2], bf[2];
+            tg_bf16x8 af[2], bf[JT];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + (lane & 31);
                 af[i] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Xs + tg_off(row, chunk)));
-                const int n = wn * 64 + i * 32 + (lane & 31);
-                bf[i] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Ws + tg_off(n, chunk)));
+            }
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int n = wn * JT * 32 + j * 32 + (lane & 31);
+                bf[j] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Ws + tg_off(n, chunk)));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < JT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // ---- epilogue: bf16 (RNE) through an LDS tile [128][128] (256-byte rows), then whole row pieces to memory
+    // ---- epilogue: bf16 (RNE) through an LDS tile [BM][BN], then whole row pieces (16-byte chunks, a row = CH of them) to memory
     unsigned short *Ys = reinterpret_cast<unsigned short *>(smem);
-    float *red = reinterpret_cast<float *>(smem + 32768);          // [4 waves][128 columns] x {sum, sum of squares} halves
+    float *red = reinterpret_cast<float *>(smem + MAIN);           // [4 waves][BN columns] sums, then the same of squares
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < JT; ++j) {
+        const int col = wn * JT * 32 + j * 32 + (lane & 31);
         float bv = 0.f;
         if (a.bias && col0 + col < a.N) bv = tg_f32(tg_bf16(a.bias[col0 + col]));
 #pragma unroll
@@ -135,18 +159,19 @@ __global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ys[row * 128 + col] = tg_bf16(acc[i][j][r] + bv);
+                Ys[row * BN + col] = tg_bf16(acc[i][j][r] + bv);
             }
     }
     __syncthreads();
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    const int chunk = t & 15;
+    constexpr int RPP = TG_T / CH;               // rows per pass of the workgroup
+    const int chunk = t % CH;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (t >> 4) + 16 * i;
-        const uint4 v = *reinterpret_cast<const uint4 *>(smem + row * 256 + chunk * 16);
+    for (int i = 0; i < BM / RPP; ++i) {
+        const int row = t / CH + RPP * i;
+        const uint4 v = *reinterpret_cast<const uint4 *>(smem + row * (BN * 2) + chunk * 16);
         const long long r = row0 + row;
         const int n = col0 + chunk * 8;
         if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
@@ -160,23 +185,26 @@ __global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
             }
         }
     }
-    if (a.stats) {   // rows beyond R were staged as zeros: they add nothing
+    if (a.stats) {   // rows beyond R were staged as zeros: they add nothing.  Lanes with equal t % CH hold the same columns.
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            s1[e] += __shfl_xor(s1[e], 16, 64); s2[e] += __shfl_xor(s2[e], 16, 64);
-            s1[e] += __shfl_xor(s1[e], 32, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
+#pragma unroll
+            for (int off = CH; off < 64; off <<= 1) {
+                s1[e] += __shfl_xor(s1[e], off, 64);
+                s2[e] += __shfl_xor(s2[e], off, 64);
+            }
         }
-        if (lane < 16) {
+        if (lane < CH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                red[wave * 128 + chunk * 8 + e] = s1[e];
-                red[512 + wave * 128 + chunk * 8 + e] = s2[e];
+                red[wave * BN + chunk * 8 + e] = s1[e];
+                red[4 * BN + wave * BN + chunk * 8 + e] = s2[e];
             }
         }
         __syncthreads();
-        if (t < 128 && col0 + t < a.N) {
-            const float sa = ((red[t] + red[128 + t]) + red[256 + t]) + red[384 + t];
-            const float sb = ((red[512 + t] + red[640 + t]) + red[768 + t]) + red[896 + t];
+        if (t < BN && col0 + t < a.N) {
+            const float sa = ((red[t] + red[BN + t]) + red[2 * BN + t]) + red[3 * BN + t];
+            const float sb = ((red[4 * BN + t] + red[5 * BN + t]) + red[6 * BN + t]) + red[7 * BN + t];
             float *o = a.stats + (row_tile * a.N + col0 + t) * 2;
             o[0] = sa; o[1] = sb;
         }
@@ -277,14 +305,39 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
         }
 }
 
-// dW[e] (+)= sum over the slabs, in slab order
-__global__ __launch_bounds__(256) void tg_slab_sum_kernel(const float *__restrict__ partial, int slabs, long long elems, float *__restrict__ dW,
-                                                          int accumulate) {
+// out[c][e] = sum of in[c * TG_FOLD + k][e], k < TG_FOLD (in order): one level of a fixed-shape summation tree over the leading
+// dimension (slabs of the weight gradient, row tiles of the BatchNorm statistics).  A single thread per element walking
+// thousands of slabs was a 200 us latency chain per layer; a level of this tree is one coalesced pass over its input.
+constexpr int TG_FOLD = 32;
+__global__ __launch_bounds__(256) void tg_fold_kernel(const float *__restrict__ in, int parts, long long elems, float *__restrict__ out,
+                                                      int accumulate) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
-    float s = accumulate ? dW[e] : 0.f;
-    for (int k = 0; k < slabs; ++k) s += partial[(long long)k * elems + e];
-    dW[e] = s;
+    const int k0 = blockIdx.y * TG_FOLD, k1 = k0 + TG_FOLD < parts ? k0 + TG_FOLD : parts;
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += in[(long long)k * elems + e];
+    float *o = out + (long long)blockIdx.y * elems + e;
+    *o = accumulate ? *o + s : s;
+}
+
+// folds in[parts][elems] down to out[elems] (accumulate: out += ...) through scratch (>= ceil(parts / TG_FOLD) * elems floats)
+static int tg_fold(hipStream_t stream, const float *in, int parts, long long elems, float *out, int accumulate, float *scratch) {
+    const unsigned gx = (unsigned)((elems + 255) / 256);
+    float *bufs[2] = {scratch, scratch + (long long)((parts + TG_FOLD - 1) / TG_FOLD) * elems};
+    int which = 0;
+    while (parts > TG_FOLD) {
+        const int np = (parts + TG_FOLD - 1) / TG_FOLD;
+        hipLaunchKernelGGL(tg_fold_kernel, dim3(gx, (unsigned)np), dim3(256), 0, stream, in, parts, elems, bufs[which], 0);
+        in = bufs[which];
+        which ^= 1;
+        parts = np;
+    }
+    hipLaunchKernelGGL(tg_fold_kernel, dim3(gx, 1), dim3(256), 0, stream, in, parts, elems, out, accumulate);
+    return check_launch("tg_fold");
+}
+static size_t tg_fold_scratch_floats(long long parts, long long elems) {
+    const long long l1 = (parts + TG_FOLD - 1) / TG_FOLD, l2 = (l1 + TG_FOLD - 1) / TG_FOLD;
+    return (size_t)((l1 + l2) * elems);
 }
 
 // W (N, K) fp32 -> Wb (N, ldb) bf16 and / or Wt (K, ldt) bf16 (transposed), zero padded to the strides
@@ -307,33 +360,55 @@ static inline bool tg_al16(const void *p) { return (reinterpret_cast<uintptr_t>(
 
 using namespace pdm;
 
-extern "C" int pdm_tg_row_tiles(long long rows) { return (int)((rows + TG_BM - 1) / TG_BM); }
+// tile shape by output width (see tg_nt_kernel): rows per workgroup
+static inline int tg_bm_for(int N) { return N <= 64 ? 256 : 128; }
+static inline int tg_bn_for(int N) { return N <= 32 ? 32 : N <= 64 ? 64 : 128; }
+
+// floats of scratch pdm_tg_gemm_nt needs when it is asked for statistics (per-row-tile sums + the levels of the fold tree)
+extern "C" size_t pdm_tg_stats_scratch_floats(long long rows, int N) {
+    if (rows <= 0 || N <= 0) return 0;
+    const long long tiles = (rows + tg_bm_for(N) - 1) / tg_bm_for(N);
+    return (size_t)(tiles * 2 * N) + tg_fold_scratch_floats(tiles, 2ll * N);
+}
 
 // Y (R, N) bf16 = X (R, K) bf16 . W (N, K)^T bf16 [+ bias], fp32 accumulation, one rounding.  Strides in elements, multiples
-// of 8; K and N multiples of 8; pointers 16-byte aligned.  stats: null or [pdm_tg_row_tiles(R)][N][2] fp32.
+// of 8; K and N multiples of 8; pointers 16-byte aligned.  stats: null, or (N, 2) fp32 = the column sums of y and y^2 over ALL
+// rows (of the rounded outputs), folded from per-tile sums in a fixed order through stats_scratch
+// (pdm_tg_stats_scratch_floats(R, N) floats).
 extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
-                              void *Y, long long ldy, const float *bias, float *stats) {
+                              void *Y, long long ldy, const float *bias, float *stats, float *stats_scratch) {
     PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_gemm_nt: negative size");
     if (R == 0 || N == 0) return 0;
-    PDM_REQUIRE(X && W && Y, PDM_E_BADARG, "tg_gemm_nt: null pointer");
+    PDM_REQUIRE(X && W && Y && (!stats || stats_scratch), PDM_E_BADARG, "tg_gemm_nt: null pointer");
     PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldw >= K && ldy >= N,
                 PDM_E_BADARG, "tg_gemm_nt: K=%d N=%d ldx=%lld ldw=%lld ldy=%lld must be multiples of 8 and cover the rows", K, N, ldx, ldw, ldy);
     PDM_REQUIRE(tg_al16(X) && tg_al16(W) && tg_al16(Y), PDM_E_BADARG, "tg_gemm_nt: operands must be 16-byte aligned");
-    const long long tiles = ((R + TG_BM - 1) / TG_BM) * ((N + TG_BN - 1) / TG_BN);
+    const int bm = tg_bm_for(N), bn = tg_bn_for(N);
+    const long long row_tiles = (R + bm - 1) / bm;
+    const long long tiles = row_tiles * ((N + bn - 1) / bn);
     PDM_REQUIRE(tiles <= 0x7fffffffll, PDM_E_TOOLARGE, "tg_gemm_nt: %lld tiles", tiles);
     TgNtArgs a;
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
-    a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.R = R; a.K = K; a.N = N;
-    hipLaunchKernelGGL(tg_nt_kernel, dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
-    return check_launch("tg_gemm_nt");
+    a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats ? stats_scratch : nullptr; a.R = R; a.K = K; a.N = N;
+    if (bn == 32) hipLaunchKernelGGL((tg_nt_kernel<1, 1>), dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
+    else if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<1, 2>), dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((tg_nt_kernel<2, 2>), dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
+    int rc = check_launch("tg_gemm_nt");
+    if (rc || !stats) return rc;
+    PDM_REQUIRE(row_tiles <= 0x7fffffffll, PDM_E_TOOLARGE, "tg_gemm_nt: %lld row tiles", row_tiles);
+    return tg_fold(as_stream(stream), stats_scratch, (int)row_tiles, 2ll * N, stats, 0, stats_scratch + row_tiles * 2 * N);
 }
 
-extern "C" size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N) {
-    if (R <= 0 || K <= 0 || N <= 0) return 0;
+static long long tg_wgrad_slabs(long long R, int K, int N) {
     long long slabs = (R + 1023) / 1024;
     const long long cap = (24ll << 20) / ((long long)N * K * 4);
     if (slabs > cap) slabs = cap < 1 ? 1 : cap;
-    return (size_t)slabs * N * K * sizeof(float);
+    return slabs < 1 ? 1 : slabs;
+}
+extern "C" size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N) {
+    if (R <= 0 || K <= 0 || N <= 0) return 0;
+    const long long slabs = tg_wgrad_slabs(R, K, N);
+    return ((size_t)slabs * N * K + tg_fold_scratch_floats(slabs, (long long)N * K)) * sizeof(float);
 }
 
 // dW (N, K) fp32 (+)= dY (R, N)^T bf16 . X (R, K) bf16, fp32 accumulation; workspace of pdm_tg_wgrad_ws_bytes(R, K, N) bytes.
@@ -355,7 +430,7 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     PDM_REQUIRE(tg_al16(dY) && tg_al16(X) && tg_al16(workspace), PDM_E_BADARG, "tg_wgrad: operands must be 16-byte aligned");
     PDM_REQUIRE(workspace_bytes >= pdm_tg_wgrad_ws_bytes(R, K, N), PDM_E_BADARG, "tg_wgrad: workspace of %zu bytes, need %zu",
                 workspace_bytes, pdm_tg_wgrad_ws_bytes(R, K, N));
-    const long long slabs = (long long)(pdm_tg_wgrad_ws_bytes(R, K, N) / ((size_t)N * K * sizeof(float)));
+    const long long slabs = tg_wgrad_slabs(R, K, N);
     long long rps = (R + slabs - 1) / slabs;
     rps = (rps + TG_WR - 1) / TG_WR * TG_WR;
     const long long used = (R + rps - 1) / rps;
@@ -368,9 +443,7 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     int rc = check_launch("tg_wgrad");
     if (rc) return rc;
     const long long elems = (long long)N * K;
-    hipLaunchKernelGGL(tg_slab_sum_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, as_stream(stream), a.partial, (int)used, elems, dW,
-                       accumulate);
-    return check_launch("tg_wgrad(sum)");
+    return tg_fold(as_stream(stream), a.partial, (int)used, elems, dW, accumulate, a.partial + slabs * elems);
 }
 
 // W (N, K) fp32 -> bf16 copies: Wb (N, ldb) row-major and / or Wt (K, ldt) transposed (either may be null); pad columns zero.

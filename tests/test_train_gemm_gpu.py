@@ -18,7 +18,8 @@ def ints(shape, lo, hi, seed, dev):
 
 
 @pytest.mark.parametrize("R,K,N,ldx", [(1000, 64, 32, 64), (300, 72, 200, 80), (129, 8, 8, 8), (4096, 1536, 512, 1536),
-                                        (20000, 128, 128, 128), (77, 200, 136, 208)])
+                                        (20000, 128, 128, 128), (77, 200, 136, 208), (70000, 8, 16, 8), (9000, 104, 64, 104),
+                                        (513, 32, 48, 32), (255, 16, 24, 16)])   # all three tile shapes: N <= 32, <= 64, wider
 def test_gemm_nt_exact_on_integer_data(dev, R, K, N, ldx):
     xs = torch.zeros((R, ldx), dtype=torch.bfloat16, device=dev)
     xs[:, :K] = ints((R, K), -4, 4, 1, dev).bfloat16()
