@@ -426,13 +426,13 @@ int pdm_sample_points(void *stream, int B, int num_points, unsigned seed, int C,
  * pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:91-97 and models/dense_heads/point_head_template.py:35-48)
  * over channels-last rows: bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, ONE rounding of the result.
  * All strides in elements and multiples of 8, K and N multiples of 8, pointers 16-byte aligned. */
-/* Y (R, N) bf16 = X (R, K) . W (N, K)^T [+ bias (N) fp32, rounded to bf16 first].  stats: null, or (N, 2) fp32 = the column
- * sums of y and y^2 of the ROUNDED outputs over all rows (BatchNorm statistics without another pass over Y), folded from
- * per-row-tile sums in a fixed order through stats_scratch (pdm_tg_stats_scratch_floats(R, N) floats).  The data gradient is
- * the same call on the transposed weights. */
-size_t pdm_tg_stats_scratch_floats(long long rows, int N);
+/* Y (R, N) bf16 = X (R, K) . W (N, K)^T [+ bias (N) fp32, rounded to bf16 first].  stats: null, or
+ * (pdm_tg_stats_parts(R, N), N, 2) fp32 = per persistent slot the column sums of y and y^2 of the ROUNDED outputs (BatchNorm
+ * statistics without another pass over Y; pdm_bn_relu_forward_stats folds the parts).  The data gradient is the same call on
+ * the transposed weights. */
+int pdm_tg_stats_parts(long long rows, int N);
 int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
-                   void *Y, long long ldy, const float *bias, float *stats, float *stats_scratch);
+                   void *Y, long long ldy, const float *bias, float *stats);
 size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N);
 /* dW (N, K) fp32 (+)= dY (R, N)^T . X (R, K): row slabs summed in a fixed order (bit-reproducible) */
 int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,

@@ -64,27 +64,35 @@ __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + (
 // Tile shapes (4 waves, each 64 rows x JT * 32 columns): WN x JT = 2 x 2 -> 128 rows x 128 columns (wide layers),
 // 1 x 2 -> 256 x 64, 1 x 1 -> 256 x 32 (the narrow first SA levels: no MFMA work and no LDS traffic on absent columns,
 // twice the rows per workgroup behind one latency chain).
+// PERSISTENT over row tiles: workgroup (slot, column tile) walks row tiles slot, slot + slots, ...; the next tile's first
+// loads are requested before this tile's epilogue, the weights of a single-step contraction (K <= 64) are staged once, and
+// the BatchNorm sums stay in registers until the end — one partial per slot (<= 1024: what the BatchNorm finalize kernel
+// folds itself), no per-tile partials.
+// The product is formed TRANSPOSED (D = W_tile . X_tile^T): a lane then owns one output ROW and, per 4 accumulator
+// registers, 4 CONSECUTIVE channels — 8 bytes of bf16, one ds_write_b64 — where the direct form had 16 scattered 2-byte LDS
+// writes per 32 x 32 tile (the epilogue's LDS writes alone were 1.7x the HBM time of a narrow tile).
 template <int WN, int JT>
-__global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
+__global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
     constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
     constexpr int XI = BM * 8 / TG_T, WI = (BN * 8 + TG_T - 1) / TG_T;   // 16-byte chunks per thread
     constexpr int CH = BN / 8;                                   // 16-byte chunks per output row
-    constexpr int YB = BM * BN * 2;
+    constexpr int YP = BN * 2 + 16;                              // pitch of the epilogue tile (8-byte writes down a column of rows)
+    constexpr int YB = BM * YP;
     constexpr int MAIN = (XB + WB) > YB ? (XB + WB) : YB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 4 * BN * 2 * 4];
     unsigned char *Xs = smem, *Ws = smem + XB;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int ncol = (a.N + BN - 1) / BN;
-    const long long row_tile = blockIdx.x / ncol;
     const int col_tile = blockIdx.x % ncol;
-    const long long row0 = row_tile * BM;
+    const int slot = blockIdx.x / ncol;
     const int col0 = col_tile * BN;
     const int nk = (a.K + TG_BK - 1) / TG_BK;
+    const long long row_tiles = (a.R + BM - 1) / BM;
 
     uint4 xr[XI], wr[WI];
-    auto load = [&](int kt) {
+    auto load_x = [&](long long row0, int kt) {
         const int k0 = kt * TG_BK;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -93,6 +101,9 @@ __global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
             const long long r = row0 + row;
             xr[i] = (r < a.R && k < a.K) ? *reinterpret_cast<const uint4 *>(a.X + r * a.ldx + k) : make_uint4(0, 0, 0, 0);
         }
+    };
+    auto load_w = [&](int kt) {
+        const int k0 = kt * TG_BK;
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
@@ -101,91 +112,109 @@ __global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
             wr[i] = (row < BN && n < a.N && k < a.K) ? *reinterpret_cast<const uint4 *>(a.W + (long long)n * a.ldw + k) : make_uint4(0, 0, 0, 0);
         }
     };
-    tg_f32x16 acc[2][JT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    load(0);
-    for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
-            *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = xr[i];
-        }
+    auto store_w = [&]() {
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
             if (row < BN) *reinterpret_cast<uint4 *>(Ws + tg_off(row, chunk)) = wr[i];
         }
-        __syncthreads();
-        if (kt + 1 < nk) load(kt + 1);     // in flight behind the MFMAs of this step
-        const int rem = a.K - kt * TG_BK;
-        const int ksteps = rem >= TG_BK ? TG_BK / 16 : (rem + 15) / 16;   // 16-deep steps that hold data (K = 8: one, not four)
-        for (int s = 0; s < ksteps; ++s) {
-            const int chunk = 2 * s + (lane >> 5);
-            tg_bf16x8 af[2], bf[JT];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + (lane & 31);
-                af[i] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Xs + tg_off(row, chunk)));
-            }
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                const int n = wn * JT * 32 + j * 32 + (lane & 31);
-                bf[j] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Ws + tg_off(n, chunk)));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < JT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: bf16 (RNE) through an LDS tile [BM][BN], then whole row pieces (16-byte chunks, a row = CH of them) to memory
-    unsigned short *Ys = reinterpret_cast<unsigned short *>(smem);
-    float *red = reinterpret_cast<float *>(smem + MAIN);           // [4 waves][BN columns] sums, then the same of squares
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const int col = wn * JT * 32 + j * 32 + (lane & 31);
-        float bv = 0.f;
-        if (a.bias && col0 + col < a.N) bv = tg_f32(tg_bf16(a.bias[col0 + col]));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ys[row * BN + col] = tg_bf16(acc[i][j][r] + bv);
-            }
-    }
-    __syncthreads();
+    };
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    constexpr int RPP = TG_T / CH;               // rows per pass of the workgroup
-    const int chunk = t % CH;
+    constexpr int RPP = TG_T / CH;               // rows per pass of the workgroup in the store phase
+    const int chunk_o = t % CH;
+
+    long long rt = slot;
+    if (rt < row_tiles) { load_x(rt * BM, 0); load_w(0); }
+    bool w_resident = false;                     // nk == 1: the weights stay in LDS across row tiles
+    for (; rt < row_tiles; rt += slots) {
+        const long long row0 = rt * BM;
+        tg_f32x16 acc[2][JT];
 #pragma unroll
-    for (int i = 0; i < BM / RPP; ++i) {
-        const int row = t / CH + RPP * i;
-        const uint4 v = *reinterpret_cast<const uint4 *>(smem + row * (BN * 2) + chunk * 16);
-        const long long r = row0 + row;
-        const int n = col0 + chunk * 8;
-        if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
-        if (a.stats) {
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                s1[2 * e] += lo; s2[2 * e] = fmaf(lo, lo, s2[2 * e]);
-                s1[2 * e + 1] += hi; s2[2 * e + 1] = fmaf(hi, hi, s2[2 * e + 1]);
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = xr[i];
+            }
+            if (!w_resident) store_w();
+            __syncthreads();
+            // the next loads travel behind the MFMAs (and, at the last step, behind this tile's epilogue)
+            if (kt + 1 < nk) { load_x(row0, kt + 1); load_w(kt + 1); }
+            else if (rt + slots < row_tiles) { load_x((rt + slots) * BM, 0); if (nk > 1) load_w(0); }
+            const int rem = a.K - kt * TG_BK;
+            const int ksteps = rem >= TG_BK ? TG_BK / 16 : (rem + 15) / 16;   // 16-deep steps that hold data (K = 8: one, not four)
+            for (int s = 0; s < ksteps; ++s) {
+                const int chunk = 2 * s + (lane >> 5);
+                tg_bf16x8 af[2], bf[JT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wm * 64 + i * 32 + (lane & 31);
+                    af[i] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Xs + tg_off(row, chunk)));
+                }
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const int n = wn * JT * 32 + j * 32 + (lane & 31);
+                    bf[j] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Ws + tg_off(n, chunk)));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < JT; ++j)   // D[n][r] = sum_k W[n][k] X[r][k]: the weights as the A operand
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: bf16 (RNE) into an LDS tile [BM][pitch YP]; lane = output row, 4 registers = 4 consecutive channels
+        if (nk == 1 && XB + WB <= MAIN && YB <= XB) w_resident = true;      // the epilogue tile does not reach the weight stage
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wn * JT * 32 + j * 32 + 8 * g + 4 * (lane >> 5);
+                    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) {   // only the heads' last layers carry one: fetched here (L2) rather than held in 16 JT registers
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col0 + col + e < a.N) b4[e] = tg_f32(tg_bf16(a.bias[col0 + col + e]));
+                    }
+                    uint2 v;
+                    v.x = (unsigned)tg_bf16(acc[i][j][4 * g] + b4[0]) | ((unsigned)tg_bf16(acc[i][j][4 * g + 1] + b4[1]) << 16);
+                    v.y = (unsigned)tg_bf16(acc[i][j][4 * g + 2] + b4[2]) | ((unsigned)tg_bf16(acc[i][j][4 * g + 3] + b4[3]) << 16);
+                    *reinterpret_cast<uint2 *>(smem + row * YP + col * 2) = v;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BM / RPP; ++i) {
+            const int row = t / CH + RPP * i;
+            const uint4 v = *reinterpret_cast<const uint4 *>(smem + row * YP + chunk_o * 16);
+            const long long r = row0 + row;
+            const int n = col0 + chunk_o * 8;
+            if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
+            if (a.stats) {   // rows beyond R were staged as zeros: they add nothing
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                    s1[2 * e] += lo; s2[2 * e] = fmaf(lo, lo, s2[2 * e]);
+                    s1[2 * e + 1] += hi; s2[2 * e + 1] = fmaf(hi, hi, s2[2 * e + 1]);
+                }
             }
         }
+        __syncthreads();
     }
-    if (a.stats) {   // rows beyond R were staged as zeros: they add nothing.  Lanes with equal t % CH hold the same columns.
+    if (a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
+        float *red = reinterpret_cast<float *>(smem + MAIN);       // [4 waves][BN columns] sums, then the same of squares
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -197,15 +226,15 @@ __global__ __launch_bounds__(TG_T) void tg_nt_kernel(TgNtArgs a) {
         if (lane < CH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                red[wave * BN + chunk * 8 + e] = s1[e];
-                red[4 * BN + wave * BN + chunk * 8 + e] = s2[e];
+                red[wave * BN + chunk_o * 8 + e] = s1[e];
+                red[4 * BN + wave * BN + chunk_o * 8 + e] = s2[e];
             }
         }
         __syncthreads();
         if (t < BN && col0 + t < a.N) {
             const float sa = ((red[t] + red[BN + t]) + red[2 * BN + t]) + red[3 * BN + t];
             const float sb = ((red[4 * BN + t] + red[5 * BN + t]) + red[6 * BN + t]) + red[7 * BN + t];
-            float *o = a.stats + (row_tile * a.N + col0 + t) * 2;
+            float *o = a.stats + ((long long)slot * a.N + col0 + t) * 2;
             o[0] = sa; o[1] = sb;
         }
     }
@@ -363,40 +392,40 @@ using namespace pdm;
 // tile shape by output width (see tg_nt_kernel): rows per workgroup
 static inline int tg_bm_for(int N) { return N <= 64 ? 256 : 128; }
 static inline int tg_bn_for(int N) { return N <= 32 ? 32 : N <= 64 ? 64 : 128; }
-
-// floats of scratch pdm_tg_gemm_nt needs when it is asked for statistics (per-row-tile sums + the levels of the fold tree)
-extern "C" size_t pdm_tg_stats_scratch_floats(long long rows, int N) {
-    if (rows <= 0 || N <= 0) return 0;
-    const long long tiles = (rows + tg_bm_for(N) - 1) / tg_bm_for(N);
-    return (size_t)(tiles * 2 * N) + tg_fold_scratch_floats(tiles, 2ll * N);
+// persistent slots (workgroups per column tile): every slot walks row tiles slot, slot + slots, ...
+static inline int tg_slots(long long rows, int N) {
+    const long long row_tiles = (rows + tg_bm_for(N) - 1) / tg_bm_for(N);
+    const int ncol = (N + tg_bn_for(N) - 1) / tg_bn_for(N);
+    long long s = 1024 / ncol;                       // ~4 workgroups per CU in all
+    if (s < 64) s = 64;
+    if (s > 1024) s = 1024;
+    return (int)(row_tiles < s ? row_tiles : s);
 }
 
+// statistics of pdm_tg_gemm_nt: (parts, N, 2) fp32, parts = pdm_tg_stats_parts(rows, N) <= 1024 — one partial per persistent slot
+extern "C" int pdm_tg_stats_parts(long long rows, int N) { return rows <= 0 || N <= 0 ? 0 : tg_slots(rows, N); }
+
 // Y (R, N) bf16 = X (R, K) bf16 . W (N, K)^T bf16 [+ bias], fp32 accumulation, one rounding.  Strides in elements, multiples
-// of 8; K and N multiples of 8; pointers 16-byte aligned.  stats: null, or (N, 2) fp32 = the column sums of y and y^2 over ALL
-// rows (of the rounded outputs), folded from per-tile sums in a fixed order through stats_scratch
-// (pdm_tg_stats_scratch_floats(R, N) floats).
+// of 8; K and N multiples of 8; pointers 16-byte aligned.  stats: null, or (pdm_tg_stats_parts(R, N), N, 2) fp32 = per slot the
+// column sums of y and y^2 of the ROUNDED outputs (pdm_bn_relu_forward_stats folds them in double, in slot order).
 extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
-                              void *Y, long long ldy, const float *bias, float *stats, float *stats_scratch) {
+                              void *Y, long long ldy, const float *bias, float *stats) {
     PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_gemm_nt: negative size");
     if (R == 0 || N == 0) return 0;
-    PDM_REQUIRE(X && W && Y && (!stats || stats_scratch), PDM_E_BADARG, "tg_gemm_nt: null pointer");
+    PDM_REQUIRE(X && W && Y, PDM_E_BADARG, "tg_gemm_nt: null pointer");
     PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldw >= K && ldy >= N,
                 PDM_E_BADARG, "tg_gemm_nt: K=%d N=%d ldx=%lld ldw=%lld ldy=%lld must be multiples of 8 and cover the rows", K, N, ldx, ldw, ldy);
     PDM_REQUIRE(tg_al16(X) && tg_al16(W) && tg_al16(Y), PDM_E_BADARG, "tg_gemm_nt: operands must be 16-byte aligned");
-    const int bm = tg_bm_for(N), bn = tg_bn_for(N);
-    const long long row_tiles = (R + bm - 1) / bm;
-    const long long tiles = row_tiles * ((N + bn - 1) / bn);
-    PDM_REQUIRE(tiles <= 0x7fffffffll, PDM_E_TOOLARGE, "tg_gemm_nt: %lld tiles", tiles);
+    const int bn = tg_bn_for(N);
+    const int slots = tg_slots(R, N);
+    const unsigned wgs = (unsigned)slots * (unsigned)((N + bn - 1) / bn);
     TgNtArgs a;
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
-    a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats ? stats_scratch : nullptr; a.R = R; a.K = K; a.N = N;
-    if (bn == 32) hipLaunchKernelGGL((tg_nt_kernel<1, 1>), dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
-    else if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<1, 2>), dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL((tg_nt_kernel<2, 2>), dim3((unsigned)tiles), dim3(TG_T), 0, as_stream(stream), a);
-    int rc = check_launch("tg_gemm_nt");
-    if (rc || !stats) return rc;
-    PDM_REQUIRE(row_tiles <= 0x7fffffffll, PDM_E_TOOLARGE, "tg_gemm_nt: %lld row tiles", row_tiles);
-    return tg_fold(as_stream(stream), stats_scratch, (int)row_tiles, 2ll * N, stats, 0, stats_scratch + row_tiles * 2 * N);
+    a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.R = R; a.K = K; a.N = N;
+    if (bn == 32) hipLaunchKernelGGL((tg_nt_kernel<1, 1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    else if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<1, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    else hipLaunchKernelGGL((tg_nt_kernel<2, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    return check_launch("tg_gemm_nt");
 }
 
 static long long tg_wgrad_slabs(long long R, int K, int N) {

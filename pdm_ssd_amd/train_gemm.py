@@ -58,18 +58,17 @@ def pack_weight_into(w, out, transposed=False):
 
 def gemm_nt(x, w, bias=None, stats=False, out=None):
     """x (R, K) bf16 rows (row stride a multiple of 8), w (N, K') bf16 with K' >= K zero padded -> y (R, N) bf16 =
-    x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the column sums over all rows,
-    (1, N, 2) fp32 (sum y, sum y^2 of the rounded y): one "part" for pdm_bn_relu_forward_stats."""
+    x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the column sums (parts, N, 2) fp32 (sum y,
+    sum y^2 of the rounded y, one part per persistent workgroup slot): what pdm_bn_relu_forward_stats takes."""
     R, K = x.shape
     N = w.shape[0]
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1
     y = torch.empty((R, N), dtype=torch.bfloat16, device=x.device) if out is None else out
-    st = scratch = None
+    st = None
     if stats:
-        st = torch.empty((1, N, 2), dtype=torch.float32, device=x.device)
-        scratch = torch.empty((max(_native.lib().pdm_tg_stats_scratch_floats(R, N), 4),), dtype=torch.float32, device=x.device)
+        st = torch.empty((_native.lib().pdm_tg_stats_parts(R, N), N, 2), dtype=torch.float32, device=x.device)
     _native.call("pdm_tg_gemm_nt", _stream(x), R, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
-                 0 if bias is None else bias.data_ptr(), 0 if st is None else st.data_ptr(), 0 if scratch is None else scratch.data_ptr())
+                 0 if bias is None else bias.data_ptr(), 0 if st is None else st.data_ptr())
     return (y, st) if stats else y
 
 
