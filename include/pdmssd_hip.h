@@ -421,6 +421,17 @@ int pdm_points_in_boxes(void *stream, int B, int T, int M, const float *boxes, c
 int pdm_sample_points(void *stream, int B, int num_points, unsigned seed, int C, const float *raw,
                       const int *counts, float *out, int *choice);
 
+/* ---- rows form of the FP module's input for the training path (csrc/interpolate.hip) --------------------------------
+ * out (B, n, ld) bf16 = [ three_interpolate(known, idx, weight) (C2) | skip (C1) | zeros ]: the reference's
+ * cat([interpolated, unknow_feats], dim=1) (pointnet2_modules.py:158-165) written once as the rows the bf16 layers read, each
+ * element the fp32 value (pinned fma order of pdm_three_interpolate) rounded to nearest even.  known (B, m, C2) and skip
+ * (B, n, C1) are point-major rows, fp32 or bf16.  Backward: dx (B, n, ld) bf16 -> dknown (B, m, C2) fp32 through an inverted
+ * (CSR) index, no atomics; the skip gradient is dx[..., C2 : C2 + C1].  workspace: pdm_three_interpolate_grad_ws_bytes(b, n, m). */
+int pdm_interp_concat_rows(void *stream, int b, int n, int m, int c2, int c1, int ld, const void *known, int known_bf16,
+                           const void *skip, int skip_bf16, const int *idx, const float *weight, void *out);
+int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
+                                const float *weight, float *dknown, void *workspace, size_t workspace_bytes);
+
 /* ---- bf16 contractions of the training path (csrc/train_gemm.hip) ---------------------------------------------------
  * The shared MLPs' 1x1 convolutions / Linear layers in TRAINING (reference: torch Conv2d / Linear inside
  * pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:91-97 and models/dense_heads/point_head_template.py:35-48)

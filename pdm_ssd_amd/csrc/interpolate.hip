@@ -337,6 +337,118 @@ int csr_scatter_grad_launch(void *stream, const char *who, int b, int c, int row
 }
 }  // namespace pdm
 
+// ---- rows form of the FP module's input (training path, csrc/train_gemm.hip consumes it) ------------------------------------
+// The reference forms cat([three_interpolate(known_feats, idx, weight), unknow_feats], dim=1) as a channel-major fp32 tensor
+// (pointnet2_modules.py:158-165) and hands it to the shared MLP.  Here the same values are written ONCE, as the bf16 rows
+// (B, n, ld) the MFMA layers read: [ interpolated (C2) | skip (C1) | zeros up to ld ], each element the fp32 value of the
+// reference expression (the pinned fma order of three_interpolate_kernel) rounded to nearest even — exactly what autocast's
+// cast of the concatenated fp32 tensor holds.  known (B, m, C2) and skip (B, n, C1) are point-major rows, fp32 or bf16.
+namespace pdm {
+
+__device__ __forceinline__ float icr_load(const void *p, size_t i, bool bf16) {
+    return bf16 ? __uint_as_float((unsigned)static_cast<const unsigned short *>(p)[i] << 16) : static_cast<const float *>(p)[i];
+}
+__device__ __forceinline__ unsigned short icr_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void interp_concat_rows_kernel(long long total, int n, int m, int c2, int c1, int ld,
+                                                                 const void *__restrict__ known, int known_bf16,
+                                                                 const void *__restrict__ skip, int skip_bf16,
+                                                                 const int *__restrict__ idx, const float *__restrict__ weight,
+                                                                 unsigned short *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / ld;                 // b * n + i
+        const int ch = (int)(e - row * ld);
+        float v = 0.0f;
+        if (ch < c2) {
+            const long long b = row / n;
+            const int *id = idx + row * 3;
+            const float *w = weight + row * 3;
+            const float p0 = icr_load(known, ((size_t)b * m + id[0]) * c2 + ch, known_bf16);
+            const float p1 = icr_load(known, ((size_t)b * m + id[1]) * c2 + ch, known_bf16);
+            const float p2 = icr_load(known, ((size_t)b * m + id[2]) * c2 + ch, known_bf16);
+            v = __fmaf_rn(w[2], p2, __fmaf_rn(w[1], p1, __fmul_rn(w[0], p0)));
+        } else if (ch < c2 + c1) {
+            v = icr_load(skip, (size_t)row * c1 + (ch - c2), skip_bf16);
+        }
+        out[e] = icr_bf16(v);
+    }
+}
+
+// d known[b, j, c] = sum over the CSR list of j of w * dx[b, i, c], c < C2: one wave per known point, lanes over channels,
+// every gradient row read contiguously, no atomics (fixed order: reproducible)
+__global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int c2, int ld, int ne, const unsigned short *__restrict__ dx,
+                                                               const int *__restrict__ start_all, const unsigned short *__restrict__ ej_all,
+                                                               const float *__restrict__ ew_all, float *__restrict__ dknown) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= m) return;
+    const int *__restrict__ start = start_all + (size_t)b * (m + 1);
+    const unsigned short *__restrict__ ej = ej_all + (size_t)b * ne;
+    const float *__restrict__ ew = ew_all + (size_t)b * ne;
+    const int s = start[j], e = start[j + 1];
+    for (int c0 = 0; c0 < c2; c0 += 64) {
+        const int ch = c0 + lane;
+        if (ch < c2) {
+            float acc = 0.0f;
+            for (int p = s; p < e; ++p)
+                acc = __fmaf_rn(ew[p], __uint_as_float((unsigned)dx[((size_t)b * n + ej[p]) * ld + ch] << 16), acc);
+            dknown[((size_t)b * m + j) * c2 + ch] = acc;
+        }
+    }
+}
+
+}  // namespace pdm
+
+// out (B, n, ld) bf16 = [ three_interpolate(known, idx, weight) | skip | 0 ], ld >= C2 + C1.  known (B, m, C2), skip (B, n, C1)
+// (may be null when C1 == 0) are point-major rows, fp32 or bf16 (known_bf16 / skip_bf16); idx, weight (B, n, 3).
+extern "C" int pdm_interp_concat_rows(void *stream, int b, int n, int m, int c2, int c1, int ld, const void *known, int known_bf16,
+                                      const void *skip, int skip_bf16, const int *idx, const float *weight, void *out) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c2 >= 0 && c1 >= 0 && ld >= c2 + c1, PDM_E_BADARG, "interp_concat_rows: bad size");
+    const long long total = (long long)b * n * ld;
+    if (total == 0) return 0;
+    PDM_REQUIRE(out && (c2 == 0 || (known && idx && weight && m >= 1)) && (c1 == 0 || skip), PDM_E_BADARG, "interp_concat_rows: null pointer");
+    const long long want = (total + 255) / 256;
+    const int blocks = (int)(want < 256 * 64 ? want : 256 * 64);
+    hipLaunchKernelGGL(interp_concat_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), total, n, m, c2, c1, ld, known, known_bf16,
+                       skip, skip_bf16, idx, weight, static_cast<unsigned short *>(out));
+    return check_launch("interp_concat_rows");
+}
+
+// Its backward towards the known features: dx (B, n, ld) bf16 -> dknown (B, m, C2) fp32, fully written.  The skip features'
+// gradient is the column block dx[..., C2 : C2 + C1] itself.  workspace: pdm_three_interpolate_grad_ws_bytes(b, n, m).
+extern "C" int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
+                                           const float *weight, float *dknown, void *workspace, size_t workspace_bytes) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c2 >= 0 && ld >= c2, PDM_E_BADARG, "interp_concat_rows_grad: bad size");
+    if (b == 0 || m == 0 || c2 == 0) return 0;
+    PDM_REQUIRE(dknown && workspace && (n == 0 || (dx && idx && weight)), PDM_E_BADARG, "interp_concat_rows_grad: null pointer");
+    PDM_REQUIRE(m <= 16384 && n <= 65535 && b <= 65535, PDM_E_TOOLARGE, "interp_concat_rows_grad: m=%d (<= 16384), n=%d (<= 65535)", m, n);
+    PDM_REQUIRE(workspace_bytes >= csr_workspace_bytes(b, 3ll * n, m), PDM_E_BADARG, "interp_concat_rows_grad: workspace of %zu bytes, need %zu",
+                workspace_bytes, csr_workspace_bytes(b, 3ll * n, m));
+    const int ne = 3 * n;
+    uintptr_t p = (reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15;
+    int *start = reinterpret_cast<int *>(p);
+    p += ((size_t)b * (m + 1) * sizeof(int) + 15) / 16 * 16;
+    unsigned short *ej = reinterpret_cast<unsigned short *>(p);
+    p += ((size_t)b * ne * sizeof(unsigned short) + 15) / 16 * 16;
+    float *ew = reinterpret_cast<float *>(p);
+    if ((size_t)m * sizeof(int) + 1024 > 64 * 1024) {
+        const int e = grant_lds(reinterpret_cast<const void *>(&interp_csr_build_kernel), 128 * 1024);
+        PDM_REQUIRE(e == 0, PDM_E_TOOLARGE, "interp_concat_rows_grad: cannot obtain %zu bytes of LDS", (size_t)m * sizeof(int));
+    }
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(TIC_THREADS), (size_t)m * sizeof(int), as_stream(stream), ne, 3, m, idx, weight,
+                       start, ej, ew);
+    int rc = check_launch("interp_concat_rows_grad(csr)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(interp_rows_grad_kernel, dim3((unsigned)((m + 3) / 4), (unsigned)b), dim3(256), 0, as_stream(stream), n, m, c2, ld, ne,
+                       static_cast<const unsigned short *>(dx), start, ej, ew, dknown);
+    return check_launch("interp_concat_rows_grad");
+}
+
 extern "C" size_t pdm_three_interpolate_grad_ws_bytes(int b, int n, int m) { return csr_workspace_bytes(b, 3ll * n, m); }
 
 // pdm_three_interpolate_grad with a caller-provided workspace (pdm_three_interpolate_grad_ws_bytes(b, n, m) bytes): the

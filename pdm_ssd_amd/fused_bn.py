@@ -137,9 +137,30 @@ def applies(x, bn):
             and x.dim() >= 2 and x.shape[1] == bn.num_features and _layout(x) is not None)
 
 
+def _padded_applies(x, bn):
+    """x carries bn.num_features channels rounded up to a multiple of 8, the extra ones ZERO (the rows layers keep 16-byte
+    rows that way, _RowsGemm): BatchNorm runs over the padded width with zero gamma / beta on the padding, which then
+    stays zero forward and backward."""
+    C = bn.num_features
+    return (ENABLED and bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32
+            and x.dim() >= 2 and C % 8 != 0 and x.shape[1] == _round8(C) and _layout(x) is not None)
+
+
 def batch_norm_relu(x, bn, relu=True, stats=None):
     """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch.
     stats: the column sums the producing GEMM took of x ([tiles][C][2], rows_linear(..., want_stats=True)) or None."""
+    if _padded_applies(x, bn):
+        C, Cp = bn.num_features, x.shape[1]
+        z = bn.weight.new_zeros(Cp - C)
+        rm, rv = torch.cat([bn.running_mean, z]), torch.cat([bn.running_var, z + 1.0])
+        layout, n, L = _layout(x)
+        y = _BnRelu.apply(x, torch.cat([bn.weight, z]), torch.cat([bn.bias, z]), rm, rv, bn.eps, bn.momentum, relu, layout, n, L,
+                          stats if layout == 0 else None)
+        with torch.no_grad():
+            bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
+            bn.num_batches_tracked += 1
+        return y
     if not applies(x, bn):
         y = bn(x)
         return torch.relu(y) if relu else y
@@ -167,7 +188,7 @@ class _RowsGemm(Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, want_stats):
+    def forward(ctx, x, weight, bias, want_stats, keep_pad=False):
         from . import train_gemm as tg
         xr = tg.row_view(x)
         assert xr is not None
@@ -188,7 +209,8 @@ class _RowsGemm(Function):
         y, stats = tg.gemm_nt(xr, wb, bias=bias, stats=True) if want_stats else (tg.gemm_nt(xr, wb, bias=bias), None)
         ctx.save_for_backward(xr, weight)
         ctx.geom = (tuple(x.shape), x.dim(), N, Np, K, Kw, bias is not None, x.dtype)
-        out = _rows_to_layout(y, x, N)
+        # keep_pad: the caller (a BatchNorm over the padded width follows) takes all round8(N) channels, the extra ones zero
+        out = _rows_to_layout(y, x, Np if keep_pad else N)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return out, stats
@@ -203,9 +225,10 @@ class _RowsGemm(Function):
         dyr = tg.row_view(dy)
         if dyr is None or dyr.dtype != torch.bfloat16 or dyr.shape[1] != Np or dyr.stride(0) % 8:
             # a gradient that does not arrive as bf16 rows of the padded width: one copy into that form
-            src = dy.movedim(1, -1).reshape(R, N) if xdim > 2 else dy
-            dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != N else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
-            dyr[:, :N].copy_(src)
+            nc = dy.shape[1]                                  # N, or Np when the forward kept the padding
+            src = dy.movedim(1, -1).reshape(R, nc) if xdim > 2 else dy
+            dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
+            dyr[:, :nc].copy_(src)
         w2 = weight.reshape(N, -1)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -219,7 +242,7 @@ class _RowsGemm(Function):
         dw = tg.wgrad(dyr, xr)                               # (Np, K) fp32
         dw = dw[:N, :Kw].reshape(weight.shape)
         db = dyr[:, :N].sum(0, dtype=torch.float32) if has_bias else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def _rows_to_layout(rows, like, channels, shape=None, dim=None):
@@ -232,9 +255,10 @@ def _rows_to_layout(rows, like, channels, shape=None, dim=None):
     return rows.view(*lead, rows.shape[1])[..., :channels].movedim(-1, 1)
 
 
-def rows_linear(x, layer, want_stats=False):
+def rows_linear(x, layer, want_stats=False, keep_pad=False):
     """layer(x) for a 1x1 convolution / Linear through _RowsGemm when x is (castable to) bf16 rows on the GPU under bf16
-    autocast; returns (y, stats) — stats None when not requested or not taken; (None, None) when the form does not apply."""
+    autocast; returns (y, stats) — stats None when not requested or not taken; (None, None) when the form does not apply.
+    keep_pad: y keeps round8(out_channels) channels (the extra ones zero) for a BatchNorm over the padded width."""
     from . import train_gemm as tg
     if not (ENABLED and ROWS_GEMM and x.is_cuda and _bf16_autocast() and layer.weight.dtype == torch.float32 and x.dim() in (2, 3, 4)):
         return None, None
@@ -249,7 +273,7 @@ def rows_linear(x, layer, want_stats=False):
     K = x.shape[1]
     if x.dtype not in (torch.bfloat16, torch.float32) or K != _round8(kin) or tg.row_view(x) is None:
         return None, None
-    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats))
+    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad))
 
 
 ROWS_GEMM = os.environ.get("PDM_ROWS_GEMM", "1") != "0"   # 0: the round-2 path (vendor GEMMs) for A/B measurements
@@ -402,7 +426,7 @@ class TrainSequential(nn.Sequential):
         stats = None      # column sums of x taken by the GEMM that produced it, for the BatchNorm right behind it
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, _BN) and applies(x, m):
+            if isinstance(m, _BN) and (applies(x, m) or _padded_applies(x, m)):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = batch_norm_relu(x, m, relu, stats)
                 stats = None
@@ -411,8 +435,12 @@ class TrainSequential(nn.Sequential):
             stats = None
             if isinstance(m, nn.Linear) or type(m) in (nn.Conv1d, nn.Conv2d):
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
-                want = isinstance(nxt, _BN) and nxt.training and nxt.num_features % 8 == 0 and nxt.num_features // 8 <= 256
-                y, st = rows_linear(x, m, want)
+                want = isinstance(nxt, _BN) and nxt.training and _round8(nxt.num_features) // 8 <= 256
+                # an odd width (196) travels zero-padded to a multiple of 8 through its BatchNorm into the next layer
+                pad = want and nxt.num_features % 8 != 0 and i + 3 < len(mods) and \
+                    (isinstance(mods[i + 3], nn.Linear) or type(mods[i + 3]) in (nn.Conv1d, nn.Conv2d)) and isinstance(mods[i + 2], nn.ReLU)
+                want = want and (nxt.num_features % 8 == 0 or pad)
+                y, st = rows_linear(x, m, want, pad)
                 if y is not None:
                     x, stats = y, st
                 else:

@@ -256,6 +256,17 @@ class PointnetFPModule(nn.Module):
                     else:
                         fused.fp_forward(pk, known_pm, skip_pm, idx, weight.contiguous(), out_pm)
                     return out_pm.transpose(1, 2)
+            from .. import fused_bn
+            rows_path = (self.training and torch.is_grad_enabled() and CHANNELS_LAST_TRAINING and fused_bn.ENABLED and fused_bn.ROWS_GEMM
+                         and known_feats.is_cuda and isinstance(self.mlp, TrainSequential)
+                         and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+                         and known.shape[1] <= 16384 and unknown.shape[1] <= 65535)
+            if rows_path:
+                # interpolation + concat written once as the bf16 rows the MFMA layers read (zero channels up to a multiple
+                # of 8); the features arrive and leave as (B, C, n) VIEWS of point-major storage: nothing is transposed
+                x = pointnet2_utils.interp_concat_rows(known_feats.transpose(1, 2), None if unknow_feats is None else unknow_feats.transpose(1, 2),
+                                                       idx.contiguous(), weight.contiguous())
+                return self.mlp(x).squeeze(-1)
             interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

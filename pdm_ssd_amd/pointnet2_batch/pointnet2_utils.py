@@ -200,6 +200,63 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+class InterpConcatRows(Function):
+    """The FP module's MLP input for the training path, in ONE kernel: cat([three_interpolate(known_feats, idx, weight),
+    unknow_feats], dim=1) (ref pointnet2_modules.py:158-165) written as bf16 rows (B, n, ld), ld = C2 + C1 rounded up to a
+    multiple of 8 with the extra channels zero — what the bf16 MFMA layers read (fused_bn.rows_linear).  Each element is the
+    fp32 value of the reference expression rounded to nearest even, i.e. autocast's cast of the concatenated tensor.
+    known_rows (B, m, C2), skip_rows (B, n, C1) | None: point-major rows, fp32 or bf16.  Returns the logical
+    (B, ld, n, 1) tensor (a channels-last view of the rows).  Gradients: known_rows (through an inverted index, no atomics),
+    skip_rows (a column block of the incoming gradient)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, known_rows, skip_rows, idx, weight):
+        from .. import _native
+        B, m, C2 = known_rows.shape
+        n = idx.shape[1]
+        C1 = 0 if skip_rows is None else skip_rows.shape[2]
+        ld = (C2 + C1 + 7) // 8 * 8
+        known_rows = known_rows.contiguous()
+        skip = None if skip_rows is None else skip_rows.contiguous()
+        assert known_rows.dtype in (torch.float32, torch.bfloat16) and (skip is None or skip.dtype in (torch.float32, torch.bfloat16))
+        out = torch.empty((B, n, ld), dtype=torch.bfloat16, device=known_rows.device)
+        _native.call("pdm_interp_concat_rows", torch.cuda.current_stream(out.device).cuda_stream, B, n, m, C2, C1, ld,
+                     known_rows.data_ptr(), 1 if known_rows.dtype == torch.bfloat16 else 0,
+                     0 if skip is None else skip.data_ptr(), 0 if skip is None or skip.dtype != torch.bfloat16 else 1,
+                     idx.data_ptr(), weight.data_ptr(), out.data_ptr())
+        ctx.geom = (B, n, m, C2, C1, ld, known_rows.dtype, None if skip is None else skip.dtype)
+        ctx.save_for_backward(idx, weight)
+        return out.view(B, n, 1, ld).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        from .. import _native
+        idx, weight = ctx.saved_tensors
+        B, n, m, C2, C1, ld, kdtype, sdtype = ctx.geom
+        rows = g.permute(0, 2, 3, 1).reshape(B, n, ld)
+        if rows.dtype != torch.bfloat16 or not rows.is_contiguous():
+            rows = rows.to(torch.bfloat16).contiguous()
+        dknown = dskip = None
+        if ctx.needs_input_grad[0]:
+            dknown = torch.empty((B, m, C2), dtype=torch.float32, device=g.device)
+            nbytes = _native.lib().pdm_three_interpolate_grad_ws_bytes(B, n, m)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+            _native.call("pdm_interp_concat_rows_grad", torch.cuda.current_stream(g.device).cuda_stream, B, n, m, C2, ld, rows.data_ptr(),
+                         idx.data_ptr(), weight.data_ptr(), dknown.data_ptr(), ws.data_ptr(), nbytes)
+            if kdtype != torch.float32:
+                dknown = dknown.to(kdtype)
+        if C1 and ctx.needs_input_grad[1]:
+            dskip = rows[:, :, C2:C2 + C1]
+            if sdtype != torch.bfloat16:
+                dskip = dskip.to(sdtype)
+        return dknown, dskip, None, None
+
+
+interp_concat_rows = InterpConcatRows.apply
+
+
 class GroupingOperation(Function):
     """ref pointnet2_utils.py:156-194 — features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
 
