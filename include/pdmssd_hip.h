@@ -448,6 +448,9 @@ size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N);
 /* dW (N, K) fp32 (+)= dY (R, N)^T . X (R, K): row slabs summed in a fixed order (bit-reproducible) */
 int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,
                  int accumulate, void *workspace, size_t workspace_bytes);
+/* out (N) fp32 = column sums of Y (R, N) bf16 — the bias gradient; N a multiple of 8, <= 512; fixed summation order */
+size_t pdm_tg_colsum_ws_floats(long long R, int N);
+int pdm_tg_colsum(void *stream, long long R, int N, const void *Y, long long ld, float *out, float *scratch);
 /* W (N, K) fp32 -> bf16 Wb (N, ldb) and / or its transpose Wt (K, ldt); either may be null; pad columns zero */
 int pdm_tg_pack_weight(void *stream, int N, int K, const float *W, void *Wb, int ldb, void *Wt, int ldt);
 

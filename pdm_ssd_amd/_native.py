@@ -91,6 +91,7 @@ _SIGNATURES = {
     "pdm_interp_concat_rows_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_tg_gemm_nt": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp],
     "pdm_tg_wgrad": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _i, _vp, ctypes.c_size_t],
+    "pdm_tg_colsum": [ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "pdm_tg_pack_weight": [_i, _i, _vp, _vp, _i, _vp, _i],
     "pdm_tune_fps_variant": None,
     "pdm_tune_fused_waves": None,
@@ -117,7 +118,7 @@ EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_b
            "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
            "pdm_sa_pack_rows", "pdm_three_interpolate_grad_ws_bytes",
            "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes", "pdm_bn_parts", "pdm_bn_pool_parts",
-           "pdm_tg_stats_parts", "pdm_tg_wgrad_ws_bytes"] + list(_SIGNATURES)
+           "pdm_tg_stats_parts", "pdm_tg_wgrad_ws_bytes", "pdm_tg_colsum_ws_floats"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -160,6 +161,8 @@ def lib():
         l.pdm_nms_workspace_bytes.argtypes = [_i]
         l.pdm_bn_pool_parts.restype = _i
         l.pdm_bn_pool_parts.argtypes = [_i, ctypes.c_longlong, _i]
+        l.pdm_tg_colsum_ws_floats.restype = ctypes.c_size_t
+        l.pdm_tg_colsum_ws_floats.argtypes = [ctypes.c_longlong, _i]
         l.pdm_tg_stats_parts.restype = _i
         l.pdm_tg_stats_parts.argtypes = [ctypes.c_longlong, _i]
         l.pdm_tg_wgrad_ws_bytes.restype = ctypes.c_size_t

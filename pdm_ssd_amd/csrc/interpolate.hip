@@ -379,6 +379,53 @@ __global__ __launch_bounds__(256) void interp_concat_rows_kernel(long long total
     }
 }
 
+// The same, eight channels per thread (C2 % 8 == 0, ld % 8 == 0, 16-byte aligned rows): one 16-byte store per thread, the
+// three known rows read as 16-byte (bf16) or 2 x 16-byte (fp32) pieces — an eighth of the instructions of the element form.
+template <bool KB>
+__global__ __launch_bounds__(256) void interp_concat_rows8_kernel(long long total8, int n, int m, int c2, int c1, int ld,
+                                                                  const void *__restrict__ known, const void *__restrict__ skip, int skip_bf16,
+                                                                  const int *__restrict__ idx, const float *__restrict__ weight,
+                                                                  unsigned short *__restrict__ out) {
+    const int cpr = ld >> 3;    // chunks per row
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
+        const long long row = e / cpr;
+        const int ch = (int)(e - row * cpr) << 3;
+        float v[8];
+        if (ch < c2) {
+            const long long b = row / n;
+            const int *id = idx + row * 3;
+            const float *w = weight + row * 3;
+            float p[3][8];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const size_t off = ((size_t)b * m + id[k]) * c2 + ch;
+                if (KB) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(static_cast<const unsigned short *>(known) + off);
+                    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { p[k][2 * t] = __uint_as_float(u[t] << 16); p[k][2 * t + 1] = __uint_as_float(u[t] & 0xffff0000u); }
+                } else {
+                    const float4 a = *reinterpret_cast<const float4 *>(static_cast<const float *>(known) + off);
+                    const float4 c = *reinterpret_cast<const float4 *>(static_cast<const float *>(known) + off + 4);
+                    p[k][0] = a.x; p[k][1] = a.y; p[k][2] = a.z; p[k][3] = a.w; p[k][4] = c.x; p[k][5] = c.y; p[k][6] = c.z; p[k][7] = c.w;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = __fmaf_rn(w[2], p[2][t], __fmaf_rn(w[1], p[1][t], __fmul_rn(w[0], p[0][t])));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int c = ch + t - c2;
+                v[t] = c < c1 ? icr_load(skip, (size_t)row * c1 + c, skip_bf16) : 0.0f;
+            }
+        }
+        uint4 o;
+        o.x = (unsigned)icr_bf16(v[0]) | ((unsigned)icr_bf16(v[1]) << 16); o.y = (unsigned)icr_bf16(v[2]) | ((unsigned)icr_bf16(v[3]) << 16);
+        o.z = (unsigned)icr_bf16(v[4]) | ((unsigned)icr_bf16(v[5]) << 16); o.w = (unsigned)icr_bf16(v[6]) | ((unsigned)icr_bf16(v[7]) << 16);
+        *reinterpret_cast<uint4 *>(out + e * 8) = o;
+    }
+}
+
 // d known[b, j, c] = sum over the CSR list of j of w * dx[b, i, c], c < C2: one wave per known point, lanes over channels,
 // every gradient row read contiguously, no atomics (fixed order: reproducible)
 __global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int c2, int ld, int ne, const unsigned short *__restrict__ dx,
@@ -391,6 +438,28 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int
     const unsigned short *__restrict__ ej = ej_all + (size_t)b * ne;
     const float *__restrict__ ew = ew_all + (size_t)b * ne;
     const int s = start[j], e = start[j + 1];
+    if ((c2 & 7) == 0 && (ld & 7) == 0) {        // eight channels per lane: 16-byte reads of the gradient rows
+        for (int c0 = 0; c0 < c2; c0 += 512) {
+            const int ch = c0 + lane * 8;
+            if (ch < c2) {
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int p = s; p < e; ++p) {
+                    const float w = ew[p];
+                    const uint4 q = *reinterpret_cast<const uint4 *>(dx + ((size_t)b * n + ej[p]) * ld + ch);
+                    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[2 * t] = __fmaf_rn(w, __uint_as_float(u[t] << 16), acc[2 * t]);
+                        acc[2 * t + 1] = __fmaf_rn(w, __uint_as_float(u[t] & 0xffff0000u), acc[2 * t + 1]);
+                    }
+                }
+                float *o = dknown + ((size_t)b * m + j) * c2 + ch;
+                *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
+        }
+        return;
+    }
     for (int c0 = 0; c0 < c2; c0 += 64) {
         const int ch = c0 + lane;
         if (ch < c2) {
@@ -412,6 +481,18 @@ extern "C" int pdm_interp_concat_rows(void *stream, int b, int n, int m, int c2,
     const long long total = (long long)b * n * ld;
     if (total == 0) return 0;
     PDM_REQUIRE(out && (c2 == 0 || (known && idx && weight && m >= 1)) && (c1 == 0 || skip), PDM_E_BADARG, "interp_concat_rows: null pointer");
+    if (c2 % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(known) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const long long total8 = total / 8;
+        const long long want8 = (total8 + 255) / 256;
+        const int blocks8 = (int)(want8 < 256 * 64 ? want8 : 256 * 64);
+        if (known_bf16)
+            hipLaunchKernelGGL(interp_concat_rows8_kernel<true>, dim3(blocks8), dim3(256), 0, as_stream(stream), total8, n, m, c2, c1, ld, known,
+                               skip, skip_bf16, idx, weight, static_cast<unsigned short *>(out));
+        else
+            hipLaunchKernelGGL(interp_concat_rows8_kernel<false>, dim3(blocks8), dim3(256), 0, as_stream(stream), total8, n, m, c2, c1, ld, known,
+                               skip, skip_bf16, idx, weight, static_cast<unsigned short *>(out));
+        return check_launch("interp_concat_rows");
+    }
     const long long want = (total + 255) / 256;
     const int blocks = (int)(want < 256 * 64 ? want : 256 * 64);
     hipLaunchKernelGGL(interp_concat_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), total, n, m, c2, c1, ld, known, known_bf16,

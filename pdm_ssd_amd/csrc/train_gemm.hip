@@ -383,6 +383,37 @@ __global__ __launch_bounds__(256) void tg_pack_weight_kernel(const float *__rest
     }
 }
 
+// column sums of a (R, N) bf16 matrix in fp32 (the bias gradient of a Linear / convolution with bias): slot s walks rows
+// s * rows_per_slot ..., a thread keeps 8 columns; partial[slot][N], folded by tg_fold.  CHP = chunks per row rounded up to a
+// power of two <= 64.
+__global__ __launch_bounds__(256) void tg_colsum_kernel(const unsigned short *__restrict__ Y, long long ld, long long R, int N, int chp,
+                                                        long long rows_per_slot, float *__restrict__ partial) {
+    __shared__ float red[4 * 512];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int chunk = t & (chp - 1), rpp = 256 / chp;
+    const long long r0 = (long long)blockIdx.x * rows_per_slot;
+    const long long r1 = r0 + rows_per_slot < R ? r0 + rows_per_slot : R;
+    float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (chunk * 8 < N) {
+        for (long long r = r0 + t / chp; r < r1; r += rpp) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(Y + r * ld + chunk * 8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[2 * e] += __uint_as_float(w[e] << 16); s1[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        for (int off = chp; off < 64; off <<= 1) s1[e] += __shfl_xor(s1[e], off, 64);
+    if (lane < chp && chunk * 8 < N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * 512 + chunk * 8 + e] = s1[e];
+    }
+    __syncthreads();
+    for (int c = t; c < N; c += 256)
+        partial[(long long)blockIdx.x * N + c] = ((red[c] + red[512 + c]) + red[1024 + c]) + red[1536 + c];
+}
+
 static inline bool tg_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace pdm
@@ -432,6 +463,7 @@ static long long tg_wgrad_slabs(long long R, int K, int N) {
     long long slabs = (R + 1023) / 1024;
     const long long cap = (24ll << 20) / ((long long)N * K * 4);
     if (slabs > cap) slabs = cap < 1 ? 1 : cap;
+    if (slabs > 1024) slabs = 1024;                  // two levels of the fold tree at most
     return slabs < 1 ? 1 : slabs;
 }
 extern "C" size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N) {
@@ -473,6 +505,36 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     if (rc) return rc;
     const long long elems = (long long)N * K;
     return tg_fold(as_stream(stream), a.partial, (int)used, elems, dW, accumulate, a.partial + slabs * elems);
+}
+
+extern "C" size_t pdm_tg_colsum_ws_floats(long long R, int N) {
+    if (R <= 0 || N <= 0) return 0;
+    const long long slots = (R + 511) / 512 < 1024 ? (R + 511) / 512 : 1024;
+    return (size_t)(slots * N) + tg_fold_scratch_floats(slots, N);
+}
+
+// out (N) fp32 = column sums of Y (R, N) bf16 (row stride ld, multiple of 8); N a multiple of 8, N <= 512; scratch of
+// pdm_tg_colsum_ws_floats(R, N) floats.  Fixed summation order.
+extern "C" int pdm_tg_colsum(void *stream, long long R, int N, const void *Y, long long ld, float *out, float *scratch) {
+    PDM_REQUIRE(R >= 0 && N >= 0, PDM_E_BADARG, "tg_colsum: negative size");
+    if (N == 0) return 0;
+    PDM_REQUIRE(out, PDM_E_BADARG, "tg_colsum: null pointer");
+    if (R == 0) {
+        const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, as_stream(stream));
+        PDM_REQUIRE(e == hipSuccess, PDM_E_BADARG, "tg_colsum: memset failed");
+        return 0;
+    }
+    PDM_REQUIRE(Y && scratch && N % 8 == 0 && N <= 512 && ld % 8 == 0 && ld >= N && tg_al16(Y), PDM_E_BADARG,
+                "tg_colsum: N=%d (multiple of 8, <= 512), ld=%lld (multiple of 8), 16-byte aligned rows", N, ld);
+    int chp = 1;
+    while (chp * 8 < N) chp <<= 1;
+    const long long slots = (R + 511) / 512 < 1024 ? (R + 511) / 512 : 1024;
+    const long long rps = (R + slots - 1) / slots;
+    hipLaunchKernelGGL(tg_colsum_kernel, dim3((unsigned)slots), dim3(256), 0, as_stream(stream), static_cast<const unsigned short *>(Y), ld, R, N,
+                       chp, rps, scratch);
+    int rc = check_launch("tg_colsum");
+    if (rc) return rc;
+    return tg_fold(as_stream(stream), scratch, (int)slots, N, out, 0, scratch + slots * N);
 }
 
 // W (N, K) fp32 -> bf16 copies: Wb (N, ldb) row-major and / or Wt (K, ldt) transposed (either may be null); pad columns zero.

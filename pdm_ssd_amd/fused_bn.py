@@ -199,15 +199,11 @@ class _RowsGemm(Function):
         w2 = weight.reshape(N, -1)
         Kw, Np = w2.shape[1], _round8(N)
         assert Kw <= K < Kw + 8 and K % 8 == 0
-        if Np == N:
-            wb = tg.pack_weight(w2, pad_to=K)
-        else:                                                # a narrow last layer (3 class logits): zero rows up to 8
-            wb = torch.zeros((Np, K), dtype=torch.bfloat16, device=x.device)
-            tg.pack_weight_into(w2, wb)
+        wb, wt = tg.pack_weight_pair(w2, Np, K)              # forward weights and their transpose (data gradient): one launch
         if bias is not None and Np != N:
             bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
         y, stats = tg.gemm_nt(xr, wb, bias=bias, stats=True) if want_stats else (tg.gemm_nt(xr, wb, bias=bias), None)
-        ctx.save_for_backward(xr, weight)
+        ctx.save_for_backward(xr, weight, wt)
         ctx.geom = (tuple(x.shape), x.dim(), N, Np, K, Kw, bias is not None, x.dtype)
         # keep_pad: the caller (a BatchNorm over the padded width follows) takes all round8(N) channels, the extra ones zero
         out = _rows_to_layout(y, x, Np if keep_pad else N)
@@ -219,7 +215,7 @@ class _RowsGemm(Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dstats=None):
         from . import train_gemm as tg
-        xr, weight = ctx.saved_tensors
+        xr, weight, wt = ctx.saved_tensors
         xshape, xdim, N, Np, K, Kw, has_bias, xdtype = ctx.geom
         R = xr.shape[0]
         dyr = tg.row_view(dy)
@@ -229,19 +225,17 @@ class _RowsGemm(Function):
             src = dy.movedim(1, -1).reshape(R, nc) if xdim > 2 else dy
             dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
             dyr[:, :nc].copy_(src)
-        w2 = weight.reshape(N, -1)
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = torch.zeros((K, Np), dtype=torch.bfloat16, device=dy.device) if (K != Kw or Np != N) else \
-                torch.empty((K, Np), dtype=torch.bfloat16, device=dy.device)
-            tg.pack_weight_into(w2, wt, transposed=True)     # (Kw, N) block of a (K, Np) matrix; the rest stays zero
             dxr = tg.gemm_nt(dyr, wt)                        # (R, K) bf16: the pad channels come out zero
             dx = _rows_to_layout(dxr, None, K, xshape, xdim)
             if xdtype != torch.bfloat16:
                 dx = dx.to(xdtype)
         dw = tg.wgrad(dyr, xr)                               # (Np, K) fp32
         dw = dw[:N, :Kw].reshape(weight.shape)
-        db = dyr[:, :N].sum(0, dtype=torch.float32) if has_bias else None
+        db = None
+        if has_bias:   # column sums of the gradient rows (torch's strided reduction over 8 of them took 0.28 ms at 524288 rows)
+            db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
         return dx, dw, db, None, None
 
 

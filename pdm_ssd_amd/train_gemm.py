@@ -56,6 +56,19 @@ def pack_weight_into(w, out, transposed=False):
     return out
 
 
+def pack_weight_pair(w, rows_to, cols_to):
+    """fp32 (N, K) parameter -> (wb (rows_to, cols_to), wt (cols_to, rows_to)) bf16: the weight for the forward product and
+    its transpose for the data gradient, zero padded (rows_to >= N, cols_to >= K, both multiples of 8), in ONE launch."""
+    assert w.dim() == 2 and w.is_cuda and w.dtype == torch.float32
+    w = w.detach().contiguous()
+    N, K = w.shape
+    alloc = torch.zeros if (rows_to != N or cols_to != K) else torch.empty
+    buf = alloc((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)
+    wb, wt = buf[0].view(rows_to, cols_to), buf[1].view(cols_to, rows_to)
+    _native.call("pdm_tg_pack_weight", _stream(w), N, K, w.data_ptr(), wb.data_ptr(), cols_to, wt.data_ptr(), rows_to)
+    return wb, wt
+
+
 def gemm_nt(x, w, bias=None, stats=False, out=None):
     """x (R, K) bf16 rows (row stride a multiple of 8), w (N, K') bf16 with K' >= K zero padded -> y (R, N) bf16 =
     x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the column sums (parts, N, 2) fp32 (sum y,
@@ -83,3 +96,13 @@ def wgrad(dy, x, out=None, accumulate=False):
     _native.call("pdm_tg_wgrad", _stream(x), R, K, N, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
                  1 if accumulate else 0, ws.data_ptr(), nbytes)
     return dw
+
+
+def colsum(y):
+    """y (R, N) bf16 rows (N a multiple of 8, <= 512) -> (N,) fp32 column sums, fixed summation order (a bias gradient)."""
+    R, N = y.shape
+    assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and N % 8 == 0 and N <= 512
+    out = torch.empty((N,), dtype=torch.float32, device=y.device)
+    ws = torch.empty((max(_native.lib().pdm_tg_colsum_ws_floats(R, N), 4),), dtype=torch.float32, device=y.device)
+    _native.call("pdm_tg_colsum", _stream(y), R, N, y.data_ptr(), y.stride(0), out.data_ptr(), ws.data_ptr())
+    return out

@@ -93,3 +93,12 @@ def test_row_view_recognises_the_training_layouts(dev):
     b = torch.zeros(7, 24, dtype=torch.bfloat16, device=dev)
     assert tg.row_view(b) is b and tg.row_view(b[:, :16]).shape == (7, 16)
     assert tg.usable(10, 64, 32) and not tg.usable(10, 99, 32)
+
+
+@pytest.mark.parametrize("R,N,ld", [(524288, 8, 8), (1000, 24, 32), (77, 512, 512), (1, 64, 64), (30000, 200, 200)])
+def test_colsum_exact_on_integer_data(dev, R, N, ld):
+    ys = torch.zeros((R, ld), dtype=torch.bfloat16, device=dev)
+    ys[:, :N] = ints((R, N), -3, 3, 11, dev).bfloat16()
+    ys[:, N:] = 5.0
+    got = tg.colsum(ys[:, :N])
+    assert torch.equal(got, ys[:, :N].double().sum(0).float())      # |sums| < 2^24: exact in fp32
