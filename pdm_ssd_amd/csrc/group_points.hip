@@ -475,6 +475,39 @@ __global__ __launch_bounds__(256) void group_concat_cl_kernel(long long total, i
 // out (B, M, ns, 3+C) fp32 (out_bf16 = 0) or bf16 (1); feat_pm (B, N, C) point-major, may be null when c == 0; idx (B, M, ns).
 extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
                                       const float *feat_pm, const int *idx, void *out, int out_bf16, int ld);
+namespace pdm {
+// bf16 rows with ld % 8 == 0 (the padded form): a thread writes EIGHT consecutive channels of one row with one 16-byte store —
+// one index / centre lookup and one 64-bit division per 16 bytes instead of per 2 (the element form spent its time there).
+__global__ __launch_bounds__(256) void group_concat_cl8_kernel(long long total8, int n, int m, int c, int ns, int ld,
+                                                               const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                               const float *__restrict__ feat_pm, const int *__restrict__ idx,
+                                                               unsigned short *__restrict__ out) {
+    const int w = 3 + c, cpr = ld >> 3;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
+        const long long row = e / cpr;               // (b, centre, slot)
+        const int ch0 = (int)(e - row * cpr) << 3;
+        const long long bm = row / ns;
+        const int b = (int)(bm / m);
+        const int src = idx[row];
+        const float *__restrict__ f = feat_pm ? feat_pm + ((size_t)b * n + src) * c - 3 : nullptr;
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int ch = ch0 + t;
+            if (ch < 3) v[t] = xyz[((size_t)b * n + src) * 3 + ch] - new_xyz[bm * 3 + ch];
+            else if (ch < w) v[t] = f[ch];
+            else v[t] = 0.0f;
+        }
+        uint4 o;
+        o.x = (unsigned)f32_to_bf16_rne(v[0]) | ((unsigned)f32_to_bf16_rne(v[1]) << 16);
+        o.y = (unsigned)f32_to_bf16_rne(v[2]) | ((unsigned)f32_to_bf16_rne(v[3]) << 16);
+        o.z = (unsigned)f32_to_bf16_rne(v[4]) | ((unsigned)f32_to_bf16_rne(v[5]) << 16);
+        o.w = (unsigned)f32_to_bf16_rne(v[6]) | ((unsigned)f32_to_bf16_rne(v[7]) << 16);
+        *reinterpret_cast<uint4 *>(out + e * 8) = o;
+    }
+}
+}  // namespace pdm
+
 extern "C" int pdm_group_concat_cl(void *stream, int b, int n, int m, int c, int nsample, const float *xyz,
                                    const float *new_xyz, const float *feat_pm, const int *idx, void *out, int out_bf16) {
     return pdm_group_concat_cl_ld(stream, b, n, m, c, nsample, xyz, new_xyz, feat_pm, idx, out, out_bf16, 3 + c);
@@ -490,6 +523,12 @@ extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, 
     PDM_REQUIRE(xyz && new_xyz && idx && out && (c == 0 || feat_pm), PDM_E_BADARG, "group_concat_cl: null pointer");
     const long long want = (total + 255) / 256;
     const int blocks = (int)(want < 256 * 64 ? want : 256 * 64);
+    if (out_bf16 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const long long total8 = total / 8, want8 = (total8 + 255) / 256;
+        hipLaunchKernelGGL(pdm::group_concat_cl8_kernel, dim3((unsigned)(want8 < 256 * 64 ? want8 : 256 * 64)), dim3(256), 0,
+                           pdm::as_stream(stream), total8, n, m, c, nsample, ld, xyz, new_xyz, feat_pm, idx, static_cast<unsigned short *>(out));
+        return pdm::check_launch("group_concat_cl");
+    }
     if (out_bf16)
         hipLaunchKernelGGL(pdm::group_concat_cl_kernel<true>, dim3(blocks), dim3(256), 0, pdm::as_stream(stream), total, n, m, c,
                            nsample, ld, xyz, new_xyz, feat_pm, idx, out);
@@ -551,27 +590,27 @@ __global__ __launch_bounds__(GCL_THREADS) void gcl_csr_build_kernel(int ne, int 
     }
 }
 
+// lpp = lanes per source point (a power of two <= 64, >= min(c, 64) rounded up): with few channels a wave serves 64 / lpp
+// points at once (SA1 has ONE feature channel: a wave per point left 63 lanes idle)
 template <bool BF16>
-__global__ __launch_bounds__(256) void gcl_grad_kernel(int n, int c, int ne, int w, const void *__restrict__ grad,
+__global__ __launch_bounds__(256) void gcl_grad_kernel(int n, int c, int ne, int w, int lpp, const void *__restrict__ grad,
                                                        const int *__restrict__ start_all, const int *__restrict__ el_all,
                                                        float *__restrict__ out_pm) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per source point
+    const int ppw = 64 / lpp;                                            // points per wave
+    const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw + lane / lpp;
     if (k >= n) return;
     const int *__restrict__ start = start_all + (size_t)b * (n + 1);
     const int *__restrict__ el = el_all + (size_t)b * ne;
     const int s = start[k], e = start[k + 1];   // w = row stride of grad (>= 3 + c)
-    for (int c0 = 0; c0 < c; c0 += 64) {
-        const int ch = c0 + lane;
+    for (int ch = lane % lpp; ch < c; ch += lpp) {
         float acc = 0.0f;
-        if (ch < c) {
-            for (int p = s; p < e; ++p) {
-                const size_t off = ((size_t)b * ne + el[p]) * w + 3 + ch;
-                if constexpr (BF16) acc += __uint_as_float((unsigned)static_cast<const unsigned short *>(grad)[off] << 16);
-                else acc += static_cast<const float *>(grad)[off];
-            }
-            out_pm[((size_t)b * n + k) * c + ch] = acc;
+        for (int p = s; p < e; ++p) {
+            const size_t off = ((size_t)b * ne + el[p]) * w + 3 + ch;
+            if constexpr (BF16) acc += __uint_as_float((unsigned)static_cast<const unsigned short *>(grad)[off] << 16);
+            else acc += static_cast<const float *>(grad)[off];
         }
+        out_pm[((size_t)b * n + k) * c + ch] = acc;
     }
 }
 
@@ -614,10 +653,13 @@ extern "C" int pdm_group_concat_cl_grad_ld(void *stream, int b, int n, int m, in
                        n, idx, start, el);
     int rc = pdm::check_launch("group_concat_cl_grad(csr)");
     if (rc) return rc;
-    const dim3 grid((unsigned)((n + 3) / 4), (unsigned)b);
+    int lpp = 1;
+    while (lpp < c && lpp < 64) lpp <<= 1;
+    const int ppb = 4 * (64 / lpp);                                      // points per workgroup
+    const dim3 grid((unsigned)((n + ppb - 1) / ppb), (unsigned)b);
     if (grad_bf16)
-        hipLaunchKernelGGL(pdm::gcl_grad_kernel<true>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, ld, grad, start, el, grad_feat_pm);
+        hipLaunchKernelGGL(pdm::gcl_grad_kernel<true>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, ld, lpp, grad, start, el, grad_feat_pm);
     else
-        hipLaunchKernelGGL(pdm::gcl_grad_kernel<false>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, ld, grad, start, el, grad_feat_pm);
+        hipLaunchKernelGGL(pdm::gcl_grad_kernel<false>, grid, dim3(256), 0, pdm::as_stream(stream), n, c, ne, ld, lpp, grad, start, el, grad_feat_pm);
     return pdm::check_launch("group_concat_cl_grad");
 }
