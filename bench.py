@@ -896,8 +896,8 @@ def main():
     gp_launch_bytes = gp["alg_MB_per_step"] * 1e6 / gp["calls_per_step"]
     gp_launch_s = gp["ms_per_step"] / 1e3 / gp["calls_per_step"]
     gp_gbs = gp_launch_bytes / gp_launch_s / 1e9
-    roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_v4_kernel + pdm::group_points_lds_kernel (all launches of "
-                    "pdm_group_points, the API-exact operator)",
+    roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_rows_kernel + pdm::group_points_lds_kernel + pdm::group_points_v4_kernel "
+                    "(all launches of pdm_group_points, the API-exact operator)",
                     "achieved": round(gp_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gp_gbs / HBM_PEAK_GBS, 4),
                     "frac_of_measured_copy": round(gp_gbs / copy_gbs, 4),
                     "traffic": pmc_traffic(("pdm::group_points_v4_kernel", "pdm::group_points_lds_kernel", "pdm::group_points_rows_kernel")),

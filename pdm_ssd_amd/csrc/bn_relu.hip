@@ -397,12 +397,12 @@ __device__ __forceinline__ void bn_fold(const float *__restrict__ partial, int p
 __global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const float *__restrict__ partial, int parts, int C, double count,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                              float momentum, float *running_mean, float *running_var,
-                                                             float *__restrict__ coef) {
+                                                             float *__restrict__ coef, int zero_pivot = 0) {
     const int c = blockIdx.x;
     double s, q;
     bn_fold(partial, parts, C, c, s, q);
     if (threadIdx.x != 0) return;
-    const double dm = s / count, mean = (double)coef[3 * C + c] + dm;
+    const double dm = s / count, mean = (zero_pivot ? 0.0 : (double)coef[3 * C + c]) + dm;   // zero_pivot: plain sums (no parked pivot row)
     double var = q / count - dm * dm;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -501,10 +501,8 @@ extern "C" int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, i
     if (int rc = bn_check("bn_relu_forward_stats", dtype, 0, n, C, 1, x, y)) return rc;
     PDM_REQUIRE(coef && partial && parts >= 1, PDM_E_BADARG, "bn_relu_forward_stats: null workspace");
     if (n == 0) return 0;
-    const hipError_t e = hipMemsetAsync(coef + 3 * (size_t)C, 0, sizeof(float) * (size_t)C, as_stream(stream));   // the sums' pivot: 0
-    PDM_REQUIRE(e == hipSuccess, PDM_E_BADARG, "bn_relu_forward_stats: memset failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n, gamma, beta, eps,
-                       momentum, running_mean, running_var, coef);
+                       momentum, running_mean, running_var, coef, 1);   // the producer's sums are plain sums: pivot 0
     const BnCoef k = coef_of(coef, nullptr, C);
     const int V = dtype ? 8 : 4;
     const long long nvec = n * C / V;
