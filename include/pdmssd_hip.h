@@ -353,6 +353,9 @@ int pdm_bn_relu_forward(void *stream, int dtype, int layout, long long n, int C,
 int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, int C, const void *x, void *y, const float *gamma,
                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                               float *coef, const float *partial, int parts, int relu);
+/* finalize only: coef (4, C) from the producer's sums + running statistics (the consumer normalises while it reads x) */
+int pdm_bn_finalize_stats(void *stream, long long n, int C, const float *gamma, const float *beta, float eps, float momentum,
+                          float *running_mean, float *running_var, float *coef, const float *partial, int parts);
 int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                          void *dx, const float *coef, float *grads, float *partial, int relu);
 
@@ -442,12 +445,15 @@ int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, int c2, int l
  * statistics without another pass over Y; pdm_bn_relu_forward_stats folds the parts).  The data gradient is the same call on
  * the transposed weights. */
 int pdm_tg_stats_parts(long long rows, int N);
+/* x_bn_coef: null, or (4, K) fp32 [mean | invstd | gamma invstd | beta] from pdm_bn_finalize_stats: X holds the PRE-BatchNorm
+ * outputs of the layer before and is read through bf16(relu((x - mean) scale + beta)) — that layer's BatchNorm + ReLU without
+ * a pass (or a tensor) of its own; bit for bit what pdm_bn_relu_forward would have written. */
 int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
-                   void *Y, long long ldy, const float *bias, float *stats);
+                   void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef);
 size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N);
 /* dW (N, K) fp32 (+)= dY (R, N)^T . X (R, K): row slabs summed in a fixed order (bit-reproducible) */
 int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,
-                 int accumulate, void *workspace, size_t workspace_bytes);
+                 int accumulate, void *workspace, size_t workspace_bytes, const float *x_bn_coef);
 /* out (N) fp32 = column sums of Y (R, N) bf16 — the bias gradient; N a multiple of 8, <= 512; fixed summation order */
 size_t pdm_tg_colsum_ws_floats(long long R, int N);
 int pdm_tg_colsum(void *stream, long long R, int N, const void *Y, long long ld, float *out, float *scratch);

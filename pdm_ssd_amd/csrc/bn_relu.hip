@@ -513,6 +513,16 @@ extern "C" int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, i
     return check_launch("bn_relu_forward_stats");
 }
 
+// Only the finalize step of the above: coef (4, C) from the producer's sums, running statistics updated.  For a consumer that
+// applies the normalisation itself while reading x (pdm_tg_gemm_nt / pdm_tg_wgrad with x_bn_coef).
+extern "C" int pdm_bn_finalize_stats(void *stream, long long n, int C, const float *gamma, const float *beta, float eps, float momentum,
+                                     float *running_mean, float *running_var, float *coef, const float *partial, int parts) {
+    PDM_REQUIRE(n >= 1 && C >= 1 && coef && partial && parts >= 1, PDM_E_BADARG, "bn_finalize_stats: bad argument");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n, gamma, beta, eps,
+                       momentum, running_mean, running_var, coef, 1);
+    return check_launch("bn_finalize_stats");
+}
+
 // Backward: dx, and grads (4, C) = [dgamma | dbeta | k1 | k2] (the caller reads the first two rows).
 extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                                     void *dx, const float *coef, float *grads, float *partial, int relu) {

@@ -51,10 +51,33 @@ struct TgNtArgs {
     const unsigned short *W; long long ldw;     // (N, K) bf16
     unsigned short *Y; long long ldy;           // (R, N) bf16
     const float *bias;                          // (N) fp32 or null: y = bf16(acc + bf16(bias))
-    float *stats;                               // null, or [row tiles][N][2]: sum y, sum y^2 of the rounded outputs
+    float *stats;                               // null, or [slots][N][2]: sum y, sum y^2 of the rounded outputs
+    const float *xf;                            // null, or (4, K) fp32 [mean | invstd | scale | beta]: X is read through BatchNorm + ReLU
     long long R;
     int K, N;
 };
+
+// BatchNorm(train) + ReLU applied to eight bf16 activations on their way into LDS: bf16(relu((x - mean) * scale + beta)) — the
+// arithmetic of bn_cl_apply_kernel (bn_relu.hip), so the operand a layer reads this way is bit for bit the tensor that kernel
+// would have written.  `live` = the row exists (rows past R must stay zero).
+__device__ __forceinline__ uint4 tg_bn_relu8(uint4 v, const float *__restrict__ coef, int K, int k, bool live) {
+    if (!live) return make_uint4(0, 0, 0, 0);
+    const float4 m0 = *reinterpret_cast<const float4 *>(coef + k), m1 = *reinterpret_cast<const float4 *>(coef + k + 4);
+    const float4 s0 = *reinterpret_cast<const float4 *>(coef + 2 * K + k), s1 = *reinterpret_cast<const float4 *>(coef + 2 * K + k + 4);
+    const float4 b0 = *reinterpret_cast<const float4 *>(coef + 3 * K + k), b1 = *reinterpret_cast<const float4 *>(coef + 3 * K + k + 4);
+    const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = fmaxf(fmaf(__uint_as_float(w[e] << 16) - mu[2 * e], sc[2 * e], sh[2 * e]), 0.f);
+        const float hi = fmaxf(fmaf(__uint_as_float(w[e] & 0xffff0000u) - mu[2 * e + 1], sc[2 * e + 1], sh[2 * e + 1]), 0.f);
+        o[e] = (unsigned)tg_bf16(lo) | ((unsigned)tg_bf16(hi) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // 16-byte chunk `chunk` (0..7) of row `row` of a [rows][64] bf16 LDS tile: rows 2i, 2i+1 sit in the two 128-byte halves of
 // a 256-byte bank line, the pair index permutes the chunk — 16 distinct rows reading one logical chunk hit 16 different
@@ -141,7 +164,12 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
                 const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
-                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = xr[i];
+                uint4 v = xr[i];
+                if (a.xf) {   // (wave-uniform) the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
+                    const int k = kt * TG_BK + chunk * 8;
+                    v = tg_bn_relu8(v, a.xf, a.K, k < a.K ? k : 0, row0 + row < a.R && k < a.K);
+                }
+                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = v;
             }
             if (!w_resident) store_w();
             __syncthreads();
@@ -245,6 +273,7 @@ struct TgTnArgs {
     const unsigned short *dY; long long ldy;    // (R, N) bf16
     const unsigned short *X; long long ldx;     // (R, K) bf16
     float *partial;                             // [slabs][N][K] fp32
+    const float *xf;                            // null, or (4, K) fp32: X is read through BatchNorm + ReLU (see tg_bn_relu8)
     long long R, rows_per_slab;
     int N, K;
 };
@@ -301,7 +330,12 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int q = t + TG_T * i, row = q >> 4, chunk = q & 15;
             *reinterpret_cast<uint4 *>(Gs + row * TG_WPITCH + chunk * 16) = gr[i];
-            *reinterpret_cast<uint4 *>(Xs + row * TG_WPITCH + chunk * 16) = xr[i];
+            uint4 v = xr[i];
+            if (a.xf) {
+                const int k = k0 + chunk * 8;
+                v = tg_bn_relu8(v, a.xf, a.K, k < a.K ? k : 0, r0 + row < r_end && k < a.K);
+            }
+            *reinterpret_cast<uint4 *>(Xs + row * TG_WPITCH + chunk * 16) = v;
         }
         __syncthreads();
         if (r0 + TG_WR < r_end) load(r0 + TG_WR);
@@ -439,8 +473,11 @@ extern "C" int pdm_tg_stats_parts(long long rows, int N) { return rows <= 0 || N
 // Y (R, N) bf16 = X (R, K) bf16 . W (N, K)^T bf16 [+ bias], fp32 accumulation, one rounding.  Strides in elements, multiples
 // of 8; K and N multiples of 8; pointers 16-byte aligned.  stats: null, or (pdm_tg_stats_parts(R, N), N, 2) fp32 = per slot the
 // column sums of y and y^2 of the ROUNDED outputs (pdm_bn_relu_forward_stats folds them in double, in slot order).
+// x_bn_coef: null, or (4, K) fp32 [mean | invstd | gamma invstd | beta] (pdm_bn_finalize_stats): X holds the PRE-BatchNorm
+// outputs of the layer before and is read through bf16(relu((x - mean) scale + beta)) — that layer's BatchNorm + ReLU without a
+// pass (and a tensor) of its own.
 extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
-                              void *Y, long long ldy, const float *bias, float *stats) {
+                              void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef) {
     PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_gemm_nt: negative size");
     if (R == 0 || N == 0) return 0;
     PDM_REQUIRE(X && W && Y, PDM_E_BADARG, "tg_gemm_nt: null pointer");
@@ -452,7 +489,7 @@ extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const voi
     const unsigned wgs = (unsigned)slots * (unsigned)((N + bn - 1) / bn);
     TgNtArgs a;
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
-    a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.R = R; a.K = K; a.N = N;
+    a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.xf = x_bn_coef; a.R = R; a.K = K; a.N = N;
     if (bn == 32) hipLaunchKernelGGL((tg_nt_kernel<1, 1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
     else if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<1, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
     else hipLaunchKernelGGL((tg_nt_kernel<2, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
@@ -474,7 +511,7 @@ extern "C" size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N) {
 
 // dW (N, K) fp32 (+)= dY (R, N)^T bf16 . X (R, K) bf16, fp32 accumulation; workspace of pdm_tg_wgrad_ws_bytes(R, K, N) bytes.
 extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,
-                            int accumulate, void *workspace, size_t workspace_bytes) {
+                            int accumulate, void *workspace, size_t workspace_bytes, const float *x_bn_coef) {
     PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_wgrad: negative size");
     if (K == 0 || N == 0) return 0;
     PDM_REQUIRE(dW, PDM_E_BADARG, "tg_wgrad: null pointer");
@@ -498,7 +535,7 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     PDM_REQUIRE(used <= 65535, PDM_E_TOOLARGE, "tg_wgrad: %lld slabs", used);
     TgTnArgs a;
     a.dY = static_cast<const unsigned short *>(dY); a.ldy = ldy; a.X = static_cast<const unsigned short *>(X); a.ldx = ldx;
-    a.partial = static_cast<float *>(workspace); a.R = R; a.rows_per_slab = rps; a.N = N; a.K = K;
+    a.partial = static_cast<float *>(workspace); a.xf = x_bn_coef; a.R = R; a.rows_per_slab = rps; a.N = N; a.K = K;
     const unsigned tiles = (unsigned)(((N + 127) / 128) * ((K + 127) / 128));
     hipLaunchKernelGGL(tg_tn_kernel, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
     int rc = check_launch("tg_wgrad");

@@ -239,6 +239,103 @@ class _RowsGemm(Function):
         return dx, dw, db, None, None
 
 
+class _BnReluRowsGemm(Function):
+    """layer(relu(bn(x))) for x = the raw bf16 rows a _RowsGemm just produced together with their column sums: the
+    BatchNorm is finalized from those sums (pdm_bn_finalize_stats) and applied, with the ReLU, WHILE the next contraction
+    reads x (pdm_tg_gemm_nt / pdm_tg_wgrad with x_bn_coef) — the normalised tensor is never written or read; the values
+    are bit for bit those of the separate operator.  Backward: data gradient of the layer -> BatchNorm + ReLU backward
+    (pdm_bn_relu_backward over x and that gradient) -> gradient of x, dgamma, dbeta; weight gradient with the layer's
+    input recomputed on the fly.  gamma / beta / running statistics arrive at x's (possibly zero-padded) width."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, stats, gamma, beta, running_mean, running_var, eps, momentum, weight, bias, want_stats, keep_pad):
+        from . import train_gemm as tg
+        xr = tg.row_view(x)
+        R, K = xr.shape
+        N = weight.shape[0]
+        w2 = weight.reshape(N, -1)
+        Kw, Np = w2.shape[1], _round8(N)
+        assert xr.dtype == torch.bfloat16 and Kw <= K < Kw + 8 and K % 8 == 0 and stats.shape[1:] == (K, 2)
+        coef = torch.empty((4, K), dtype=torch.float32, device=x.device)
+        _native.call("pdm_bn_finalize_stats", torch.cuda.current_stream(x.device).cuda_stream, R, K, gamma.data_ptr(), beta.data_ptr(),
+                     float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(), stats.data_ptr(),
+                     stats.shape[0])
+        wb, wt = tg.pack_weight_pair(w2, Np, K)
+        if bias is not None and Np != N:
+            bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
+        if want_stats:
+            y, st = tg.gemm_nt(xr, wb, bias=bias, stats=True, x_bn_coef=coef)
+        else:
+            y, st = tg.gemm_nt(xr, wb, bias=bias, x_bn_coef=coef), None
+        ctx.save_for_backward(xr, coef, weight, wt)
+        ctx.geom = (tuple(x.shape), x.dim(), N, Np, K, Kw, bias is not None)
+        out = _rows_to_layout(y, x, Np if keep_pad else N)
+        if st is not None:
+            ctx.mark_non_differentiable(st)
+        return out, st
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy, _dstats=None):
+        from . import train_gemm as tg
+        xr, coef, weight, wt = ctx.saved_tensors
+        xshape, xdim, N, Np, K, Kw, has_bias = ctx.geom
+        R = xr.shape[0]
+        dyr = tg.row_view(dy)
+        if dyr is None or dyr.dtype != torch.bfloat16 or dyr.shape[1] != Np or dyr.stride(0) % 8:
+            nc = dy.shape[1]
+            src = dy.movedim(1, -1).reshape(R, nc) if xdim > 2 else dy
+            dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
+            dyr[:, :nc].copy_(src)
+        da = tg.gemm_nt(dyr, wt)                             # gradient of relu(bn(x)), (R, K) bf16
+        dw = tg.wgrad(dyr, xr, x_bn_coef=coef)[:N, :Kw].reshape(weight.shape)   # the layer's input recomputed while it is read
+        db = None
+        if has_bias:
+            db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
+        dx = torch.empty_like(xr)
+        grads = torch.empty((4, K), dtype=torch.float32, device=dy.device)
+        parts = _native.lib().pdm_bn_parts(0, R, K, 1)
+        partial = torch.empty((parts, K, 2), dtype=torch.float32, device=dy.device)
+        _native.call("pdm_bn_relu_backward", torch.cuda.current_stream(dy.device).cuda_stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(),
+                     dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), 1)
+        return _rows_to_layout(dx, None, K, xshape, xdim), None, grads[0], grads[1], None, None, None, None, dw, db, None, None
+
+
+def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False):
+    """layer(relu(bn(x))) through _BnReluRowsGemm, or (None, None) when the form does not apply (the caller then runs the
+    BatchNorm operator and the layer one after the other)."""
+    from . import train_gemm as tg
+    if not (ENABLED and ROWS_GEMM and BN_IN_GEMM and x.is_cuda and _bf16_autocast() and layer.weight.dtype == torch.float32 and stats is not None
+            and x.dtype == torch.bfloat16 and x.dim() in (2, 3, 4) and (applies(x, bn) or _padded_applies(x, bn))):
+        return None, None
+    if isinstance(layer, nn.Linear):
+        kin = layer.in_features
+    else:
+        if not (all(k == 1 for k in layer.kernel_size) and all(v == 1 for v in layer.stride) and all(v == 0 for v in layer.padding)
+                and all(v == 1 for v in layer.dilation) and layer.groups == 1 and isinstance(layer.padding, tuple)
+                and x.dim() == layer.weight.dim()):
+            return None, None
+        kin = layer.in_channels
+    C, K = bn.num_features, x.shape[1]
+    xr = tg.row_view(x)
+    if kin != C or K != _round8(C) or xr is None or xr.stride(0) != K or stats.shape[1] != K or _layout(x) is None or _layout(x)[0] != 0:
+        return None, None
+    gamma, beta, rm, rv = bn.weight, bn.bias, bn.running_mean, bn.running_var
+    if K != C:   # zero-padded width: zero gamma / beta on the padding (it stays zero), temporary running statistics
+        z = bn.weight.new_zeros(K - C)
+        gamma, beta, rm, rv = torch.cat([gamma, z]), torch.cat([beta, z]), torch.cat([rm, z]), torch.cat([rv, z + 1.0])
+    out = _BnReluRowsGemm.apply(x, stats, gamma, beta, rm, rv, bn.eps, bn.momentum, layer.weight, layer.bias, bool(want_stats), bool(keep_pad))
+    with torch.no_grad():
+        if K != C:
+            bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
+        bn.num_batches_tracked += 1
+    return out
+
+
+BN_IN_GEMM = os.environ.get("PDM_BN_IN_GEMM", "1") != "0"   # 0: BatchNorm + ReLU as its own operator in front of every layer (A/B)
+
+
 def _rows_to_layout(rows, like, channels, shape=None, dim=None):
     """(R, ld) row storage -> the logical tensor of `like`'s layout with `channels` channels (a view)."""
     shape = tuple(like.shape) if shape is None else shape
@@ -389,6 +486,16 @@ def conv1x1(x, conv):
 _BN = (nn.BatchNorm1d, nn.BatchNorm2d)
 
 
+def _stats_wanted(mods, i):
+    """for the Linear / convolution at mods[i]: (take BatchNorm column sums in its epilogue?, keep a zero-padded output width?)"""
+    nxt = mods[i + 1] if i + 1 < len(mods) else None
+    want = isinstance(nxt, _BN) and nxt.training and _round8(nxt.num_features) // 8 <= 256
+    # an odd width (196) travels zero-padded to a multiple of 8 through its BatchNorm into the next layer
+    pad = want and nxt.num_features % 8 != 0 and i + 3 < len(mods) and \
+        (isinstance(mods[i + 3], nn.Linear) or type(mods[i + 3]) in (nn.Conv1d, nn.Conv2d)) and isinstance(mods[i + 2], nn.ReLU)
+    return want and (nxt.num_features % 8 == 0 or pad), pad
+
+
 class TrainSequential(nn.Sequential):
     """nn.Sequential whose (BatchNorm, ReLU) pairs run fused in training mode on the GPU (see the module docstring)."""
 
@@ -422,18 +529,22 @@ class TrainSequential(nn.Sequential):
             m = mods[i]
             if isinstance(m, _BN) and (applies(x, m) or _padded_applies(x, m)):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                nxt = mods[i + 2] if relu and i + 2 < len(mods) else None
+                if stats is not None and nxt is not None and (isinstance(nxt, nn.Linear) or type(nxt) in (nn.Conv1d, nn.Conv2d)):
+                    # Conv -> BN -> ReLU -> Conv: the BatchNorm + ReLU ride in the second contraction's load path
+                    want, pad = _stats_wanted(mods, i + 2)
+                    y, st = bn_rows_linear(x, stats, m, nxt, want, pad)
+                    if y is not None:
+                        x, stats = y, st
+                        i += 3
+                        continue
                 x = batch_norm_relu(x, m, relu, stats)
                 stats = None
                 i += 2 if relu else 1
                 continue
             stats = None
             if isinstance(m, nn.Linear) or type(m) in (nn.Conv1d, nn.Conv2d):
-                nxt = mods[i + 1] if i + 1 < len(mods) else None
-                want = isinstance(nxt, _BN) and nxt.training and _round8(nxt.num_features) // 8 <= 256
-                # an odd width (196) travels zero-padded to a multiple of 8 through its BatchNorm into the next layer
-                pad = want and nxt.num_features % 8 != 0 and i + 3 < len(mods) and \
-                    (isinstance(mods[i + 3], nn.Linear) or type(mods[i + 3]) in (nn.Conv1d, nn.Conv2d)) and isinstance(mods[i + 2], nn.ReLU)
-                want = want and (nxt.num_features % 8 == 0 or pad)
+                want, pad = _stats_wanted(mods, i)
                 y, st = rows_linear(x, m, want, pad)
                 if y is not None:
                     x, stats = y, st

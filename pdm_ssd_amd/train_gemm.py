@@ -69,10 +69,11 @@ def pack_weight_pair(w, rows_to, cols_to):
     return wb, wt
 
 
-def gemm_nt(x, w, bias=None, stats=False, out=None):
+def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None):
     """x (R, K) bf16 rows (row stride a multiple of 8), w (N, K') bf16 with K' >= K zero padded -> y (R, N) bf16 =
     x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the column sums (parts, N, 2) fp32 (sum y,
-    sum y^2 of the rounded y, one part per persistent workgroup slot): what pdm_bn_relu_forward_stats takes."""
+    sum y^2 of the rounded y, one part per persistent workgroup slot): what pdm_bn_relu_forward_stats takes.
+    x_bn_coef (4, K) fp32: x is read through BatchNorm + ReLU with these coefficients (the layer before's, unapplied)."""
     R, K = x.shape
     N = w.shape[0]
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1
@@ -81,11 +82,12 @@ def gemm_nt(x, w, bias=None, stats=False, out=None):
     if stats:
         st = torch.empty((_native.lib().pdm_tg_stats_parts(R, N), N, 2), dtype=torch.float32, device=x.device)
     _native.call("pdm_tg_gemm_nt", _stream(x), R, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
-                 0 if bias is None else bias.data_ptr(), 0 if st is None else st.data_ptr())
+                 0 if bias is None else bias.data_ptr(), 0 if st is None else st.data_ptr(),
+                 0 if x_bn_coef is None else x_bn_coef.data_ptr())
     return (y, st) if stats else y
 
 
-def wgrad(dy, x, out=None, accumulate=False):
+def wgrad(dy, x, out=None, accumulate=False, x_bn_coef=None):
     """dy (R, N) bf16, x (R, K) bf16 -> dW (N, K) fp32 = dy^T . x (fp32 accumulation, deterministic)."""
     R, N = dy.shape
     K = x.shape[1]
@@ -94,7 +96,7 @@ def wgrad(dy, x, out=None, accumulate=False):
     nbytes = _native.lib().pdm_tg_wgrad_ws_bytes(R, K, N)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     _native.call("pdm_tg_wgrad", _stream(x), R, K, N, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
-                 1 if accumulate else 0, ws.data_ptr(), nbytes)
+                 1 if accumulate else 0, ws.data_ptr(), nbytes, 0 if x_bn_coef is None else x_bn_coef.data_ptr())
     return dw
 
 

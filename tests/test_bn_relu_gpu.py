@@ -180,3 +180,40 @@ def test_bn_relu_max_pool_as_one_operator(dev, shape, dtype):
     torch.testing.assert_close(seq[1].running_mean.cpu(), bn.running_mean, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(seq[1].running_var.cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
     assert float(y[:, 1].abs().max()) == 0.0 and float(xg.grad[:, 1].abs().max()) < 1e-3
+
+
+def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
+    """Conv -> BN -> ReLU -> Conv under bf16 autocast: with the BatchNorm + ReLU applied in the second contraction's load path
+    (fused_bn._BnReluRowsGemm: the normalised tensor is never written) outputs, input gradient and every parameter
+    gradient are BIT-identical to the path that runs BatchNorm + ReLU as an operator of its own; odd widths (20 -> padded to
+    24) and a biased last layer included; running statistics equal."""
+    import copy
+    from pdm_ssd_amd import fused_bn
+    torch.manual_seed(5)
+    net = fused_bn.TrainSequential(torch.nn.Conv2d(16, 32, 1, bias=False), torch.nn.BatchNorm2d(32), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(32, 20, 1, bias=False), torch.nn.BatchNorm2d(20), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(20, 8, 1, bias=True)).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
+    x0 = torch.randn(3, 16, 40, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    for flag in (True, False):
+        fused_bn.BN_IN_GEMM = flag
+        try:
+            m = copy.deepcopy(net)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+                loss = (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum()
+            loss.backward()
+            res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: b.clone() for k, b in m.named_buffers()}))
+        finally:
+            fused_bn.BN_IN_GEMM = True
+    (ya, ga, pa, ba), (yb, gb, pb, bb) = res
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb) and torch.equal(ga, gb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    for k in ba:
+        assert torch.equal(ba[k], bb[k]), k
