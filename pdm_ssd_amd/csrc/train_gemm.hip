@@ -60,14 +60,18 @@ struct TgNtArgs {
 // BatchNorm(train) + ReLU applied to eight bf16 activations on their way into LDS: bf16(relu((x - mean) * scale + beta)) — the
 // arithmetic of bn_cl_apply_kernel (bn_relu.hip), so the operand a layer reads this way is bit for bit the tensor that kernel
 // would have written.  `live` = the row exists (rows past R must stay zero).
-__device__ __forceinline__ uint4 tg_bn_relu8(uint4 v, const float *__restrict__ coef, int K, int k, bool live) {
-    if (!live) return make_uint4(0, 0, 0, 0);
+struct TgBnCoef { float mu[8], sc[8], sh[8]; };
+// a thread's eight channels k .. k + 7 are the same for every chunk it stages in a k-step: fetched once per step
+__device__ __forceinline__ TgBnCoef tg_bn_coef8(const float *__restrict__ coef, int K, int k) {
     const float4 m0 = *reinterpret_cast<const float4 *>(coef + k), m1 = *reinterpret_cast<const float4 *>(coef + k + 4);
     const float4 s0 = *reinterpret_cast<const float4 *>(coef + 2 * K + k), s1 = *reinterpret_cast<const float4 *>(coef + 2 * K + k + 4);
     const float4 b0 = *reinterpret_cast<const float4 *>(coef + 3 * K + k), b1 = *reinterpret_cast<const float4 *>(coef + 3 * K + k + 4);
-    const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    return TgBnCoef{{m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w},
+                    {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}};
+}
+__device__ __forceinline__ uint4 tg_bn_relu8(uint4 v, const TgBnCoef &c, bool live) {
+    if (!live) return make_uint4(0, 0, 0, 0);
+    const float *mu = c.mu, *sc = c.sc, *sh = c.sh;
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
     unsigned o[4];
 #pragma unroll
@@ -94,7 +98,7 @@ __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + (
 // The product is formed TRANSPOSED (D = W_tile . X_tile^T): a lane then owns one output ROW and, per 4 accumulator
 // registers, 4 CONSECUTIVE channels — 8 bytes of bf16, one ds_write_b64 — where the direct form had 16 scattered 2-byte LDS
 // writes per 32 x 32 tile (the epilogue's LDS writes alone were 1.7x the HBM time of a narrow tile).
-template <int WN, int JT>
+template <int WN, int JT, bool XF>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
     constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
@@ -161,15 +165,20 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (XF) {   // the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
+                const int k = kt * TG_BK + (t & 7) * 8;      // chunk = (t + 256 i) & 7 = t & 7 for every i
+                const TgBnCoef cf = tg_bn_coef8(a.xf, a.K, k < a.K ? k : 0);
 #pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
-                uint4 v = xr[i];
-                if (a.xf) {   // (wave-uniform) the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
-                    const int k = kt * TG_BK + chunk * 8;
-                    v = tg_bn_relu8(v, a.xf, a.K, k < a.K ? k : 0, row0 + row < a.R && k < a.K);
+                for (int i = 0; i < XI; ++i) {
+                    const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                    *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = tg_bn_relu8(xr[i], cf, row0 + row < a.R && k < a.K);
                 }
-                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                    *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = xr[i];
+                }
             }
             if (!w_resident) store_w();
             __syncthreads();
@@ -294,6 +303,7 @@ __device__ __forceinline__ tg_bf16x8 tg_tr_frag(const unsigned char *tile, int r
     return __builtin_bit_cast(tg_bf16x8, v);
 }
 
+template <bool XF>
 __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TG_WR * TG_WPITCH];
     unsigned char *Gs = smem, *Xs = smem + TG_WR * TG_WPITCH;
@@ -324,6 +334,9 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // BatchNorm + ReLU on the X operand: this thread's eight channels k0 + 8 (t & 15) .. are the same for every stage
+    TgBnCoef xcf{};
+    if constexpr (XF) { const int k = k0 + (t & 15) * 8; xcf = tg_bn_coef8(a.xf, a.K, k < a.K ? k : 0); }
     if (r_begin < r_end) load(r_begin);
     for (long long r0 = r_begin; r0 < r_end; r0 += TG_WR) {
 #pragma unroll
@@ -331,10 +344,7 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
             const int q = t + TG_T * i, row = q >> 4, chunk = q & 15;
             *reinterpret_cast<uint4 *>(Gs + row * TG_WPITCH + chunk * 16) = gr[i];
             uint4 v = xr[i];
-            if (a.xf) {
-                const int k = k0 + chunk * 8;
-                v = tg_bn_relu8(v, a.xf, a.K, k < a.K ? k : 0, r0 + row < r_end && k < a.K);
-            }
+            if constexpr (XF) v = tg_bn_relu8(v, xcf, r0 + row < r_end && k0 + chunk * 8 < a.K);
             *reinterpret_cast<uint4 *>(Xs + row * TG_WPITCH + chunk * 16) = v;
         }
         __syncthreads();
@@ -490,9 +500,15 @@ extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const voi
     TgNtArgs a;
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
     a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.xf = x_bn_coef; a.R = R; a.K = K; a.N = N;
-    if (bn == 32) hipLaunchKernelGGL((tg_nt_kernel<1, 1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
-    else if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<1, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
-    else hipLaunchKernelGGL((tg_nt_kernel<2, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+#define TG_NT(WN, JT)                                                                                                        \
+    do {                                                                                                                     \
+        if (x_bn_coef) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);  \
+        else hipLaunchKernelGGL((tg_nt_kernel<WN, JT, false>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);           \
+    } while (0)
+    if (bn == 32) TG_NT(1, 1);
+    else if (bn == 64) TG_NT(1, 2);
+    else TG_NT(2, 2);
+#undef TG_NT
     return check_launch("tg_gemm_nt");
 }
 
@@ -537,7 +553,8 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     a.dY = static_cast<const unsigned short *>(dY); a.ldy = ldy; a.X = static_cast<const unsigned short *>(X); a.ldx = ldx;
     a.partial = static_cast<float *>(workspace); a.xf = x_bn_coef; a.R = R; a.rows_per_slab = rps; a.N = N; a.K = K;
     const unsigned tiles = (unsigned)(((N + 127) / 128) * ((K + 127) / 128));
-    hipLaunchKernelGGL(tg_tn_kernel, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+    if (x_bn_coef) hipLaunchKernelGGL(tg_tn_kernel<true>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(tg_tn_kernel<false>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
     int rc = check_launch("tg_wgrad");
     if (rc) return rc;
     const long long elems = (long long)N * K;
