@@ -198,6 +198,7 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
             m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
     x0 = torch.randn(3, 16, 40, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
     res = []
+    default = fused_bn.BN_IN_GEMM
     for flag in (True, False):
         fused_bn.BN_IN_GEMM = flag
         try:
@@ -210,7 +211,7 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
             res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
                         {k: b.clone() for k, b in m.named_buffers()}))
         finally:
-            fused_bn.BN_IN_GEMM = True
+            fused_bn.BN_IN_GEMM = default
     (ya, ga, pa, ba), (yb, gb, pb, bb) = res
     assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb) and torch.equal(ga, gb)
     for k in pa:
