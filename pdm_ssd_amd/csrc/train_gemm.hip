@@ -45,6 +45,14 @@ __device__ __forceinline__ unsigned short tg_bf16(float f) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float tg_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// two fp32 -> two bf16 (round to nearest even) in one instruction, v_cvt_pk_bf16_f32: `a` in the low half.  (The software
+// form costs ~8 VALU instructions per value; the forward kernel's epilogue was issue-bound on it: SQ_ACTIVE_INST_ANY 52 %.)
+typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float tg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned tg_pack2(float a, float b) {
+    const tg_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tg_bf16x2));
+}
 
 struct TgNtArgs {
     const unsigned short *X; long long ldx;     // (R, K) bf16, row stride ldx elements (multiple of 8)
@@ -78,7 +86,7 @@ __device__ __forceinline__ uint4 tg_bn_relu8(uint4 v, const TgBnCoef &c, bool li
     for (int e = 0; e < 4; ++e) {
         const float lo = fmaxf(fmaf(__uint_as_float(w[e] << 16) - mu[2 * e], sc[2 * e], sh[2 * e]), 0.f);
         const float hi = fmaxf(fmaf(__uint_as_float(w[e] & 0xffff0000u) - mu[2 * e + 1], sc[2 * e + 1], sh[2 * e + 1]), 0.f);
-        o[e] = (unsigned)tg_bf16(lo) | ((unsigned)tg_bf16(hi) << 16);
+        o[e] = tg_pack2(lo, hi);
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -225,8 +233,8 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
                             if (col0 + col + e < a.N) b4[e] = tg_f32(tg_bf16(a.bias[col0 + col + e]));
                     }
                     uint2 v;
-                    v.x = (unsigned)tg_bf16(acc[i][j][4 * g] + b4[0]) | ((unsigned)tg_bf16(acc[i][j][4 * g + 1] + b4[1]) << 16);
-                    v.y = (unsigned)tg_bf16(acc[i][j][4 * g + 2] + b4[2]) | ((unsigned)tg_bf16(acc[i][j][4 * g + 3] + b4[3]) << 16);
+                    v.x = tg_pack2(acc[i][j][4 * g] + b4[0], acc[i][j][4 * g + 1] + b4[1]);
+                    v.y = tg_pack2(acc[i][j][4 * g + 2] + b4[2], acc[i][j][4 * g + 3] + b4[3]);
                     *reinterpret_cast<uint2 *>(smem + row * YP + col * 2) = v;
                 }
         }
@@ -376,6 +384,100 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
                 if (n < a.N && k < a.K) P[(long long)n * a.K + k] = acc[i][j][r];
             }
         }
+}
+
+// Weight gradient of NARROW layers (N, K <= C, C = 32 or 64: the first SA levels, 4 M rows each).  The 128 x 128 tile above
+// ran 16 x the MFMA work a 32 x 32 result needs and was bound by it (SQ_VALU_MFMA_BUSY 134 M cycles on a 200 us launch).
+// Here the WAVES split the ROWS of a stage: a stage holds WR rows of dY and X (C columns each, row-major as in memory), wave w
+// takes the 16-row chunks w, w + 4, ... and keeps the whole C x C result in its accumulators; the four partial results are
+// added in wave order at the end (fixed order: reproducible).  C = 32: 64-byte LDS rows are conflict-free for the transposing
+// reads as they are; C = 64: pitch 192 bytes.
+template <int C>
+__global__ __launch_bounds__(TG_T) void tg_tn_narrow_kernel(TgTnArgs a) {
+    constexpr int WR = C == 32 ? 256 : 128;                  // rows per stage
+    constexpr int P = C == 32 ? 64 : 192;                    // LDS row pitch in bytes
+    constexpr int CPR = C / 8;                               // 16-byte chunks per row
+    constexpr int T = C / 32;                                // 32 x 32 tiles per side
+    constexpr int STAGE = WR * P;
+    constexpr int SMEM = 2 * STAGE > C * C * 4 ? 2 * STAGE : C * C * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char *Gs = smem, *Xs = smem + STAGE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long slab = blockIdx.y;
+    const long long r_begin = slab * a.rows_per_slab;
+    const long long r_end = r_begin + a.rows_per_slab < a.R ? r_begin + a.rows_per_slab : a.R;
+    constexpr int LI = WR * CPR / TG_T;                      // chunks per thread and operand (4)
+    uint4 gr[LI], xr[LI];
+    auto load = [&](long long r0) {
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const int q = t + TG_T * i, row = q / CPR, chunk = q % CPR;
+            const long long r = r0 + row;
+            gr[i] = (r < r_end && chunk * 8 < a.N) ? *reinterpret_cast<const uint4 *>(a.dY + r * a.ldy + chunk * 8) : make_uint4(0, 0, 0, 0);
+            xr[i] = (r < r_end && chunk * 8 < a.K) ? *reinterpret_cast<const uint4 *>(a.X + r * a.ldx + chunk * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    tg_f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    typedef __attribute__((address_space(3))) tg_s16x4 *lds_ptr;
+    auto frag = [&](const unsigned char *tile, int r0, int c0) {   // tg_tr_frag with this kernel's pitch
+        const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3, h = g >> 1;
+        const unsigned char *p0 = tile + (r0 + 8 * h + q) * P + (c0 + 16 * (g & 1) + 4 * p) * 2;
+        const tg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
+        const tg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0 + 4 * P));
+        tg_s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(tg_bf16x8, v);
+    };
+    if (r_begin < r_end) load(r_begin);
+    for (long long r0 = r_begin; r0 < r_end; r0 += WR) {
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const int q = t + TG_T * i, row = q / CPR, chunk = q % CPR;
+            *reinterpret_cast<uint4 *>(Gs + row * P + chunk * 16) = gr[i];
+            *reinterpret_cast<uint4 *>(Xs + row * P + chunk * 16) = xr[i];
+        }
+        __syncthreads();
+        if (r0 + WR < r_end) load(r0 + WR);
+#pragma unroll
+        for (int c = 0; c < WR / 64; ++c) {                  // this wave's 16-row chunks: wave, wave + 4, ...
+            const int rc = (c * 4 + wave) * 16;
+            tg_bf16x8 af[T], bf[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) { af[i] = frag(Gs, rc, i * 32); bf[i] = frag(Xs, rc, i * 32); }
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // the four waves' results, added in wave order through an LDS tile [C][C] fp32
+    float *red = reinterpret_cast<float *>(smem);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), k = j * 32 + (lane & 31);
+                        red[n * C + k] = w == 0 ? acc[i][j][r] : red[n * C + k] + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *Pout = a.partial + slab * (long long)a.N * a.K;
+    for (int e = t; e < C * C; e += TG_T) {
+        const int n = e / C, k = e % C;
+        if (n < a.N && k < a.K) Pout[(long long)n * a.K + k] = red[e];
+    }
 }
 
 // out[c][e] = sum of in[c * TG_FOLD + k][e], k < TG_FOLD (in order): one level of a fixed-shape summation tree over the leading
@@ -553,6 +655,10 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     a.dY = static_cast<const unsigned short *>(dY); a.ldy = ldy; a.X = static_cast<const unsigned short *>(X); a.ldx = ldx;
     a.partial = static_cast<float *>(workspace); a.xf = x_bn_coef; a.R = R; a.rows_per_slab = rps; a.N = N; a.K = K;
     const unsigned tiles = (unsigned)(((N + 127) / 128) * ((K + 127) / 128));
+    if (!x_bn_coef && N <= 64 && K <= 64) {       // narrow layers: the waves split the rows, one C x C result per workgroup
+        if (N <= 32 && K <= 32) hipLaunchKernelGGL(tg_tn_narrow_kernel<32>, dim3(1, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+        else hipLaunchKernelGGL(tg_tn_narrow_kernel<64>, dim3(1, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+    } else
     if (x_bn_coef) hipLaunchKernelGGL(tg_tn_kernel<true>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
     else hipLaunchKernelGGL(tg_tn_kernel<false>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
     int rc = check_launch("tg_wgrad");
