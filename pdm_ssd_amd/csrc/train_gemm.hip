@@ -392,7 +392,7 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
 // takes the 16-row chunks w, w + 4, ... and keeps the whole C x C result in its accumulators; the four partial results are
 // added in wave order at the end (fixed order: reproducible).  C = 32: 64-byte LDS rows are conflict-free for the transposing
 // reads as they are; C = 64: pitch 192 bytes.
-template <int C>
+template <int C, bool XF>
 __global__ __launch_bounds__(TG_T) void tg_tn_narrow_kernel(TgTnArgs a) {
     constexpr int WR = C == 32 ? 256 : 128;                  // rows per stage
     constexpr int P = C == 32 ? 64 : 192;                    // LDS row pitch in bytes
@@ -434,13 +434,17 @@ __global__ __launch_bounds__(TG_T) void tg_tn_narrow_kernel(TgTnArgs a) {
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return __builtin_bit_cast(tg_bf16x8, v);
     };
+    TgBnCoef xcf{};   // BatchNorm + ReLU on the X operand: this thread's eight channels are the same for every stage
+    if constexpr (XF) { const int k = (t % CPR) * 8; xcf = tg_bn_coef8(a.xf, a.K, k < a.K ? k : 0); }
     if (r_begin < r_end) load(r_begin);
     for (long long r0 = r_begin; r0 < r_end; r0 += WR) {
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
             const int q = t + TG_T * i, row = q / CPR, chunk = q % CPR;
             *reinterpret_cast<uint4 *>(Gs + row * P + chunk * 16) = gr[i];
-            *reinterpret_cast<uint4 *>(Xs + row * P + chunk * 16) = xr[i];
+            uint4 v = xr[i];
+            if constexpr (XF) v = tg_bn_relu8(v, xcf, r0 + row < r_end && chunk * 8 < a.K);
+            *reinterpret_cast<uint4 *>(Xs + row * P + chunk * 16) = v;
         }
         __syncthreads();
         if (r0 + WR < r_end) load(r0 + WR);
@@ -655,9 +659,15 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
     a.dY = static_cast<const unsigned short *>(dY); a.ldy = ldy; a.X = static_cast<const unsigned short *>(X); a.ldx = ldx;
     a.partial = static_cast<float *>(workspace); a.xf = x_bn_coef; a.R = R; a.rows_per_slab = rps; a.N = N; a.K = K;
     const unsigned tiles = (unsigned)(((N + 127) / 128) * ((K + 127) / 128));
-    if (!x_bn_coef && N <= 64 && K <= 64) {       // narrow layers: the waves split the rows, one C x C result per workgroup
-        if (N <= 32 && K <= 32) hipLaunchKernelGGL(tg_tn_narrow_kernel<32>, dim3(1, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
-        else hipLaunchKernelGGL(tg_tn_narrow_kernel<64>, dim3(1, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+    if (N <= 64 && K <= 64) {       // narrow layers: the waves split the rows, one C x C result per workgroup
+        const dim3 g(1, (unsigned)used);
+        if (N <= 32 && K <= 32) {
+            if (x_bn_coef) hipLaunchKernelGGL((tg_tn_narrow_kernel<32, true>), g, dim3(TG_T), 0, as_stream(stream), a);
+            else hipLaunchKernelGGL((tg_tn_narrow_kernel<32, false>), g, dim3(TG_T), 0, as_stream(stream), a);
+        } else {
+            if (x_bn_coef) hipLaunchKernelGGL((tg_tn_narrow_kernel<64, true>), g, dim3(TG_T), 0, as_stream(stream), a);
+            else hipLaunchKernelGGL((tg_tn_narrow_kernel<64, false>), g, dim3(TG_T), 0, as_stream(stream), a);
+        }
     } else
     if (x_bn_coef) hipLaunchKernelGGL(tg_tn_kernel<true>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
     else hipLaunchKernelGGL(tg_tn_kernel<false>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
