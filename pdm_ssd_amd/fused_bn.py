@@ -487,7 +487,23 @@ def conv1x1(x, conv):
     return conv(x)
 
 
-_BN = (nn.BatchNorm1d, nn.BatchNorm2d)
+class _BNMeta(type):
+    """isinstance(m, _BN): BatchNorm1d / BatchNorm2d, and SyncBatchNorm while it has nothing to synchronise with (no process
+    group, or a single rank) — what tools/train.py:130-131 of the reference turns every BatchNorm into under --sync_bn.  With
+    several ranks a SyncBatchNorm keeps torch's own implementation (its statistics cross ranks: an all-gather this operator
+    does not do); the layers around it still run on the rows kernels."""
+
+    def __instancecheck__(cls, m):
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            return True
+        if isinstance(m, nn.SyncBatchNorm):
+            import torch.distributed as dist
+            return not (dist.is_available() and dist.is_initialized() and dist.get_world_size(m.process_group) > 1)
+        return False
+
+
+class _BN(metaclass=_BNMeta):
+    pass
 
 
 def _stats_wanted(mods, i):
@@ -508,7 +524,7 @@ class TrainSequential(nn.Sequential):
         mode on the GPU the last pair and the pooling run as one operator (the normalised tensor is never written)."""
         mods = list(self)
         if (ENABLED and self.training and x.is_cuda and len(mods) >= 3 and isinstance(mods[-1], nn.ReLU)
-                and isinstance(mods[-2], nn.BatchNorm2d)):
+                and isinstance(mods[-2], _BN) and mods[-2].weight.dim() == 1):
             h = self._run(x, mods[:-2])
             bn = mods[-2]
             if pool_applies(h, bn):

@@ -100,3 +100,35 @@ def test_shard_range_partitions_whole_clouds(total, world):
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     sizes = [e - b for b, e in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_train_sequential_after_convert_sync_batchnorm():
+    """tools/train.py:130-131 of the reference turns every BatchNorm into SyncBatchNorm under --sync_bn.  TrainSequential keeps
+    its child indices (state_dict keys) through the conversion, still pairs (BatchNorm, ReLU) for its fused operators while
+    there is nothing to synchronise with, and hands a multi-rank SyncBatchNorm back to torch."""
+    import torch
+    from pdm_ssd_amd import fused_bn
+    seq = fused_bn.TrainSequential(torch.nn.Conv2d(8, 16, 1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(16, 8, 1, bias=False), torch.nn.BatchNorm2d(8), torch.nn.ReLU())
+    keys = list(seq.state_dict())
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(seq)
+    assert type(conv) is fused_bn.TrainSequential and list(conv.state_dict()) == keys
+    assert isinstance(conv[1], torch.nn.SyncBatchNorm) and isinstance(conv[1], fused_bn._BN)      # no process group: a local BatchNorm
+    assert isinstance(torch.nn.BatchNorm1d(4), fused_bn._BN) and not isinstance(torch.nn.ReLU(), fused_bn._BN)
+    want, pad = fused_bn._stats_wanted(list(conv), 0)
+    assert want and not pad
+    x = torch.randn(2, 8, 5, 3)
+    y = conv.train()(x)                                       # CPU: the torch modules (SyncBatchNorm without a group = batch_norm)
+    ref = seq.train()(x)
+    torch.testing.assert_close(y, ref)
+
+    class FakeGroup:                                          # what a two-rank group looks like to the check
+        pass
+    import torch.distributed as dist
+    real = (dist.is_initialized, dist.get_world_size)
+    dist.is_initialized, dist.get_world_size = (lambda: True), (lambda group=None: 2)
+    try:
+        assert not isinstance(conv[1], fused_bn._BN)
+        assert fused_bn._stats_wanted(list(conv), 0) == (False, False)
+    finally:
+        dist.is_initialized, dist.get_world_size = real

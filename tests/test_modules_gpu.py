@@ -287,3 +287,74 @@ def test_query_and_group_channels_last(dev, bf16):
     got.backward(go.to(got.dtype).contiguous(memory_format=torch.channels_last))
     tol = 2e-2 if bf16 else 1e-5
     torch.testing.assert_close(f2.grad, f1.grad, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("c,rows_feat", [(37, False), (5, True), (96, True), (0, False)])
+def test_query_and_group_rows_form_zero_padded(dev, oracle, c, rows_feat):
+    """The rows form of the training path (pad_to_8): (B, round8(3 + C), M, ns) bf16, the first 3 + C channels equal the
+    reference tensor rounded to nearest even (QueryAndGroup of the oracle), the padding channels are exact zeros, features may
+    arrive as a (B, C, N) VIEW of point-major storage; the gradient reads only the real channels."""
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    cl = synthetic.lidar_like_clouds(2, 2048, 3)
+    xyz_np = np.ascontiguousarray(cl[:, :, :3])
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    new_xyz = xyz[:, :300].contiguous()
+    g = torch.Generator().manual_seed(c)
+    f_np = torch.randn(2, c, 2048, generator=g).numpy() if c else None
+    if c:
+        f = torch.from_numpy(f_np).to(dev)
+        feats = (f.transpose(1, 2).contiguous().transpose(1, 2) if rows_feat else f).requires_grad_(True)
+    else:
+        feats = None
+    mod = pu.QueryAndGroup(0.9, 16)
+    mod.channels_last, mod.pad_to_8 = True, True
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        got = mod(xyz, new_xyz, feats)
+    cp = (3 + c + 7) // 8 * 8
+    assert got.shape == (2, cp, 300, 16) and got.dtype == torch.bfloat16 and got.permute(0, 2, 3, 1).is_contiguous()
+    want, _ = oracle.query_and_group(0.9, 16, xyz_np, xyz_np[:, :300].copy(), f_np)
+    assert torch.equal(got[:, :3 + c].float().cpu(), torch.from_numpy(want).bfloat16().float())
+    assert float(got[:, 3 + c:].float().abs().max()) == 0.0 if cp > 3 + c else True
+    if c:
+        go = torch.randn(2, cp, 300, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        got.backward(go)
+        idx = oracle.ball_query(0.9, 16, xyz_np, xyz_np[:, :300].copy())
+        ref = oracle.grouping_operation_grad(np.ascontiguousarray(go[:, 3:3 + c].float().cpu().numpy()), idx, 2048)
+        np.testing.assert_allclose(feats.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("c2,c1,kb,sb", [(256, 1, True, False), (64, 96, True, True), (40, 0, False, False), (12, 5, False, True)])
+def test_interp_concat_rows_matches_oracle(dev, oracle, c2, c1, kb, sb):
+    """InterpConcatRows = cat([three_interpolate(known, idx, w), skip], 1) written as zero-padded bf16 rows: every element the
+    oracle's fp32 value (pinned fma order) rounded to nearest even — BIT-exact; the gradient towards the known features
+    against the oracle's scatter-add (fp32 order: 1e-4), the skip gradient = the column block of the incoming gradient."""
+    from pdm_ssd_amd import synthetic
+    from pdm_ssd_amd.pointnet2_batch import pointnet2_utils as pu
+    B, n, m = 2, 1500, 400
+    cl = synthetic.lidar_like_clouds(B, n, 8)
+    unknown = np.ascontiguousarray(cl[:, :, :3]); known = np.ascontiguousarray(cl[:, :m, :3]) + np.float32(0.05)
+    dist, idx = oracle.three_nn(unknown, known)
+    w = 1.0 / (dist + 1e-8); w = (w / w.sum(2, keepdims=True)).astype(np.float32)
+    g = torch.Generator().manual_seed(c2 + c1)
+    kf = torch.randn(B, m, c2, generator=g)
+    sf = torch.randn(B, n, c1, generator=g) if c1 else None
+    if kb: kf = kf.bfloat16().float()
+    if sb and c1: sf = sf.bfloat16().float()
+    known_rows = (kf.bfloat16() if kb else kf).to(dev).requires_grad_(True)
+    skip_rows = None if sf is None else (sf.bfloat16() if sb else sf).to(dev).requires_grad_(True)
+    out = pu.interp_concat_rows(known_rows, skip_rows, torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev))
+    ld = (c2 + c1 + 7) // 8 * 8
+    assert out.shape == (B, ld, n, 1) and out.dtype == torch.bfloat16 and out.permute(0, 2, 3, 1).is_contiguous()
+    interp = oracle.three_interpolate(np.ascontiguousarray(kf.numpy().transpose(0, 2, 1)), idx, w)      # (B, c2, n)
+    want = torch.from_numpy(interp) if sf is None else torch.cat([torch.from_numpy(interp), sf.permute(0, 2, 1)], 1)
+    assert torch.equal(out[:, :c2 + c1, :, 0].float().cpu(), want.bfloat16().float())
+    if ld > c2 + c1:
+        assert float(out[:, c2 + c1:].float().abs().max()) == 0.0
+    go = torch.randn(B, ld, n, 1, generator=g).bfloat16().to(dev)
+    out.backward(go)
+    ref = oracle.three_interpolate_grad(np.ascontiguousarray(go[:, :c2, :, 0].float().cpu().numpy()), idx, w, m)   # (B, c2, m)
+    tol = 2e-2 if kb else 1e-4        # a bf16 known tensor receives its gradient rounded to bf16
+    np.testing.assert_allclose(known_rows.grad.float().cpu().numpy(), ref.transpose(0, 2, 1), rtol=tol, atol=tol)
+    if c1:
+        assert torch.equal(skip_rows.grad.float().cpu(), go[:, c2:c2 + c1, :, 0].float().cpu().permute(0, 2, 1))
