@@ -85,22 +85,41 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
 #pragma unroll
         for (int c = 0; c < BQ_CPW; ++c) wave_done = wave_done && cnt[c] >= nsample;
         if (!wave_done) {
-            for (int s = 0; s < tile; s += 64) {
-                const int k = s + lane;
-                const bool in = k < tile;
-                const float x = in ? sx[k] : 0.f, y = in ? sy[k] : 0.f, z = in ? sz[k] : 0.f;
+            // 256 points per pass: the four 64-point groups are tested first and ONE ballot says whether any of them holds a hit
+            // for this centre — usually none does (a ball holds a handful of the cloud's points), and the ordered bookkeeping
+            // (ballot per group, prefix popcount, writes) runs only for passes that have one.  The scan is bound by instruction
+            // issue (8 waves per SIMD, ~40 instructions per group and centre before): ~12 per group on the common path now.
+            for (int s = 0; s < tile; s += 256) {
+                float px[4], py[4], pz[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = s + u * 64 + lane;
+                    in[u] = k < tile;
+                    px[u] = in[u] ? sx[k] : 0.f; py[u] = in[u] ? sy[k] : 0.f; pz[u] = in[u] ? sz[k] : 0.f;
+                }
                 bool all_done = true;
 #pragma unroll
                 for (int c = 0; c < BQ_CPW; ++c) {
                     if (cnt[c] >= nsample) continue;  // wave-uniform
-                    const float d2 = sqdist(cx[c] - x, cy[c] - y, cz[c] - z);
-                    const bool hit = in && d2 < radius2;
-                    const unsigned long long mask = __ballot(hit);
-                    if (mask != 0ull) {
-                        if (first[c] < 0) first[c] = base + s + (__ffsll((long long)mask) - 1);
-                        const int pos = cnt[c] + __popcll(mask & below);
-                        if (hit && pos < nsample) out[(size_t)c * nsample + pos] = base + k;
-                        cnt[c] += __popcll(mask);
+                    bool hit[4], any = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        hit[u] = in[u] && sqdist(cx[c] - px[u], cy[c] - py[u], cz[c] - pz[u]) < radius2;
+                        any = any || hit[u];
+                    }
+                    if (__ballot(any) != 0ull) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (cnt[c] >= nsample) break;   // wave-uniform: later groups of the pass are not consumed
+                            const unsigned long long mask = __ballot(hit[u]);
+                            if (mask != 0ull) {
+                                if (first[c] < 0) first[c] = base + s + u * 64 + (__ffsll((long long)mask) - 1);
+                                const int pos = cnt[c] + __popcll(mask & below);
+                                if (hit[u] && pos < nsample) out[(size_t)c * nsample + pos] = base + s + u * 64 + lane;
+                                cnt[c] += __popcll(mask);
+                            }
+                        }
                     }
                     all_done = all_done && cnt[c] >= nsample;
                 }
