@@ -390,11 +390,18 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
                 f.write("# 3 steady-state train steps (divide totals by 3 for one step)\n")
                 f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=110))
         return
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    dist_utils.barrier()
-    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+    import gc
+    gc.collect()
+    gc.disable()     # ~1500 launches per step are issued from Python: a generational collection inside the timed region is host time
+    try:
+        dist_utils.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        dist_utils.barrier()
+        elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+    finally:
+        gc.enable()
     return {
         "metric": f"train frames/sec ({N}-pt clouds, bs={B}/GPU, bf16 autocast)", "value": round(world * B * steps / elapsed, 2),
         "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
