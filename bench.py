@@ -973,6 +973,9 @@ def main():
             # configs[3] on this GPU: the bf16-autocast training step of the whole detector (real losses, AdamW), 5 steps
             # after 3 warm-up steps, on a fresh copy of the model (the timed inference model stays in eval mode)
             import copy
+            import gc
+            gc.collect()              # the Bench objects above hold reference cycles (bound methods): their graphs and stream
+            torch.cuda.empty_cache()  # pools are only released by a collection, and a live one costs the train step ~3 ms
             tm = copy.deepcopy(model)
             try:
                 tl = train_bench(args, tm, points, B, N, rank, world, local_rank, device, steps=5, warmup=3)
