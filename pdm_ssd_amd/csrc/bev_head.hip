@@ -2,8 +2,8 @@
 //   out[b, y, x, c] = relu(sum_{dy,dx in -1..1} w[(dy+1)*3 + dx+1][c] * in[b, y+dy, x+dx, c] + shift[c]),  zero padding.
 // The "context learning" stage of the BEV heat-map head (pdm_ssd_amd/dense_heads/pdm_heatmap_head.py; build-defined,
 // the reference snapshot holds no source for PDM-SSD's head: SURVEY.md F1).  The PDM neck's grid is channels-last
-// storage (B, H, W, C), so a cell is one contiguous row of C floats: a thread owns four channels of one cell, a
-// workgroup a run of cells; the nine taps of neighbouring cells hit L1 / L2 (three map rows = 270 KB per cloud), so
+// storage (B, H, W, C), so a cell is one contiguous row of C floats: a thread owns four channels of one cell (of a strip
+// of four cells when the map row holds eight or more), a workgroup a run of cells; the nine taps of neighbouring cells hit L1 / L2 (three map rows = 270 KB per cloud), so
 // HBM sees the map once in and once out.  Bound: HBM (8 * C bytes per cell).
 #include "common.h"
 
@@ -38,6 +38,53 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_kernel(int H, int W, int 
     out[((size_t)b * H * W + cell) * C4 + cq] = acc;
 }
 
+// The same, a thread owning a STRIP of four consecutive cells of a map row (same channel quad): the 3 x 6 input cells it needs
+// are loaded once (18 loads for 4 outputs instead of 36; the one-cell form ran at 2.5 TB/s of map traffic, bound by the vector
+// L1's request rate).  Same fma order per output as the one-cell kernel (taps row by row, left to right): identical results.
+__global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W, int C4, const float4 *__restrict__ in,
+                                                                   const float4 *__restrict__ w, const float4 *__restrict__ shift,
+                                                                   float4 *__restrict__ out, int relu) {
+    const int b = blockIdx.y;
+    const int spr = (W + 3) / 4;                       // strips per map row
+    const int cq = threadIdx.x % C4, ls = threadIdx.x / C4;
+    const long long strip = (long long)blockIdx.x * (256 / C4) + ls;
+    if (strip >= (long long)H * spr || ls >= 256 / C4) return;
+    const int y = (int)(strip / spr), x0 = (int)(strip - (long long)y * spr) * 4;
+    const float4 *__restrict__ img = in + (size_t)b * H * W * C4;
+    float4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = w[t * C4 + cq];
+    const float4 sh = shift[cq];
+    float4 acc[4] = {sh, sh, sh, sh};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        float4 v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = x0 - 1 + j;
+            v[j] = (xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * C4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (x0 + i + dx - 1 < 0 || x0 + i + dx - 1 >= W) continue;     // the one-cell kernel skips out-of-map taps: same sum
+                const float4 kk = k[(dy + 1) * 3 + dx], vv = v[i + dx];
+                acc[i].x = fmaf(kk.x, vv.x, acc[i].x); acc[i].y = fmaf(kk.y, vv.y, acc[i].y);
+                acc[i].z = fmaf(kk.z, vv.z, acc[i].z); acc[i].w = fmaf(kk.w, vv.w, acc[i].w);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (x0 + i >= W) break;
+        float4 a = acc[i];
+        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        out[((size_t)b * H * W + (size_t)y * W + x0 + i) * C4 + cq] = a;
+    }
+}
+
 }  // namespace pdm
 
 // in / out (B, H, W, C) fp32 channels-last (distinct buffers), w (9, C) tap-major with the BatchNorm scale folded in,
@@ -54,6 +101,13 @@ extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, co
     const int C4 = C / 4, cells_per_wg = 256 / C4 > 0 ? 256 / C4 : 1;
     PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "bev_depthwise3x3: C=%d", C);
     const long long cells = (long long)H * W;
+    if (W >= 8) {   // strips of four cells along x
+        const long long strips = (long long)H * ((W + 3) / 4);
+        hipLaunchKernelGGL(depthwise3x3_cl_strip_kernel, dim3((unsigned)((strips + cells_per_wg - 1) / cells_per_wg), B), dim3(256), 0,
+                           as_stream(stream), H, W, C4, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(w),
+                           reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu);
+        return check_launch("bev_depthwise3x3");
+    }
     hipLaunchKernelGGL(depthwise3x3_cl_kernel, dim3((unsigned)((cells + cells_per_wg - 1) / cells_per_wg), B), dim3(256), 0,
                        as_stream(stream), H, W, C4, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(w),
                        reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu);
@@ -62,7 +116,7 @@ extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, co
 
 // Weight gradient of the depthwise 3x3 convolution above:
 //   gw[tap][c] = sum over (b, y, x) of gout[b, y, x, c] * in[b, y + dy, x + dx, c]      (zero padding)
-// A thread owns four channels and walks a strip of cells with 36 running sums; a workgroup's threads with the same
+// A thread owns four channels and walks strips of four cells with 36 running sums; a workgroup's threads with the same
 // channel quad are reduced through LDS and added to gw (9, C) with one float atomic per (tap, channel) per workgroup.
 // (The data gradient is the same convolution with the taps mirrored: pdm_bev_depthwise3x3 on gout.)
 namespace pdm {
@@ -78,22 +132,36 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_wgrad_kernel(int H, int W
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lc < rows) {
-        for (long long cell = c_begin + lc; cell < c_end; cell += rows) {
-            const long long b = cell / ((long long)H * W);
-            const int rem = (int)(cell - b * (long long)H * W);
-            const int y = rem / W, x = rem - y * W;
-            const float4 g = gout[cell * C4 + cq];
+        // units are strips of four cells of one map row: the 3 x 6 input cells around a strip are loaded once (22 loads per
+        // four cells instead of 40)
+        const int spr = (W + 3) / 4;
+        for (long long strip = c_begin + lc; strip < c_end; strip += rows) {
+            const long long by = strip / spr;                     // b * H + y
+            const int x0 = (int)(strip - by * spr) * 4;
+            const int y = (int)(by % H);
+            float4 g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                g[i] = x0 + i < W ? gout[(by * W + x0 + i) * C4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy) {
                 const int yy = y + dy;
                 if (yy < 0 || yy >= H) continue;
+                float4 v[6];
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int xx = x + dx;
-                    if (xx < 0 || xx >= W) continue;
-                    const float4 v = in[((b * H + yy) * W + xx) * C4 + cq];
-                    float4 &a = acc[(dy + 1) * 3 + dx + 1];
-                    a.x = fmaf(g.x, v.x, a.x); a.y = fmaf(g.y, v.y, a.y); a.z = fmaf(g.z, v.z, a.z); a.w = fmaf(g.w, v.w, a.w);
+                for (int j = 0; j < 6; ++j) {
+                    const int xx = x0 - 1 + j;
+                    v[j] = (xx >= 0 && xx < W) ? in[((by + dy) * W + xx) * C4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float4 &a = acc[(dy + 1) * 3 + dx];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 vv = v[i + dx];
+                        a.x = fmaf(g[i].x, vv.x, a.x); a.y = fmaf(g[i].y, vv.y, a.y);
+                        a.z = fmaf(g[i].z, vv.z, a.z); a.w = fmaf(g[i].w, vv.w, a.w);
+                    }
                 }
             }
         }
@@ -125,7 +193,7 @@ extern "C" int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int
     PDM_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(gw)) & 15) == 0,
                 PDM_E_BADARG, "bev_depthwise3x3_wgrad: buffers must be 16-byte aligned");
     const int C4 = C / 4;
-    const long long cells = (long long)B * H * W;
+    const long long cells = (long long)B * H * ((W + 3) / 4);   // work units: strips of four cells along x
     const int rows = 256 / C4 > 0 ? 256 / C4 : 1;
     PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "bev_depthwise3x3_wgrad: C=%d", C);
     int wgs = 2048;
