@@ -390,6 +390,43 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
                 f.write("# 3 steady-state train steps (divide totals by 3 for one step)\n")
                 f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=110))
         return
+    if args.train_host_profile:     # where the HOST spends a step (the step is within ~1 ms of host-issue-bound)
+        import cProfile, pstats
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(3):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        # host synchronisations inside a step: torch's sync debug mode warns at every blocking call (a size read back for
+        # a boolean-mask index, .item(), a pageable host->device copy ...); the innermost repo frame is listed
+        import traceback, warnings
+        syncs = []
+        def note(message, category, filename, lineno, file=None, line=None):
+            frames = [fr for fr in traceback.extract_stack() if "/pdm_ssd_amd/" in fr.filename or fr.filename.endswith("bench.py")]
+            syncs.append(f"{message} <- " + " <- ".join(f"{os.path.basename(fr.filename)}:{fr.lineno}" for fr in frames[::-1][:3]))
+        old_show = warnings.showwarning
+        warnings.showwarning = note
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            step()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+            warnings.showwarning = old_show
+        torch.cuda.synchronize()
+        if rank == 0:
+            with open(args.train_host_profile, "w") as f:
+                f.write(f"# host synchronisations in one train step (forward + loss on this thread; the backward runs on the "
+                        f"autograd thread): {len(syncs)}\n")
+                for m in syncs:
+                    f.write("#   " + m + "\n")
+                f.write("# cProfile of 3 steady-state train steps (host side; divide by 3)\n")
+                st = pstats.Stats(pr, stream=f)
+                st.sort_stats("tottime").print_stats(45)
+                st.sort_stats("cumulative").print_stats(70)
+        return
     import gc
     gc.collect()
     gc.disable()     # ~1500 launches per step are issued from Python: a generational collection inside the timed region is host time
@@ -398,6 +435,7 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
+        host_ms = (time.perf_counter() - t0) / steps * 1e3    # all launches issued; the device may still be working
         dist_utils.barrier()
         elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
     finally:
@@ -405,7 +443,8 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
     return {
         "metric": f"train frames/sec ({N}-pt clouds, bs={B}/GPU, bf16 autocast)", "value": round(world * B * steps / elapsed, 2),
         "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "host_issue_ms_per_step": round(host_ms, 3),
+        "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
         "config": {"workload": f"configs[3]: PDM-SSD train step (PointNet2MSG + PDM neck + hybrid head losses), bs={B}/GPU x {N} "
                                "pts, 12 synthetic boxes per cloud, AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
@@ -655,6 +694,8 @@ def main():
                     help="BASELINE config 4 instead: bf16-autocast forward+backward+AdamW step of the detector, "
                          "DistributedDataParallel gradient all-reduce over RCCL when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-host-profile", metavar="FILE", default=None,
+                    help="with --train: write a cProfile table of three steady-state steps (host side) to FILE and exit")
     ap.add_argument("--train-profile", metavar="FILE", default=None,
                     help="with --train: after the warm-up, run 3 steps under torch.profiler and write the per-kernel table "
                          "(steady state: MIOpen's one-off solver search stays outside) to FILE instead of timing")
@@ -979,7 +1020,7 @@ def main():
             tm = copy.deepcopy(model)
             try:
                 tl = train_bench(args, tm, points, B, N, rank, world, local_rank, device, steps=5, warmup=3)
-                extras["train_step_bf16"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "final_loss")}
+                extras["train_step_bf16"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "host_issue_ms_per_step", "steps", "warmup", "dtype", "final_loss")}
                 extras["train_step_bf16"]["workload"] = tl["config"]["workload"]
             except Exception as e:   # the inference line must not be lost to a training-side failure: say so instead
                 extras["train_step_bf16"] = {"error": f"{type(e).__name__}: {e}"}

@@ -22,6 +22,7 @@
 namespace pdm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f4 *gf4c;   // a pointer the compiler must treat as global (no flat loads)
 
 struct RowsChainArgs {
     int rows, in_stride;        // floats between input rows (= cin, a multiple of 16)
@@ -41,16 +42,42 @@ constexpr int RC_THREADS = 256;
 #define RC_AHEAD 1   // rows_chain_kernel: request the next tile's input rows under the current tile's second layer
 #endif
 constexpr int RC_CHUNK_F4 = 16 * 64;   // 16 fragments x 64 lanes
+#ifndef RC_DIAG
+#define RC_DIAG 0   // timing builds (make diag-rc, results wrong): 1 = no barriers in the chunk loop, 2 = no weight stream
+#endif
 
 // chunk (mb0 .. mb0 + nmb - 1) x (kb0 .. kb0 + 3) of a layer with NKB k-blocks: thread t fetches lane t % 64 of
 // fragments (mb0 + i, kb0 + t / 64)
 // (nkg < 4: the layer's last, partial group of k-blocks — the waves past it fetch nothing)
 __device__ __forceinline__ void rc_fetch(f4 (&r)[4], const f4 *__restrict__ w, int nkb, int mb0, int kb0, int nmb, int t, int nkg = 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nmb && (nkg == 4 || (t >> 6) < nkg)) r[i] = (w + ((size_t)(mb0 + i) * nkb + kb0) * 64)[t];   // uniform base (SGPRs) + one lane offset
+    for (int i = 0; i < 4; ++i) {
+        // (the weight pointers pass through an empty asm in the tile loop, after which the compiler no longer knows they
+        //  are global and emits flat loads; those count on lgkmcnt too, so every wait for an LDS fragment also waited
+        //  for the L2 round trip of the chunk just requested: the cast makes them global loads again, vmcnt only)
+#if RC_DIAG & 16   // timing build: every fetch reads the same L1-resident 4 KB
+        if (i < nmb && (nkg == 4 || (t >> 6) < nkg)) r[i] = ((gf4c)(w + i * 64))[t & 63];
+        if (true) continue;
+#endif
+        if (i < nmb && (nkg == 4 || (t >> 6) < nkg))
+            r[i] = ((gf4c)(w + ((size_t)(mb0 + i) * nkb + kb0) * 64))[t];   // uniform base (SGPRs) + one lane offset
+    }
 }
+// A layer with ONE output block over 16 k-blocks (the heads' last layer, 256 -> <= 16): its 16 fragments travel as one chunk,
+// slot (i, kbi) = k-block 4 kbi + i, so the slots of one kbi are four consecutive k-blocks (one barrier for the layer
+// instead of four chunks of 16 MFMAs with a barrier each: the layer took ~9k cycles of a tile's ~110k for 4 % of its MFMAs)
+__device__ __forceinline__ void rc_fetch_k16(f4 (&r)[4], const f4 *__restrict__ w, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = ((gf4c)(w + (size_t)((t >> 6) * 4 + i) * 64))[t & 63];
+}
+constexpr int rc_next_nkb(int nkb, int nmb) { return (nkb == 16 && nmb == 1) ? -16 : nkb; }   // rc_layer's next_nkb: < 0 = that form
 __device__ __forceinline__ void rc_stash(const f4 (&r)[4], f4 *buf, int nmb, int t) {
+#if RC_DIAG & 8    // timing build: the chunk is fetched but not written to LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nmb) asm volatile("" :: "v"(r[i]));
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < nmb) buf[i * 256 + t] = r[i];
@@ -58,39 +85,97 @@ __device__ __forceinline__ void rc_stash(const f4 (&r)[4], f4 *buf, int nmb, int
 
 // One layer: in[NKB] -> acc[NMB] (bias added, floored).  `p` = which LDS buffer holds this layer's first chunk.
 // next_*: the first chunk of the following layer (prefetched behind this layer's last chunk), next_w == nullptr: none.
+// an[]: the A fragments of the NEXT k-block, read from LDS one k-block ahead of the MFMAs that use them (on entry: k-block
+// 0 of this layer's first chunk; on exit: k-block 0 of the chunk prefetched last).  The chunk's barrier sits in front of
+// its LAST k-block: the stash of chunk c + 1 and the barrier come there, then k-block 0 of chunk c + 1 is read from the
+// other buffer under the last 16 MFMAs of chunk c, so no LDS read latency is exposed anywhere in the stream (with the
+// barrier behind the chunk every k-block began with four ds_reads and a wait: the pipe sat idle ~1/4 of a wave's time).
+// WAR on the buffers: all reads of chunk c (k-blocks 1.. during its k-blocks 0..) complete before the barrier of chunk c,
+// and chunk c + 2 is stashed into that buffer only after it.
 template <int NKB, int NMB>
 __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], const f4 *__restrict__ w, const float *__restrict__ bias,
                                          f4 *lds, int &p, float floor, const f4 *__restrict__ next_w, int next_nkb, int next_nmb,
-                                         int t, int lane, f4 (&r)[4]) {
+                                         int t, int lane, f4 (&r)[4], f4 (&an)[4]) {
     constexpr int KG = (NKB + 3) / 4, MG = (NMB + 3) / 4, NCH = KG * MG;   // the last k-group of a layer may hold < 4 k-blocks
     const int g = lane >> 4;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) acc[mb] = *reinterpret_cast<const f4 *>(bias + 16 * mb + 4 * g);
+    if constexpr (rc_next_nkb(NKB, NMB) < 0) {   // one chunk: slot (i, kbi) = k-block 4 kbi + i (rc_fetch_k16); k ascending as in the general form
+        int fn = 0;
+        if (!(RC_DIAG & 2) && next_w) {
+            fn = next_nmb < 4 ? next_nmb : 4;
+            rc_fetch(r, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
+        }
+        const f4 *buf = lds + p * RC_CHUNK_F4 + lane, *nbuf = lds + (p ^ 1) * RC_CHUNK_F4 + lane;
+#pragma unroll
+        for (int kbi = 0; kbi < 4; ++kbi) {
+            f4 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = an[i];
+            if (kbi + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = buf[(i * 4 + kbi + 1) * 64];
+            } else {
+                if (fn) rc_stash(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
+#if !(RC_DIAG & 1)
+                __syncthreads();
+#endif
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = nbuf[(i * 4) * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f4 b = in[4 * kbi + i];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[0], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        p ^= 1;
+    } else {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int mb0 = (c / KG) * 4, kb0 = (c % KG) * 4;
-        constexpr int dummy = 0; (void)dummy;
         const int nmb = NMB - mb0 < 4 ? NMB - mb0 : 4;
         const int nkg = NKB - kb0 < 4 ? NKB - kb0 : 4;
         // next chunk -> registers
         int fn = 0;
-        if (c + 1 < NCH) {
+        if (RC_DIAG & 2) {
+        } else if (c + 1 < NCH) {
             const int nm0 = ((c + 1) / KG) * 4, nk0 = ((c + 1) % KG) * 4;
             fn = NMB - nm0 < 4 ? NMB - nm0 : 4;
             rc_fetch(r, w, NKB, nm0, nk0, fn, t, NKB - nk0 < 4 ? NKB - nk0 : 4);
+        } else if (next_w && next_nkb < 0) {
+            fn = 4;
+            rc_fetch_k16(r, next_w, t);
         } else if (next_w) {
             fn = next_nmb < 4 ? next_nmb : 4;
             rc_fetch(r, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
         }
-        // this chunk: 4 k-blocks x nmb output blocks
-        const f4 *buf = lds + p * RC_CHUNK_F4 + lane;
+        // this chunk: nkg k-blocks x nmb output blocks
+        const f4 *buf = lds + p * RC_CHUNK_F4 + lane, *nbuf = lds + (p ^ 1) * RC_CHUNK_F4 + lane;
 #pragma unroll
         for (int kbi = 0; kbi < 4; ++kbi) {
             if (kbi >= nkg) break;
             f4 a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nmb) a[i] = buf[(i * 4 + kbi) * 64];
+            for (int i = 0; i < 4; ++i) a[i] = an[i];
+            if (kbi + 1 < nkg) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nmb) an[i] = buf[(i * 4 + kbi + 1) * 64];
+            } else {
+                if (fn) rc_stash(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
+#if !(RC_DIAG & 1)
+                __syncthreads();
+#endif
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = nbuf[(i * 4) * 64];   // (fragments past the next chunk's nmb: unused values)
+            }
+            // (pinning these reads in front of the k-block's MFMAs with a sched_barrier measured 1 % slower than the scheduler's own
+            //  placement behind the 14th MFMA)
             const f4 b = in[kb0 + kbi];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -104,13 +189,11 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < nmb) acc[mb0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[mb0 + i], 0, 0, 0);
-            // keeps the fragment loads of later k-blocks from piling up in registers (an explicit one-ahead
-            // prefetch of the next k-block's fragments measured no faster: the second wave of the SIMD covers the gap)
+            // keeps the fragment loads of later k-blocks from piling up in registers
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (fn) rc_stash(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
-        __syncthreads();
         p ^= 1;
+    }
     }
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
@@ -119,6 +202,11 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
         acc[mb].z = __builtin_amdgcn_fmed3f(acc[mb].z, floor, __builtin_inff());
         acc[mb].w = __builtin_amdgcn_fmed3f(acc[mb].w, floor, __builtin_inff());
     }
+}
+// k-block 0 of the chunk in buffer p (the kernel prologue's first chunk)
+__device__ __forceinline__ void rc_first_fragments(f4 (&an)[4], const f4 *lds, int p, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) an[i] = lds[p * RC_CHUNK_F4 + lane + (i * 4) * 64];
 }
 
 // NK0 = k-blocks (16 channels) of the input, NK1 .. NK3 = output blocks of layers 1 .. 3 (0 = layer absent)
@@ -148,6 +236,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
     rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
     __syncthreads();
+    f4 an[4];
+    rc_first_fragments(an, lds, 0, lane);
     constexpr bool AHEAD = !DW && NL >= 2 && RC_AHEAD;
     f4 xn[AHEAD ? NK0 : 1];
     for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
@@ -238,9 +328,13 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
                 }
             }
         };
+#if RC_DIAG & 4   // phase timestamps of wave 0 (first two tiles of each workgroup) instead of results: tools/diag/rows_chain_phase.py
+        long long ts[4];
+        ts[0] = __builtin_amdgcn_s_memtime();
+#endif
         f4 x1[NK1];
         rc_layer<NK0, NK1>(x0, x1, w1, a.bias + a.boff[0], lds, p, (NL > 1 || a.relu_last) ? 0.0f : neg_inf, NL > 1 ? w2 : w1,
-                           NL > 1 ? NK1 : NK0, NL > 1 ? NK2 : NK1, t, lane, r);
+                           NL > 1 ? NK1 : NK0, NL > 1 ? NK2 : NK1, t, lane, r, an);
         if constexpr (NL == 1) {
             store(x1, NK1);
         } else {
@@ -250,17 +344,38 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
                 if (nrow >= a.rows) nrow = a.rows - 1;
                 const float *__restrict__ nsrc = a.in + (size_t)nrow * a.in_stride + 4 * g;
 #pragma unroll
-                for (int kb = 0; kb < NK0; ++kb) xn[kb] = *reinterpret_cast<const f4 *>(nsrc + 16 * kb);
+                for (int kb = 0; kb < NK0; ++kb)
+#if RC_DIAG & 32   // timing build: the next tile's rows are not read
+                    xn[kb] = f4{(float)nrow, 1.f, 2.f, 3.f};
+#else
+                    xn[kb] = *reinterpret_cast<const f4 *>(nsrc + 16 * kb);
+#endif
             }
+#if RC_DIAG & 4
+            asm volatile("" :: "v"(x1[0].x));
+            ts[1] = __builtin_amdgcn_s_memtime();
+#endif
             rc_layer<NK1, (NK2 ? NK2 : 1)>(x1, x2, w2, a.bias + a.boff[1], lds, p, (NL > 2 || a.relu_last) ? 0.0f : neg_inf,
-                                           NL > 2 ? w3 : w1, NL > 2 ? NK2 : NK0, NL > 2 ? NK3 : NK1, t, lane, r);
+                                           NL > 2 ? w3 : w1, NL > 2 ? rc_next_nkb(NK2, NK3) : NK0, NL > 2 ? NK3 : NK1, t, lane, r, an);
             if constexpr (NL == 2) {
                 store(x2, NK2);
             } else {
                 f4 x3[NK3 ? NK3 : 1];
+#if RC_DIAG & 4
+                asm volatile("" :: "v"(x2[0].x));
+                ts[2] = __builtin_amdgcn_s_memtime();
+#endif
                 rc_layer<(NK2 ? NK2 : 4), (NK3 ? NK3 : 1)>(x2, x3, w3, a.bias + a.boff[2], lds, p, a.relu_last ? 0.0f : neg_inf, w1, NK0, NK1, t,
-                                                          lane, r);
+                                                          lane, r, an);
+#if RC_DIAG & 4
+                asm volatile("" :: "v"(x3[0].x));
+                ts[3] = __builtin_amdgcn_s_memtime();
+                const long long k = (tl - blockIdx.x) / gridDim.x;
+                if (t == 0 && k < 2)
+                    for (int i = 0; i < 4; ++i) reinterpret_cast<long long *>(a.out)[((size_t)blockIdx.x * 2 + k) * 4 + i] = ts[i];
+#else
                 store(x3, NK3);
+#endif
             }
         }
     }
@@ -374,6 +489,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
         rc_stash(r, lds, NK2 < 4 ? NK2 : 4, t);
     }
     __syncthreads();
+    f4 an[4];
+    rc_first_fragments(an, lds, 0, lane);
     for (long long u = first; u < last; u += step) {
         const long long tl = tile_of(u);
         asm volatile("" : "+s"(w1), "+s"(w2));
@@ -392,7 +509,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
                 x0[kb] = f4{0.f, 0.f, 0.f, 0.f};
                 if (16 * kb + 4 * g + 4 <= a.c_skip) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);   // c_skip % 4 == 0 (host check)
             }
-            rc_layer<NK0, NK1>(x0, x1, w1, a.bias + a.boff[0], lds, p, neg_inf, w2, NK1, NK2, t, lane, r);
+            rc_layer<NK0, NK1>(x0, x1, w1, a.bias + a.boff[0], lds, p, neg_inf, w2, NK1, NK2, t, lane, r, an);
             if constexpr (FPC_LATE) request(0);
         } else {
             // c_skip <= 4 raw input channels; the packed layer-1 weights are zero past c_skip, so all four terms are formed
@@ -402,7 +519,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
 #pragma unroll
             for (int mb = 0; mb < NK1; ++mb) {
                 x1[mb] = *reinterpret_cast<const f4 *>(a.bias + a.boff[0] + 16 * mb + 4 * g);
-                const f4 *wr = w1 + (size_t)mb * 64 + 4 * g;   // layer 1 packed with ONE k-block: W1[16 mb + 4 g + j][0..3] = wr[j]
+                gf4c wr = (gf4c)(w1 + (size_t)mb * 64 + 4 * g);   // layer 1 packed with ONE k-block: W1[16 mb + 4 g + j][0..3] = wr[j]
                 const f4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
                 x1[mb].x += fmaf(q0.w, s3, fmaf(q0.z, s2, fmaf(q0.y, s1, q0.x * s0)));
                 x1[mb].y += fmaf(q1.w, s3, fmaf(q1.z, s2, fmaf(q1.y, s1, q1.x * s0)));
@@ -443,7 +560,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
         for (int mb = 0; mb < NK2; ++mb) x2[mb] = x1[mb % NK1];
         __syncthreads();
 #else
-        rc_layer<NK1, NK2>(x1, x2, w2, a.bias + a.boff[1], lds, p, 0.0f, NK0 > 0 ? w1 : w2, NK0 > 0 ? NK0 : NK1, NK0 > 0 ? NK1 : NK2, t, lane, r);
+        rc_layer<NK1, NK2>(x1, x2, w2, a.bias + a.boff[1], lds, p, 0.0f, NK0 > 0 ? w1 : w2, NK0 > 0 ? NK0 : NK1, NK0 > 0 ? NK1 : NK2, t, lane, r, an);
 #endif
         // rows leave line-wise through the same buffer.  (Measured and dropped: the next tile's z rows requested ahead
         // of these stores, 272 us against 258 at FP1's shape; the stores deferred by a tile and spread behind the next
@@ -464,6 +581,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
     }
 }
 
+static int g_rc_wg_per_cu = 12;   // grid cap of the chain kernels = 256 CUs x this many workgroups (2 are resident at a time)
+extern "C" int pdm_tune_rows_chain_wg_per_cu(int n) { const int old = g_rc_wg_per_cu; if (n > 0) g_rc_wg_per_cu = n; return old; }
 static int g_fpc_pad_lds = 0;   // diagnostic: extra dynamic LDS per workgroup (forces one workgroup per CU at 90 KB)
 extern "C" int pdm_tune_fp_chain_pad_lds(int bytes) { const int old = g_fpc_pad_lds; g_fpc_pad_lds = bytes; return old; }
 
@@ -480,7 +599,7 @@ int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *
     a.woff[0] = 0; a.boff[0] = 0; a.woff[1] = dims[0] * dims[1]; a.boff[1] = dims[1];
     a.out = out_pm; a.out_stride = out_stride; a.cout = cout;
     const long long tiles = (rows + 63) / 64;
-    int grid = (int)(tiles < 256 * 12 ? tiles : 256 * 12);
+    int grid = (int)(tiles < 256 * g_rc_wg_per_cu ? tiles : 256 * g_rc_wg_per_cu);
     if (grid >= 8) grid &= ~7;   // a multiple of the 8 XCDs (the tile loop covers the rest)
 #define FC_TRY(K0, K1, K2, COND)                                                                                      \
     if ((COND) && dims[1] == 16 * K1 && dims[2] == 16 * K2) {                                                        \
@@ -520,7 +639,7 @@ int rows_chain_launch(void *stream, int rows, int cin, const float *in_pm, int n
     }
     a.out = out_pm; a.out_stride = out_stride; a.cout = cout; a.relu_last = relu_last;
     const long long tiles = ((long long)rows + 63) / 64;
-    const int grid = (int)(tiles < 256 * 12 ? tiles : 256 * 12);
+    const int grid = (int)(tiles < 256 * g_rc_wg_per_cu ? tiles : 256 * g_rc_wg_per_cu);
 #define RC_TRY(K0, K1, K2, K3)                                                                                           \
     if (rc_shape_is(nlayers, dims, K0, K1, K2, K3)) {                                                                    \
         hipLaunchKernelGGL((rows_chain_kernel<K0, K1, K2, K3>), dim3(grid), dim3(RC_THREADS), 0, as_stream(stream), a);  \
@@ -552,7 +671,7 @@ int rows_chain_dw_launch(void *stream, int B, int H, int W, int C, const float *
     a.out = out_pm; a.out_stride = out_stride; a.cout = cout; a.relu_last = relu_last;
     a.dw_H = H; a.dw_W = W; a.dw_w = dw_w; a.dw_shift = dw_shift;
     const long long tiles = (long long)B * ((H + 3) / 4) * ((W + 15) / 16);
-    const int grid = (int)(tiles < 256 * 12 ? tiles : 256 * 12);
+    const int grid = (int)(tiles < 256 * g_rc_wg_per_cu ? tiles : 256 * g_rc_wg_per_cu);
     if (rc_shape_is(nlayers, dims, 8, 4, 4, 1)) {
         hipLaunchKernelGGL((rows_chain_kernel<8, 4, 4, 1, true>), dim3(grid), dim3(RC_THREADS), 0, as_stream(stream), a);
         *launched = 1;

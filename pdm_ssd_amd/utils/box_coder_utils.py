@@ -27,20 +27,28 @@ class PointResidualCoder(object):
         dxa, dya, dza = torch.split(size, 1, dim=-1)
         return dxa, dya, dza, torch.sqrt(dxa ** 2 + dya ** 2)
 
-    def encode_torch(self, gt_boxes, points, gt_classes=None):
+    def encode_torch(self, gt_boxes, points, gt_classes=None, check_classes=True):
         """gt_boxes (N, 7 + C), points (N, 3), gt_classes (N) in [1, num_classes] -> (N, 8 + C).
-        As in the reference (:164) the sizes of `gt_boxes` are clamped IN PLACE to >= 1e-5."""
+        As in the reference (:164) the sizes of `gt_boxes` are clamped IN PLACE to >= 1e-5.
+        check_classes: the reference's range assert on the classes (:166), a device->host synchronisation; the point
+        head's per-step target encoding passes False and checks the range on the device instead (class_range_ok)."""
         gt_boxes[:, 3:6] = torch.clamp_min(gt_boxes[:, 3:6], min=1e-5)
         xg, yg, zg, dxg, dyg, dzg, rg, *cgs = torch.split(gt_boxes, 1, dim=-1)
         xa, ya, za = torch.split(points, 1, dim=-1)
         if self.use_mean_size:
-            dxa, dya, dza, diagonal = self._anchor(gt_classes, gt_boxes, check=True)
+            dxa, dya, dza, diagonal = self._anchor(gt_classes, gt_boxes, check=check_classes)
             xt, yt, zt = (xg - xa) / diagonal, (yg - ya) / diagonal, (zg - za) / dza
             dxt, dyt, dzt = torch.log(dxg / dxa), torch.log(dyg / dya), torch.log(dzg / dza)
         else:
             xt, yt, zt = xg - xa, yg - ya, zg - za
             dxt, dyt, dzt = torch.log(dxg), torch.log(dyg), torch.log(dzg)
         return torch.cat([xt, yt, zt, dxt, dyt, dzt, torch.cos(rg), torch.sin(rg), *cgs], dim=-1)
+
+    def class_range_ok(self, classes):
+        """0-dim bool tensor on the device: every class id addresses a row of the mean-size table (no synchronisation)."""
+        if not self.use_mean_size:
+            return torch.ones((), dtype=torch.bool, device=classes.device)
+        return classes.max() <= self.mean_size.shape[0]
 
     def decode_torch(self, box_encodings, points, pred_classes=None):
         """box_encodings (N, 8 + C) [x, y, z, dx, dy, dz, cos, sin, ...], points (N, 3) -> boxes (N, 7 + C).

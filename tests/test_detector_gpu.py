@@ -102,6 +102,31 @@ def test_detector_training_contract_and_backward(dev):
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
 
 
+def test_training_step_issues_without_host_synchronisation(dev):
+    """Forward + losses of a training step contain no blocking call (torch's sync debug mode raises at a size read back
+    for a boolean-mask index, an .item(), a pageable host->device copy ...): the host can issue the backward ahead of
+    the device.  (bench.py --train-host-profile lists them for the bench model; the reference has three per step.)"""
+    torch.manual_seed(1)
+    model = build_pdm_ssd(SMALL).to(dev).train()
+    B, N = 2, 2048
+    cl = synthetic.lidar_like_clouds(B, N, 5)
+    gt = scene_boxes(B, 6, 3)
+    batch = {'batch_size': B, 'points': torch.from_numpy(synthetic.to_batch_points(cl)).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
+             'points_per_sample_checked': True}
+    for _ in range(2):     # first calls build caches (packed weights, grids)
+        ret, tb, disp = model(dict(batch))
+        ret['loss'].backward()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ret, tb, disp = model(dict(batch))
+        ret['loss'].backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(ret['loss'])
+
+
 def test_detector_eval_returns_nms_filtered_predictions(dev):
     torch.manual_seed(2)
     model = build_pdm_ssd(SMALL).to(dev).eval()

@@ -85,6 +85,23 @@ def test_ragged_samples_take_the_per_sample_path(ref, cpu_points_in_boxes):
     np.testing.assert_allclose(head.forward_ret_dict['point_box_labels'].numpy(), ref['box_labels'][keep], rtol=1e-6, atol=1e-6)
 
 
+def test_class_outside_the_coder_table_poisons_the_box_targets(ref, cpu_points_in_boxes):
+    """The reference asserts on a foreground class beyond the mean-size table (box_coder_utils.py:166, a host read-back
+    per step); here the step stays free of synchronisations and the box targets — hence the loss — turn NaN."""
+    head = make_head(ref, "attr").train()
+    gt = ref['gt_boxes'].copy()
+    fg_class = int(ref['cls_labels'][ref['cls_labels'] > 0][0])
+    gt[..., 7][gt[..., 7] == fg_class] = 7          # a class of boxes that DO hold points
+    bd = {'batch_size': 2, 'point_features': torch.from_numpy(ref['point_features']),
+          'point_coords': torch.from_numpy(ref['point_coords']), 'gt_boxes': torch.from_numpy(gt)}
+    head(bd)
+    assert torch.isnan(head.forward_ret_dict['point_box_labels']).all()
+    # the direct call keeps the reference's assert
+    coder = box_coder_utils.PointResidualCoder(code_size=8, use_mean_size=True, mean_size=[[3.9, 1.6, 1.56], [0.8, 0.6, 1.73]])
+    with pytest.raises(AssertionError):
+        coder.encode_torch(torch.rand(4, 7) + 0.5, torch.rand(4, 3), torch.tensor([1, 2, 3, 1]))
+
+
 def test_eval_forward_decodes_boxes_like_the_reference(ref):
     head = make_head(ref, "attr").eval()
     with torch.no_grad():

@@ -25,10 +25,20 @@ __global__ __launch_bounds__(256) void core(int iters, const f4 *__restrict__ sr
     if (s == 12345.678f) sink[0] = s;
 }
 
-extern "C" int run(int var, int wg_per_cu, int iters, float *ms_out) {
+// random_data != 0: operands uniform in [-1, 1) instead of zeros (all-zero operands toggle no multiplier bits: the
+// clock the power manager grants is not the one a real kernel gets)
+extern "C" int run2(int var, int wg_per_cu, int iters, float *ms_out, int random_data);
+extern "C" int run(int var, int wg_per_cu, int iters, float *ms_out) { return run2(var, wg_per_cu, iters, ms_out, 0); }
+extern "C" int run2(int var, int wg_per_cu, int iters, float *ms_out, int random_data) {
     f4 *src; float *sink;
     hipMalloc(&src, 4096 * sizeof(f4)); hipMalloc(&sink, 4);
     hipMemset(src, 0, 4096 * sizeof(f4));
+    if (random_data) {
+        static float host[4096 * 4];
+        unsigned s = 12345u;
+        for (int i = 0; i < 4096 * 4; ++i) { s = s * 1664525u + 1013904223u; host[i] = (float)(s >> 8) * (2.0f / 16777216.0f) - 1.0f; }
+        hipMemcpy(src, host, sizeof(host), hipMemcpyHostToDevice);
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = 256 * wg_per_cu;
     for (int rep = 0; rep < 2; ++rep) {
