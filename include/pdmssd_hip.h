@@ -476,6 +476,7 @@ int pdm_tune_fused_swz(int on);         /* XOR-swizzled LDS tiles in the general
 int pdm_tune_bq_quad(int on);           /* four centres per wave in the grid ball query */
 int pdm_tune_group_rows(int packed);    /* group_points LDS form: 0 heuristics; variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel in plain unit order) | rows per workgroup << 4 | parts of L << 8 | threads / 256 << 16 | index quads per lane and pass << 20 */
 int pdm_tune_rows_chain_wg_per_cu(int n); /* grid cap of the many-row chain kernels = 256 CUs x n workgroups (default 12; 2 resident) */
+int pdm_tune_rows_chain_xcd(int on);   /* heat-map chain kernel: contiguous patch range per XCD (default) / launch order */
 int pdm_tune_fp_chain_pad_lds(int bytes); /* diagnostic: extra LDS per workgroup of the FP chain kernel (occupancy experiments) */
 
 /* count device-to-device copies dst[k] <- src[k] (bytes[k] each; host arrays) in one launch per 48 buffers.

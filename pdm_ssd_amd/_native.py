@@ -107,6 +107,7 @@ _SIGNATURES = {
     "pdm_tune_fused_chain": None,
     "pdm_tune_fp_chain_pad_lds": None,
     "pdm_tune_rows_chain_wg_per_cu": None,
+    "pdm_tune_rows_chain_xcd": None,
     "pdm_tune_fused_swz": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],
     "pdm_gather_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 6 + [_i, _f, _vp, _vp, _vp, ctypes.c_size_t],

@@ -33,7 +33,7 @@ struct RowsChainArgs {
     int out_stride, cout, relu_last;
     // depthwise prologue (DW instantiations): a row is a cell of a channels-last (B, H, W, C) map and the chain's input
     // is relu(depthwise3x3(map)[cell] + shift) formed on the fly (bev_head.hip's kernel, same fma order)
-    int dw_H, dw_W;
+    int dw_H, dw_W, dw_by_xcd;
     const float *dw_w, *dw_shift;   // (9, C) tap-major with the BatchNorm scale folded in, (C)
 };
 
@@ -240,7 +240,45 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     rc_first_fragments(an, lds, 0, lane);
     constexpr bool AHEAD = !DW && NL >= 2 && RC_AHEAD;
     f4 xn[AHEAD ? NK0 : 1];
-    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    // DW: workgroups are dealt to the 8 XCDs round-robin, so with tiles walked in launch order the patches either side of a
+    // patch (which share its halo) ran on other XCDs and every halo cell came from HBM again (976 MB of traffic for a 577 MB
+    // map, exactly the 108 / 64 halo ratio).  XCD x walks the contiguous range [x per_xcd, (x + 1) per_xcd) of patches instead:
+    // neighbours meet in the same L2.
+    const bool by_xcd = DW && a.dw_by_xcd && (gridDim.x & 7) == 0;
+    const long long per_xcd = (ntiles + 7) >> 3, nsteps = by_xcd ? per_xcd * 8 : ntiles;
+    // DW: the halo of ALL slices of a patch sits in registers (hva, 64 VGPRs), requested one TILE ahead, under the
+    // previous tile's chain (with the next slice requested under the current slice's taps, ~500 cycles of work against an
+    // HBM round trip, every slice waited for memory)
+    f4 hva[DW ? NK0 : 1][2];
+    auto dw_tile = [&](long long step, int &b, int &y0, int &x0) -> bool {   // patch of step `step` of this workgroup's walk
+        if (step >= nsteps) return false;
+        const long long tl = by_xcd ? (step & 7) * per_xcd + (step >> 3) : step;
+        if (tl >= ntiles) return false;
+        b = (int)(tl / ((long long)ntx * nty));
+        y0 = (int)((tl / ntx) % nty) * 4; x0 = (int)(tl % ntx) * 16;
+        return true;
+    };
+    auto dw_fetch = [&](int b, int y0, int x0) {   // thread t: f4 (cell, quad) = t, t + 256 of the (4 + 2) x (16 + 2) halo, per slice
+        constexpr int C4 = NK0 * 4;
+        const f4 *__restrict__ img = reinterpret_cast<const f4 *>(a.in) + (size_t)b * a.dw_H * a.dw_W * C4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = t + u * RC_THREADS;
+            const int cell = i >> 2, quad = i & 3;
+            const int gy = y0 - 1 + cell / 18, gx = x0 - 1 + cell % 18;
+            const bool in = i < 6 * 18 * 4 && gy >= 0 && gy < a.dw_H && gx >= 0 && gx < a.dw_W;
+            const f4 *__restrict__ src = img + ((size_t)(in ? gy : 0) * a.dw_W + (in ? gx : 0)) * C4 + quad;
+#pragma unroll
+            for (int kb = 0; kb < (DW ? NK0 : 1); ++kb) hva[kb][u] = in ? src[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if constexpr (DW) {
+        int b0, y0, x0;
+        if (dw_tile(blockIdx.x, b0, y0, x0)) dw_fetch(b0, y0, x0);
+    }
+    for (long long step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const long long tl = by_xcd ? (step & 7) * per_xcd + (step >> 3) : step;
+        if (tl >= ntiles) continue;   // (uniform over the workgroup)
         const long long tile0 = tl * 64;
         // (the weight pointers pass through an empty asm so the ~140 chunk addresses are formed inside the loop with
         //  scalar adds instead of being hoisted out of it as loop invariants, where they would take every register)
@@ -271,33 +309,15 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
             }
         } else {
             // depthwise 3x3 + shift + ReLU: the patch's halo is staged through LDS 16 channels at a time (each cell of
-            // the map is fetched once per workgroup instead of up to nine times), the next slice's loads in flight
-            // under the current slice's taps
+            // the map is fetched once per workgroup instead of up to nine times), from the registers filled a tile ahead
             constexpr int C4 = NK0 * 4;
-            const f4 *__restrict__ img = reinterpret_cast<const f4 *>(a.in) + (size_t)dw_b * a.dw_H * a.dw_W * C4;
-            f4 hv[2];
-            auto fetch = [&](int kb) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = t + u * RC_THREADS;           // f4 index in the halo slice: (cell, quad)
-                    hv[u] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (i < 6 * 18 * 4) {
-                        const int cell = i >> 2, quad = i & 3;
-                        const int gy = dw_y0 - 1 + cell / 18, gx = dw_x0 - 1 + cell % 18;
-                        if (gy >= 0 && gy < a.dw_H && gx >= 0 && gx < a.dw_W) hv[u] = img[((size_t)gy * a.dw_W + gx) * C4 + kb * 4 + quad];
-                    }
-                }
-            };
-            fetch(0);
-            // a runtime loop over the 16-channel slices (unrolled, the compiler gathers all 80 tap reads up front and
-            // spills them); a lane parks its slice results in its own LDS row and reads them back as x0[] afterwards
+            // a lane parks its slice results in its own LDS row and reads them back as x0[] afterwards
             f4 *mine = xs + (wave * 16 + pos) * (C4 + 1) + g;
-#pragma unroll 1
+#pragma unroll
             for (int kb = 0; kb < NK0; ++kb) {
-                if (t < 6 * 18 * 4) halo[t] = hv[0];
-                if (t + RC_THREADS < 6 * 18 * 4) halo[t + RC_THREADS] = hv[1];
+                if (t < 6 * 18 * 4) halo[t] = hva[kb][0];
+                if (t + RC_THREADS < 6 * 18 * 4) halo[t + RC_THREADS] = hva[kb][1];
                 __syncthreads();
-                if (kb + 1 < NK0) fetch(kb + 1);
                 f4 acc = dww[9 * C4 + kb * 4 + g];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -310,6 +330,11 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
                     }
                 mine[kb * 4] = f4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
                 __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);   // (unpinned, the compiler gathers all 80 tap reads up front and spills them)
+            }
+            {   // the next tile's halo
+                int nb, ny0, nx0;
+                if (dw_tile(step + gridDim.x, nb, ny0, nx0)) dw_fetch(nb, ny0, nx0);
             }
 #pragma unroll
             for (int kb = 0; kb < NK0; ++kb) x0[kb] = mine[kb * 4];
@@ -581,6 +606,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
     }
 }
 
+static int g_rc_dw_xcd = 1;       // heat-map kernel: patches dealt to the XCDs in contiguous ranges (0: launch order)
+extern "C" int pdm_tune_rows_chain_xcd(int on) { const int old = g_rc_dw_xcd; g_rc_dw_xcd = on != 0; return old; }
 static int g_rc_wg_per_cu = 12;   // grid cap of the chain kernels = 256 CUs x this many workgroups (2 are resident at a time)
 extern "C" int pdm_tune_rows_chain_wg_per_cu(int n) { const int old = g_rc_wg_per_cu; if (n > 0) g_rc_wg_per_cu = n; return old; }
 static int g_fpc_pad_lds = 0;   // diagnostic: extra dynamic LDS per workgroup (forces one workgroup per CU at 90 KB)
@@ -669,7 +696,7 @@ int rows_chain_dw_launch(void *stream, int B, int H, int W, int C, const float *
         bo += dims[l + 1];
     }
     a.out = out_pm; a.out_stride = out_stride; a.cout = cout; a.relu_last = relu_last;
-    a.dw_H = H; a.dw_W = W; a.dw_w = dw_w; a.dw_shift = dw_shift;
+    a.dw_H = H; a.dw_W = W; a.dw_by_xcd = g_rc_dw_xcd; a.dw_w = dw_w; a.dw_shift = dw_shift;
     const long long tiles = (long long)B * ((H + 3) / 4) * ((W + 15) / 16);
     const int grid = (int)(tiles < 256 * g_rc_wg_per_cu ? tiles : 256 * g_rc_wg_per_cu);
     if (rc_shape_is(nlayers, dims, 8, 4, 4, 1)) {
