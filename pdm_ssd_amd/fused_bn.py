@@ -333,11 +333,12 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False):
     return out
 
 
-# 1: BatchNorm + ReLU of an inner layer ride in the next contraction's load path (_BnReluRowsGemm; bit-identical results, the
-# normalised tensor is never stored).  Measured at bs = 32 (A/B in one process pair, twice): 29.39 / 29.87 ms per step with,
-# 29.28 / 29.44 without — the BatchNorm apply kernel it removes streams at ~5 TB/s while the contractions it loads run at
-# 3-4 TB/s and pay ~50 VALU instructions per 16 bytes staged, so the default keeps the separate operator.
-BN_IN_GEMM = os.environ.get("PDM_BN_IN_GEMM", "0") == "1"
+# 1 (default): BatchNorm + ReLU of an inner layer ride in the next contraction's load path (_BnReluRowsGemm; bit-identical results,
+# the normalised tensor is never stored).  Measured at bs = 32, A/B twice: 26.17 / 26.24 ms per step with, 26.79 / 26.87
+# without.  (An earlier A/B read 29.4-29.9 against 29.3-29.4 and kept the separate operator: the step was bound by the HOST
+# then — a pageable host-to-device copy and two boolean-mask indexings in the target assignment stalled the issue thread
+# every step — so device-side savings did not show.)
+BN_IN_GEMM = os.environ.get("PDM_BN_IN_GEMM", "1") == "1"
 
 
 def _rows_to_layout(rows, like, channels, shape=None, dim=None):
