@@ -358,6 +358,12 @@ int pdm_bn_finalize_stats(void *stream, long long n, int C, const float *gamma, 
                           float *running_mean, float *running_var, float *coef, const float *partial, int parts);
 int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                          void *dx, const float *coef, float *grads, float *partial, int relu);
+/* its two halves: `_stats` leaves grads (4, C) = [dgamma | dbeta | p | q] and writes no dx (a consumer forms dx while it reads
+ * dy and x: pdm_tg_gemm_nt_dy); `_apply` writes dx = scale (dy [bn(x) > 0] - p - (x - mean) q) from grads already there */
+int pdm_bn_relu_backward_stats(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
+                               const float *coef, float *grads, float *partial, int relu);
+int pdm_bn_relu_backward_apply(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
+                               void *dx, const float *coef, float *grads, int relu);
 
 /* The tail of an SA scale in training — BatchNorm + ReLU + max over the ns neighbours of each group
  * (pointnet2_modules.py:46-52: the last (BatchNorm2d, ReLU) of the shared MLP, then F.max_pool2d over nsample) — as ONE
@@ -450,6 +456,14 @@ int pdm_tg_stats_parts(long long rows, int N);
  * a pass (or a tensor) of its own; bit for bit what pdm_bn_relu_forward would have written. */
 int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
                    void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef);
+/* Data gradient straight behind a BatchNorm + ReLU backward (the autograd rule of torch.nn.BatchNorm1d/2d + ReLU in
+ * pointnet2_modules.py:91-97's stacks, fused into the contraction that consumes it): dX (R, N) = dY (R, K) . W (N, K)^T with
+ * dY = scale (dZ [bn(Yp) > 0] - p - (Yp - mean) q) formed from dZ and Yp (R, K) while the operand is staged, and written to
+ * dYout (R, K) on the way for the layer's weight gradient.  coef (4, K) from pdm_bn_finalize_stats, grads (4, K) from
+ * pdm_bn_relu_backward_stats.  dYout is bit for bit pdm_bn_relu_backward's dx. */
+int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
+                      const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
+                      const float *grads);
 size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N);
 /* dW (N, K) fp32 (+)= dY (R, N)^T . X (R, K): row slabs summed in a fixed order (bit-reproducible) */
 int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "pdm_bn_relu_forward": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_bn_relu_forward_stats": [_i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_bn_relu_backward": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "pdm_bn_relu_backward_stats": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _i],
+    "pdm_bn_relu_backward_apply": [_i, _i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _i],
     "pdm_stack_voxel_query": [_i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdm_stack_local_neighbor_count": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i],
     "pdm_stack_local_neighbor_fill": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _i, _i, _i, _i],
@@ -90,6 +92,8 @@ _SIGNATURES = {
     "pdm_interp_concat_rows": [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "pdm_interp_concat_rows_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_tg_gemm_nt": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
+    "pdm_tg_gemm_nt_dy": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong,
+                          _vp, ctypes.c_longlong, _vp, _vp],
     "pdm_tg_wgrad": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _i, _vp, ctypes.c_size_t, _vp],
     "pdm_bn_finalize_stats": [ctypes.c_longlong, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_tg_colsum": [ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp],

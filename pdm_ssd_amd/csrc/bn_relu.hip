@@ -524,12 +524,13 @@ extern "C" int pdm_bn_finalize_stats(void *stream, long long n, int C, const flo
 }
 
 // Backward: dx, and grads (4, C) = [dgamma | dbeta | k1 | k2] (the caller reads the first two rows).
-extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
-                                    void *dx, const float *coef, float *grads, float *partial, int relu) {
+// phase 1 = the statistics of the gradient (reduce + finalize -> grads), phase 2 = dx from x, dy, coef and grads; 3 = both.
+static int bn_relu_backward_phases(const char *who, int phase, void *stream, int dtype, int layout, long long n, int C, long long L,
+                                   const void *x, const void *dy, void *dx, const float *coef, float *grads, float *partial, int relu) {
     if (layout == 0) L = 1;
-    if (int rc = bn_check("bn_relu_backward", dtype, layout, n, C, L, x, dy)) return rc;
-    PDM_REQUIRE(coef && grads && partial && (n == 0 || dx), PDM_E_BADARG, "bn_relu_backward: null pointer");
-    PDM_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, PDM_E_BADARG, "bn_relu_backward: dx must be 16-byte aligned");
+    if (int rc = bn_check(who, dtype, layout, n, C, L, x, dy)) return rc;
+    PDM_REQUIRE(coef && grads && ((phase & 1) == 0 || partial) && ((phase & 2) == 0 || n == 0 || dx), PDM_E_BADARG, "%s: null pointer", who);
+    PDM_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, PDM_E_BADARG, "%s: dx must be 16-byte aligned", who);
     if (n == 0) return 0;
     const int parts = pdm_bn_parts(layout, n, C, L);
     const int V = dtype ? 8 : 4;
@@ -537,23 +538,43 @@ extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long lo
     const long long ag = (nvec + 255) / 256;
     const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
     BnCoef k = coef_of(coef, nullptr, C);
-    if (layout == 0) {
-        if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, k, relu, partial);
-        else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, k, relu, partial);
-    } else {
-        if (dtype) hipLaunchKernelGGL((bn_cf_reduce_kernel<bf16_t, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, L, k, relu, partial);
-        else hipLaunchKernelGGL((bn_cf_reduce_kernel<float, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, L, k, relu, partial);
+    if (phase & 1) {
+        if (layout == 0) {
+            if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, k, relu, partial);
+            else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, k, relu, partial);
+        } else {
+            if (dtype) hipLaunchKernelGGL((bn_cf_reduce_kernel<bf16_t, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, L, k, relu, partial);
+            else hipLaunchKernelGGL((bn_cf_reduce_kernel<float, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, L, k, relu, partial);
+        }
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n * (double)L, coef, grads);
     }
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n * (double)L, coef, grads);
-    k = coef_of(coef, grads, C);
-    if (layout == 0) {
-        if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, k, relu);
-        else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, k, relu);
-    } else {
-        if (dtype) hipLaunchKernelGGL((bn_cf_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, L, k, relu);
-        else hipLaunchKernelGGL((bn_cf_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, L, k, relu);
+    if (phase & 2) {
+        k = coef_of(coef, grads, C);
+        if (layout == 0) {
+            if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, k, relu);
+            else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, k, relu);
+        } else {
+            if (dtype) hipLaunchKernelGGL((bn_cf_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, L, k, relu);
+            else hipLaunchKernelGGL((bn_cf_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, L, k, relu);
+        }
     }
-    return check_launch("bn_relu_backward");
+    return check_launch(who);
+}
+
+extern "C" int pdm_bn_relu_backward(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
+                                    void *dx, const float *coef, float *grads, float *partial, int relu) {
+    return bn_relu_backward_phases("bn_relu_backward", 3, stream, dtype, layout, n, C, L, x, dy, dx, coef, grads, partial, relu);
+}
+
+// The two halves of pdm_bn_relu_backward on their own: `_stats` leaves grads (4, C) = [dgamma | dbeta | p | q] and writes no dx —
+// for a consumer that forms dx while it reads dy and x (pdm_tg_gemm_nt_dy); `_apply` writes dx from grads already there.
+extern "C" int pdm_bn_relu_backward_stats(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x,
+                                          const void *dy, const float *coef, float *grads, float *partial, int relu) {
+    return bn_relu_backward_phases("bn_relu_backward_stats", 1, stream, dtype, layout, n, C, L, x, dy, nullptr, coef, grads, partial, relu);
+}
+extern "C" int pdm_bn_relu_backward_apply(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x,
+                                          const void *dy, void *dx, const float *coef, float *grads, int relu) {
+    return bn_relu_backward_phases("bn_relu_backward_apply", 2, stream, dtype, layout, n, C, L, x, dy, dx, coef, grads, nullptr, relu);
 }
 
 static int bn_pool_check(const char *who, int dtype, long long G, int ns, int C, const void *a, const void *b, const void *c,

@@ -61,6 +61,11 @@ struct TgNtArgs {
     const float *bias;                          // (N) fp32 or null: y = bf16(acc + bf16(bias))
     float *stats;                               // null, or [slots][N][2]: sum y, sum y^2 of the rounded outputs
     const float *xf;                            // null, or (4, K) fp32 [mean | invstd | scale | beta]: X is read through BatchNorm + ReLU
+    // XF == 2 (data gradient straight behind a BatchNorm + ReLU backward): X holds dZ, the gradient of relu(bn(Yp)); the operand is
+    // dY = scale (dZ [bn(Yp) > 0] - p - (Yp - mean) q) formed while it is staged (tg_bn_bwd8) and, by column tile 0, written to Xo
+    const unsigned short *Xa; long long ldxa;   // Yp (R, K) bf16: the BatchNorm's input
+    unsigned short *Xo; long long ldxo;         // dY (R, K) bf16 out
+    const float *gf;                            // (4, K) fp32 [dgamma | dbeta | p | q] of that BatchNorm's backward
     long long R;
     int K, N;
 };
@@ -91,6 +96,41 @@ __device__ __forceinline__ uint4 tg_bn_relu8(uint4 v, const TgBnCoef &c, bool li
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// BatchNorm(train) + ReLU BACKWARD applied to eight gradient values on their way into LDS: the arithmetic of
+// bn_cl_apply_kernel<MODE 1> (bn_relu.hip), d = y - mean, g = dz [d scale + beta > 0], out = bf16(scale ((g - p) - d q)) — bit
+// for bit the tensor that kernel would have written.
+struct TgBnBwd { float mu[8], sc[8], sh[8], p[8], q[8]; };
+__device__ __forceinline__ void tg_ld8(const float *__restrict__ src, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ TgBnBwd tg_bn_bwd_coef8(const float *__restrict__ coef, const float *__restrict__ grads, int K, int k) {
+    TgBnBwd c;
+    tg_ld8(coef + k, c.mu); tg_ld8(coef + 2 * K + k, c.sc); tg_ld8(coef + 3 * K + k, c.sh);
+    tg_ld8(grads + 2 * K + k, c.p); tg_ld8(grads + 3 * K + k, c.q);
+    return c;
+}
+__device__ __forceinline__ uint4 tg_bn_bwd8(uint4 dz, uint4 y, const TgBnBwd &c, bool live) {
+    if (!live) return make_uint4(0, 0, 0, 0);
+    const unsigned wz[4] = {dz.x, dz.y, dz.z, dz.w}, wy[4] = {y.x, y.y, y.z, y.w};
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * e + h;
+            const float yv = h ? __uint_as_float(wy[e] & 0xffff0000u) : __uint_as_float(wy[e] << 16);
+            const float gv = h ? __uint_as_float(wz[e] & 0xffff0000u) : __uint_as_float(wz[e] << 16);
+            const float d = yv - c.mu[i];
+            const float g = fmaf(d, c.sc[i], c.sh[i]) > 0.f ? gv : 0.f;
+            r[h] = c.sc[i] * (g - c.p[i] - d * c.q[i]);
+        }
+        o[e] = tg_pack2(r[0], r[1]);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // 16-byte chunk `chunk` (0..7) of row `row` of a [rows][64] bf16 LDS tile: rows 2i, 2i+1 sit in the two 128-byte halves of
 // a 256-byte bank line, the pair index permutes the chunk — 16 distinct rows reading one logical chunk hit 16 different
 // (half, chunk) slots
@@ -106,7 +146,7 @@ __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + (
 // The product is formed TRANSPOSED (D = W_tile . X_tile^T): a lane then owns one output ROW and, per 4 accumulator
 // registers, 4 CONSECUTIVE channels — 8 bytes of bf16, one ds_write_b64 — where the direct form had 16 scattered 2-byte LDS
 // writes per 32 x 32 tile (the epilogue's LDS writes alone were 1.7x the HBM time of a narrow tile).
-template <int WN, int JT, bool XF>
+template <int WN, int JT, int XF>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
     constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
@@ -126,7 +166,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     const int nk = (a.K + TG_BK - 1) / TG_BK;
     const long long row_tiles = (a.R + BM - 1) / BM;
 
-    uint4 xr[XI], wr[WI];
+    uint4 xr[XI], wr[WI], xa[XF == 2 ? XI : 1];
     auto load_x = [&](long long row0, int kt) {
         const int k0 = kt * TG_BK;
 #pragma unroll
@@ -135,6 +175,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
             const int k = k0 + chunk * 8;
             const long long r = row0 + row;
             xr[i] = (r < a.R && k < a.K) ? *reinterpret_cast<const uint4 *>(a.X + r * a.ldx + k) : make_uint4(0, 0, 0, 0);
+            if constexpr (XF == 2) xa[i] = (r < a.R && k < a.K) ? *reinterpret_cast<const uint4 *>(a.Xa + r * a.ldxa + k) : make_uint4(0, 0, 0, 0);
         }
     };
     auto load_w = [&](int kt) {
@@ -173,7 +214,35 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt) {
-            if constexpr (XF) {   // the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
+            if constexpr (XF == 2) {   // BatchNorm + ReLU backward on the way in; column tile 0 also writes the formed gradient out
+                // two channels at a time over all of the thread's chunks (they share its eight channels): ten coefficient
+                // registers live instead of forty
+                const int k = kt * TG_BK + (t & 7) * 8, kc = k < a.K ? k : 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 mu = *reinterpret_cast<const float2 *>(a.xf + kc + 2 * e), sc = *reinterpret_cast<const float2 *>(a.xf + 2 * a.K + kc + 2 * e),
+                                 sh = *reinterpret_cast<const float2 *>(a.xf + 3 * a.K + kc + 2 * e), pp = *reinterpret_cast<const float2 *>(a.gf + 2 * a.K + kc + 2 * e),
+                                 qq = *reinterpret_cast<const float2 *>(a.gf + 3 * a.K + kc + 2 * e);
+#pragma unroll
+                    for (int i = 0; i < XI; ++i) {
+                        const unsigned wz = e == 0 ? xr[i].x : e == 1 ? xr[i].y : e == 2 ? xr[i].z : xr[i].w;
+                        const unsigned wy = e == 0 ? xa[i].x : e == 1 ? xa[i].y : e == 2 ? xa[i].z : xa[i].w;
+                        const float d0 = __uint_as_float(wy << 16) - mu.x, d1 = __uint_as_float(wy & 0xffff0000u) - mu.y;
+                        const float g0 = fmaf(d0, sc.x, sh.x) > 0.f ? __uint_as_float(wz << 16) : 0.f;
+                        const float g1 = fmaf(d1, sc.y, sh.y) > 0.f ? __uint_as_float(wz & 0xffff0000u) : 0.f;
+                        const unsigned o = tg_pack2(sc.x * (g0 - pp.x - d0 * qq.x), sc.y * (g1 - pp.y - d1 * qq.y));
+                        if (e == 0) xr[i].x = o; else if (e == 1) xr[i].y = o; else if (e == 2) xr[i].z = o; else xr[i].w = o;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                    const bool live = row0 + row < a.R && k < a.K;
+                    const uint4 v = live ? xr[i] : make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = v;
+                    if (col_tile == 0 && live) *reinterpret_cast<uint4 *>(a.Xo + (row0 + row) * a.ldxo + k) = v;
+                }
+            } else if constexpr (XF == 1) {   // the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
                 const int k = kt * TG_BK + (t & 7) * 8;      // chunk = (t + 256 i) & 7 = t & 7 for every i
                 const TgBnCoef cf = tg_bn_coef8(a.xf, a.K, k < a.K ? k : 0);
 #pragma unroll
@@ -227,7 +296,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
                 for (int g = 0; g < 4; ++g) {
                     const int col = wn * JT * 32 + j * 32 + 8 * g + 4 * (lane >> 5);
                     float b4[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) {   // only the heads' last layers carry one: fetched here (L2) rather than held in 16 JT registers
+                    if (XF != 2 && a.bias) {   // only the heads' last layers carry one: fetched here (L2) rather than held in 16 JT registers
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (col0 + col + e < a.N) b4[e] = tg_f32(tg_bf16(a.bias[col0 + col + e]));
@@ -246,7 +315,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
             const long long r = row0 + row;
             const int n = col0 + chunk_o * 8;
             if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
-            if (a.stats) {   // rows beyond R were staged as zeros: they add nothing
+            if (XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -258,7 +327,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
         }
         __syncthreads();
     }
-    if (a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
+    if (XF != 2 && a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
         float *red = reinterpret_cast<float *>(smem + MAIN);       // [4 waves][BN columns] sums, then the same of squares
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -603,19 +672,56 @@ extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const voi
     const int bn = tg_bn_for(N);
     const int slots = tg_slots(R, N);
     const unsigned wgs = (unsigned)slots * (unsigned)((N + bn - 1) / bn);
-    TgNtArgs a;
+    TgNtArgs a{};
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
     a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.xf = x_bn_coef; a.R = R; a.K = K; a.N = N;
 #define TG_NT(WN, JT)                                                                                                        \
     do {                                                                                                                     \
-        if (x_bn_coef) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);  \
-        else hipLaunchKernelGGL((tg_nt_kernel<WN, JT, false>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);           \
+        if (x_bn_coef) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);  \
+        else hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 0>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);           \
     } while (0)
     if (bn == 32) TG_NT(1, 1);
     else if (bn == 64) TG_NT(1, 2);
     else TG_NT(2, 2);
 #undef TG_NT
     return check_launch("tg_gemm_nt");
+}
+
+// Data gradient straight behind a BatchNorm + ReLU backward: dX (R, N) = dY (R, K) . W (N, K)^T where dY is not in memory yet:
+//   dY = scale (dZ [bn(Yp) > 0] - p - (Yp - mean) q)        dZ, Yp (R, K) bf16; coef (4, K) as pdm_bn_finalize_stats leaves it;
+//                                                          grads (4, K) as pdm_bn_relu_backward_stats leaves it
+// is formed while the operand is staged and written to dYout (R, K) on the way (the weight gradient of the layer reads it from
+// there): the values of pdm_bn_relu_backward's dx bit for bit, without that operator's pass over dZ and Yp and without this
+// contraction's own read of dY.  Everything else as pdm_tg_gemm_nt (no bias, no statistics).
+extern "C" int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
+                                 const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
+                                 const float *grads) {
+    PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_gemm_nt_dy: negative size");
+    if (R == 0 || N == 0 || K == 0) return 0;
+    PDM_REQUIRE(dZ && Yp && W && dX && dYout && coef && grads, PDM_E_BADARG, "tg_gemm_nt_dy: null pointer");
+    PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && lddz % 8 == 0 && ldyp % 8 == 0 && ldw % 8 == 0 && lddx % 8 == 0 && lddy % 8 == 0 &&
+                lddz >= K && ldyp >= K && ldw >= K && lddx >= N && lddy >= K, PDM_E_BADARG,
+                "tg_gemm_nt_dy: K=%d N=%d and the strides must be multiples of 8 and cover the rows", K, N);
+    PDM_REQUIRE(tg_al16(dZ) && tg_al16(Yp) && tg_al16(W) && tg_al16(dX) && tg_al16(dYout) && tg_al16(coef) && tg_al16(grads), PDM_E_BADARG,
+                "tg_gemm_nt_dy: operands must be 16-byte aligned");
+    // tiles: 128 x 128 as pdm_tg_gemm_nt for wide outputs; 128 x 64 for N <= 64 (the 256-row tiles of the plain kernel would
+    // hold 64 more registers of staged operands than a wave has left: two tensors travel per row here)
+    const int bn = N <= 64 ? 64 : 128, bm = 128;
+    const long long row_tiles = (R + bm - 1) / bm;
+    const int ncol = (N + bn - 1) / bn;
+    long long sl = 1024 / ncol;
+    if (sl < 64) sl = 64;
+    if (sl > row_tiles) sl = row_tiles;
+    const int slots = (int)sl;
+    const unsigned wgs = (unsigned)slots * (unsigned)ncol;
+    TgNtArgs a{};
+    a.X = static_cast<const unsigned short *>(dZ); a.ldx = lddz; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
+    a.Y = static_cast<unsigned short *>(dX); a.ldy = lddx; a.xf = coef; a.gf = grads;
+    a.Xa = static_cast<const unsigned short *>(Yp); a.ldxa = ldyp; a.Xo = static_cast<unsigned short *>(dYout); a.ldxo = lddy;
+    a.R = R; a.K = K; a.N = N;
+    if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<2, 1, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    else hipLaunchKernelGGL((tg_nt_kernel<2, 2, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    return check_launch("tg_gemm_nt_dy");
 }
 
 static long long tg_wgrad_slabs(long long R, int K, int N) {

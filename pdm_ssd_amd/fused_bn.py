@@ -175,6 +175,34 @@ def _round8(v):
     return (v + 7) // 8 * 8
 
 
+# 1 (default): between two contractions of a stack the BatchNorm + ReLU backward's elementwise half rides in the data gradient of
+# the layer before (pdm_tg_gemm_nt_dy): no pass over (dZ, Y) of its own and one read of dY less.  Bit-identical gradients.
+LAZY_BN_BACKWARD = os.environ.get("PDM_LAZY_BN_BACKWARD", "1") == "1"
+
+
+def _take_lazy_bn_backward(link, dyr, wt, want_dx):
+    """The gradient rows `dyr` of a contraction's output may be UNFORMED: when the BatchNorm + ReLU behind it belongs to a
+    _BnReluRowsGemm, that node hands back the gradient of relu(bn(y)) as it is and leaves (y, coef, grads) in the link it shares
+    with the producer of y — this node.  Returns (dy rows formed, dx rows or None): with want_dx the data gradient forms dy on
+    the way (pdm_tg_gemm_nt_dy), otherwise the BatchNorm operator's apply half does."""
+    lazy = link.pop('lazy', None) if link is not None else None
+    if lazy is None:
+        return dyr, None
+    from . import train_gemm as tg
+    y_rows, coef, grads, ptr = lazy
+    if dyr.data_ptr() != ptr or dyr.shape != y_rows.shape or dyr.dtype != torch.bfloat16:
+        raise RuntimeError("fused_bn: an unformed BatchNorm gradient did not reach the contraction it was left for "
+                           f"(rows {tuple(dyr.shape)} at {dyr.data_ptr():#x}, expected {tuple(y_rows.shape)} at {ptr:#x})")
+    if want_dx:
+        dxr, dy_formed = tg.gemm_nt_dy(dyr, y_rows, coef, grads, wt)
+        return dy_formed, dxr
+    R, K = y_rows.shape
+    dy_formed = torch.empty_like(y_rows)
+    _native.call("pdm_bn_relu_backward_apply", torch.cuda.current_stream(dyr.device).cuda_stream, 1, 0, R, K, 1, y_rows.data_ptr(),
+                 dyr.data_ptr(), dy_formed.data_ptr(), coef.data_ptr(), grads.data_ptr(), 1)
+    return dy_formed, None
+
+
 class _RowsGemm(Function):
     """1x1 convolution / Linear over channels-last rows on this library's bf16 MFMA kernels (csrc/train_gemm.hip):
     forward y = x W^T [+ b], data gradient dx = dy W, weight gradient dW = dy^T x — no vendor GEMM, no layout or dtype
@@ -188,8 +216,9 @@ class _RowsGemm(Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, want_stats, keep_pad=False):
+    def forward(ctx, x, weight, bias, want_stats, keep_pad=False, link=None):
         from . import train_gemm as tg
+        ctx.link = link
         xr = tg.row_view(x)
         assert xr is not None
         if xr.dtype != torch.bfloat16:
@@ -226,8 +255,10 @@ class _RowsGemm(Function):
             dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
             dyr[:, :nc].copy_(src)
         dx = None
+        dyr, dxr = _take_lazy_bn_backward(ctx.link, dyr, wt, ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0]:
-            dxr = tg.gemm_nt(dyr, wt)                        # (R, K) bf16: the pad channels come out zero
+            if dxr is None:
+                dxr = tg.gemm_nt(dyr, wt)                    # (R, K) bf16: the pad channels come out zero
             dx = _rows_to_layout(dxr, None, K, xshape, xdim)
             if xdtype != torch.bfloat16:
                 dx = dx.to(xdtype)
@@ -236,7 +267,7 @@ class _RowsGemm(Function):
         db = None
         if has_bias:   # column sums of the gradient rows (torch's strided reduction over 8 of them took 0.28 ms at 524288 rows)
             db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _BnReluRowsGemm(Function):
@@ -249,8 +280,10 @@ class _BnReluRowsGemm(Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, stats, gamma, beta, running_mean, running_var, eps, momentum, weight, bias, want_stats, keep_pad):
+    def forward(ctx, x, stats, gamma, beta, running_mean, running_var, eps, momentum, weight, bias, want_stats, keep_pad,
+                in_link=None, out_link=None):
         from . import train_gemm as tg
+        ctx.in_link, ctx.link = in_link, out_link
         xr = tg.row_view(x)
         R, K = xr.shape
         N = weight.shape[0]
@@ -288,21 +321,34 @@ class _BnReluRowsGemm(Function):
             src = dy.movedim(1, -1).reshape(R, nc) if xdim > 2 else dy
             dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
             dyr[:, :nc].copy_(src)
-        da = tg.gemm_nt(dyr, wt)                             # gradient of relu(bn(x)), (R, K) bf16
+        dyr, da = _take_lazy_bn_backward(ctx.link, dyr, wt, True)   # this layer's own output gradient may arrive unformed (see there)
+        if da is None:
+            da = tg.gemm_nt(dyr, wt)                         # gradient of relu(bn(x)), (R, K) bf16
         dw = tg.wgrad(dyr, xr, x_bn_coef=coef)[:N, :Kw].reshape(weight.shape)   # the layer's input recomputed while it is read
         db = None
         if has_bias:
             db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
-        dx = torch.empty_like(xr)
         grads = torch.empty((4, K), dtype=torch.float32, device=dy.device)
         parts = _native.lib().pdm_bn_parts(0, R, K, 1)
         partial = torch.empty((parts, K, 2), dtype=torch.float32, device=dy.device)
-        _native.call("pdm_bn_relu_backward", torch.cuda.current_stream(dy.device).cuda_stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(),
-                     dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), 1)
-        return _rows_to_layout(dx, None, K, xshape, xdim), None, grads[0], grads[1], None, None, None, None, dw, db, None, None
+        stream = torch.cuda.current_stream(dy.device).cuda_stream
+        if LAZY_BN_BACKWARD and ctx.in_link is not None:
+            # The BatchNorm + ReLU backward's elementwise half is left to the producer of x: its data gradient forms
+            # dx = scale (da [bn(x) > 0] - p - (x - mean) q) while it reads da and x (pdm_tg_gemm_nt_dy) and writes it out for its
+            # weight gradient.  What travels back through autograd is `da` itself; the link says how to read it.
+            _native.call("pdm_bn_relu_backward_stats", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(), coef.data_ptr(),
+                         grads.data_ptr(), partial.data_ptr(), 1)
+            ctx.in_link['lazy'] = (xr, coef, grads, da.data_ptr())
+            dx = da
+        else:
+            dx = torch.empty_like(xr)
+            _native.call("pdm_bn_relu_backward", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(),
+                         dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), 1)
+        return (_rows_to_layout(dx, None, K, xshape, xdim), None, grads[0], grads[1], None, None, None, None, dw, db, None, None,
+                None, None)
 
 
-def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False):
+def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_link=None, out_link=None):
     """layer(relu(bn(x))) through _BnReluRowsGemm, or (None, None) when the form does not apply (the caller then runs the
     BatchNorm operator and the layer one after the other)."""
     from . import train_gemm as tg
@@ -325,7 +371,8 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False):
     if K != C:   # zero-padded width: zero gamma / beta on the padding (it stays zero), temporary running statistics
         z = bn.weight.new_zeros(K - C)
         gamma, beta, rm, rv = torch.cat([gamma, z]), torch.cat([beta, z]), torch.cat([rm, z]), torch.cat([rv, z + 1.0])
-    out = _BnReluRowsGemm.apply(x, stats, gamma, beta, rm, rv, bn.eps, bn.momentum, layer.weight, layer.bias, bool(want_stats), bool(keep_pad))
+    out = _BnReluRowsGemm.apply(x, stats, gamma, beta, rm, rv, bn.eps, bn.momentum, layer.weight, layer.bias, bool(want_stats), bool(keep_pad),
+                                in_link, out_link)
     with torch.no_grad():
         if K != C:
             bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
@@ -351,7 +398,7 @@ def _rows_to_layout(rows, like, channels, shape=None, dim=None):
     return rows.view(*lead, rows.shape[1])[..., :channels].movedim(-1, 1)
 
 
-def rows_linear(x, layer, want_stats=False, keep_pad=False):
+def rows_linear(x, layer, want_stats=False, keep_pad=False, link=None):
     """layer(x) for a 1x1 convolution / Linear through _RowsGemm when x is (castable to) bf16 rows on the GPU under bf16
     autocast; returns (y, stats) — stats None when not requested or not taken; (None, None) when the form does not apply.
     keep_pad: y keeps round8(out_channels) channels (the extra ones zero) for a BatchNorm over the padded width."""
@@ -369,7 +416,7 @@ def rows_linear(x, layer, want_stats=False, keep_pad=False):
     K = x.shape[1]
     if x.dtype not in (torch.bfloat16, torch.float32) or K != _round8(kin) or tg.row_view(x) is None:
         return None, None
-    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad))
+    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad), link)
 
 
 ROWS_GEMM = os.environ.get("PDM_ROWS_GEMM", "1") != "0"   # 0: the round-2 path (vendor GEMMs) for A/B measurements
@@ -546,6 +593,7 @@ class TrainSequential(nn.Sequential):
     def _run(x, mods):
         i = 0
         stats = None      # column sums of x taken by the GEMM that produced it, for the BatchNorm right behind it
+        link = None       # shared with the autograd node that produced x (a rows GEMM): see _take_lazy_bn_backward
         while i < len(mods):
             m = mods[i]
             if isinstance(m, _BN) and (applies(x, m) or _padded_applies(x, m)):
@@ -554,21 +602,23 @@ class TrainSequential(nn.Sequential):
                 if stats is not None and nxt is not None and (isinstance(nxt, nn.Linear) or type(nxt) in (nn.Conv1d, nn.Conv2d)):
                     # Conv -> BN -> ReLU -> Conv: the BatchNorm + ReLU ride in the second contraction's load path
                     want, pad = _stats_wanted(mods, i + 2)
-                    y, st = bn_rows_linear(x, stats, m, nxt, want, pad)
+                    out_link = {}
+                    y, st = bn_rows_linear(x, stats, m, nxt, want, pad, link, out_link)
                     if y is not None:
-                        x, stats = y, st
+                        x, stats, link = y, st, out_link
                         i += 3
                         continue
                 x = batch_norm_relu(x, m, relu, stats)
-                stats = None
+                stats = link = None
                 i += 2 if relu else 1
                 continue
-            stats = None
+            stats = link = None
             if isinstance(m, nn.Linear) or type(m) in (nn.Conv1d, nn.Conv2d):
                 want, pad = _stats_wanted(mods, i)
-                y, st = rows_linear(x, m, want, pad)
+                new_link = {}
+                y, st = rows_linear(x, m, want, pad, new_link)
                 if y is not None:
-                    x, stats = y, st
+                    x, stats, link = y, st, new_link
                 else:
                     kin = m.in_features if isinstance(m, nn.Linear) else m.in_channels
                     if x.shape[1] != kin and x.shape[1] == _round8(kin):

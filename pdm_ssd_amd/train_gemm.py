@@ -87,6 +87,22 @@ def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None):
     return (y, st) if stats else y
 
 
+def gemm_nt_dy(dz, yp, coef, grads, w):
+    """Data gradient straight behind a BatchNorm + ReLU backward: dz (R, K) bf16 = the gradient of relu(bn(yp)), yp (R, K) bf16 the
+    BatchNorm's input, coef / grads (4, K) fp32 from pdm_bn_finalize_stats / pdm_bn_relu_backward_stats, w (N, K) bf16 ->
+    (dx (R, N) bf16 = dy . w^T, dy (R, K) bf16) with dy = the BatchNorm + ReLU backward of dz, formed while dz and yp are read
+    (bit for bit pdm_bn_relu_backward's dx)."""
+    R, K = dz.shape
+    N = w.shape[0]
+    assert dz.dtype == torch.bfloat16 and yp.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and yp.shape == dz.shape
+    assert dz.stride(1) == 1 and yp.stride(1) == 1 and w.stride(1) == 1 and coef.shape == (4, K) and grads.shape == (4, K)
+    dx = torch.empty((R, N), dtype=torch.bfloat16, device=dz.device)
+    dy = torch.empty((R, K), dtype=torch.bfloat16, device=dz.device)
+    _native.call("pdm_tg_gemm_nt_dy", _stream(dz), R, K, N, dz.data_ptr(), dz.stride(0), yp.data_ptr(), yp.stride(0), w.data_ptr(),
+                 w.stride(0), dx.data_ptr(), dx.stride(0), dy.data_ptr(), dy.stride(0), coef.data_ptr(), grads.data_ptr())
+    return dx, dy
+
+
 def wgrad(dy, x, out=None, accumulate=False, x_bn_coef=None):
     """dy (R, N) bf16, x (R, K) bf16 -> dW (N, K) fp32 = dy^T . x (fp32 accumulation, deterministic)."""
     R, N = dy.shape

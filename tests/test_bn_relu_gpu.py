@@ -218,3 +218,43 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
         assert torch.equal(pa[k], pb[k]), k
     for k in ba:
         assert torch.equal(ba[k], bb[k]), k
+
+
+@pytest.mark.parametrize("widths,x_grad", [((16, 32, 20, 8), True), ((16, 32, 20, 8), False), ((24, 160, 136, 96), True),
+                                           ((72, 256, 256, 16), True)])
+def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths, x_grad):
+    """Conv -> BN -> ReLU -> Conv -> BN -> ReLU -> Conv under bf16 autocast: with the BatchNorm + ReLU backward's elementwise half
+    formed inside the data gradient of the layer before (pdm_tg_gemm_nt_dy, fused_bn.LAZY_BN_BACKWARD: the operator's pass
+    over (dZ, Y) and one read of dY disappear) the input gradient and every parameter gradient are BIT-identical to the path
+    that runs pdm_bn_relu_backward whole.  Narrow (128 x 64 tiles) and wide (128 x 128) outputs, padded widths, and a first
+    layer whose input needs no gradient (the apply half then runs on its own)."""
+    import copy
+    from pdm_ssd_amd import fused_bn
+    torch.manual_seed(11)
+    c0, c1, c2, c3 = widths
+    net = fused_bn.TrainSequential(torch.nn.Conv2d(c0, c1, 1, bias=False), torch.nn.BatchNorm2d(c1), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(c1, c2, 1, bias=False), torch.nn.BatchNorm2d(c2), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(c2, c3, 1, bias=True)).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
+    x0 = torch.randn(3, c0, 50, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    default = fused_bn.LAZY_BN_BACKWARD
+    assert default and fused_bn.BN_IN_GEMM, "the fused forms are the default path"
+    for flag in (True, False):
+        fused_bn.LAZY_BN_BACKWARD = flag
+        try:
+            m = copy.deepcopy(net)
+            x = x0.clone().requires_grad_(x_grad)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+                loss = (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum()
+            loss.backward()
+            res.append((y.detach().clone(), x.grad.clone() if x_grad else None, {k: p.grad.clone() for k, p in m.named_parameters()}))
+        finally:
+            fused_bn.LAZY_BN_BACKWARD = default
+    (ya, ga, pa), (yb, gb, pb) = res
+    assert torch.equal(ya, yb) and (not x_grad or torch.equal(ga, gb))
+    for k in pa:
+        assert torch.isfinite(pa[k]).all() and torch.equal(pa[k], pb[k]), k
