@@ -32,4 +32,4 @@ for g0 in range(0, 3072, 256):
     sl = slice(g0, g0 + 256)
     print(f"  workgroups {g0:4d}..{g0 + 255:4d}: start {float((ts[sl, 0, 0] - t0).double().mean()) / 1e3:8.1f}   "
           f"{float(d[sl, 0, 1].mean()):8.0f} / {float(d[sl, 1, 1].mean()):8.0f}   layer 1: {float(d[sl, 0, 0].mean()):8.0f} / {float(d[sl, 1, 0].mean()):8.0f}")
-print("kernel span:", float((ts[:, :, 3].max() - t0)) / 1e3, "k cycles")
+
