@@ -612,8 +612,7 @@ class Bench:
     def _advance(self):
         """The input buffers move one batch on: stage k now holds the batch that was at stage k + 1 (what the pipeline's
         state expects after a step), the last stage a new one.  One 10 MB device copy per stage, part of the step."""
-        for k, buf in enumerate(self.inputs):
-            buf.copy_(self.batches[(self.step_no + k) % self.NBATCH], non_blocking=True)
+        _native.copy_many(list(self.inputs), [self.batches[(self.step_no + k) % self.NBATCH] for k in range(len(self.inputs))])   # one launch
         self.step_no += 1
 
     def _capture(self):

@@ -179,6 +179,9 @@ class PipelinedHotPath:
         bd = self._features(points_cur, batch_size, extra)
         main.wait_stream(self.side3)
         main.wait_stream(self.side)
+        # (the hand-over only needs the backbone and the neck to be done with this batch's coordinate results; run on side3
+        #  behind the FP stack, beside the head kernels, it made the step LONGER: 4.64 against 4.53 ms — the replayed graph
+        #  then joins one more branch in front of the point head)
         _native.copy_many(_flat(self.cur), _flat(nxt), _live(nxt))
         # shift the segment states one stage on, last stage first (each launch's sources are the next one's targets)
         _native.copy_many([self.l1idx], [self.seg[S - 1][1]])
