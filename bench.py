@@ -235,6 +235,9 @@ def reference_op_section(backbone, points, B, iters=5):
         ms, how = e0.elapsed_time(e1) / reps, "hipGraph replay of the whole sequence (device time incl. the 27 launch boundaries)"
     except Exception as e:
         print(f"[bench] API-exact sequence: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+    # (Measured and dropped: the same 26 calls with the 8 searches on a second stream, every group_points call behind the event of
+    #  its own ball_query, replayed as one graph: 0.503 ms against 0.481 on one stream — the cross-branch edges cost more than the
+    #  overlap of the latency-bound searches with the copies returns.)
     # ball query is not bandwidth-bound as the reference states it: N * M distance evaluations of 8 flop per call
     # (SURVEY D3); the grid form visits only the cells a ball can reach, so its rate is quoted in reference-form
     # evaluations per second ("effective") next to the exhaustive scan's real rate
