@@ -193,10 +193,13 @@ def _take_lazy_bn_backward(link, dyr, wt, want_dx):
     if dyr.data_ptr() != ptr or dyr.shape != y_rows.shape or dyr.dtype != torch.bfloat16:
         raise RuntimeError("fused_bn: an unformed BatchNorm gradient did not reach the contraction it was left for "
                            f"(rows {tuple(dyr.shape)} at {dyr.data_ptr():#x}, expected {tuple(y_rows.shape)} at {ptr:#x})")
-    if want_dx:
+    R, K = y_rows.shape
+    # per shape (tools/diag/lazy_bn_rate.py): the fused form wins 1.1-1.5x where the data gradient has at most two column tiles
+    # (N <= 256) and rows of >= 64 bytes; 16-channel rows (0.69x) and three or more column tiles (every tile re-reads and
+    # re-forms the operand: 0.72-0.81x) take the apply half of the operator and the plain contraction
+    if want_dx and K >= 32 and wt.shape[0] <= 256:
         dxr, dy_formed = tg.gemm_nt_dy(dyr, y_rows, coef, grads, wt)
         return dy_formed, dxr
-    R, K = y_rows.shape
     dy_formed = torch.empty_like(y_rows)
     _native.call("pdm_bn_relu_backward_apply", torch.cuda.current_stream(dyr.device).cuda_stream, 1, 0, R, K, 1, y_rows.data_ptr(),
                  dyr.data_ptr(), dy_formed.data_ptr(), coef.data_ptr(), grads.data_ptr(), 1)
