@@ -73,6 +73,7 @@ struct TgNtArgs {
 // BatchNorm(train) + ReLU applied to eight bf16 activations on their way into LDS: bf16(relu((x - mean) * scale + beta)) — the
 // arithmetic of bn_cl_apply_kernel (bn_relu.hip), so the operand a layer reads this way is bit for bit the tensor that kernel
 // would have written.  `live` = the row exists (rows past R must stay zero).
+constexpr int TG_XFK = 512;      // widest BatchNorm the contractions apply on the fly (coefficient table in LDS)
 struct TgBnCoef { float mu[8], sc[8], sh[8]; };
 // a thread's eight channels k .. k + 7 are the same for every chunk it stages in a k-step: fetched once per step
 __device__ __forceinline__ TgBnCoef tg_bn_coef8(const float *__restrict__ coef, int K, int k) {
@@ -166,6 +167,16 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     const int nk = (a.K + TG_BK - 1) / TG_BK;
     const long long row_tiles = (a.R + BM - 1) / BM;
 
+    // XF: the per-channel coefficients of the BatchNorm sit in LDS for the whole launch (K <= TG_XFK, host check): read from
+    // global memory at the point of use they put an L2 round trip between the arrival of a stage's data and its LDS store
+    __shared__ __attribute__((aligned(16))) float cfs[XF == 2 ? 6 * TG_XFK : XF == 1 ? 4 * TG_XFK : 4];   // rows of TG_XFK: mean, -, scale, shift [, p, q]
+    if constexpr (XF != 0) {
+        for (int c = threadIdx.x; c < a.K; c += TG_T) {
+            cfs[c] = a.xf[c]; cfs[2 * TG_XFK + c] = a.xf[2 * a.K + c]; cfs[3 * TG_XFK + c] = a.xf[3 * a.K + c];
+            if constexpr (XF == 2) { cfs[4 * TG_XFK + c] = a.gf[2 * a.K + c]; cfs[5 * TG_XFK + c] = a.gf[3 * a.K + c]; }
+        }
+        __syncthreads();
+    }
     uint4 xr[XI], wr[WI], xa[XF == 2 ? XI : 1];
     auto load_x = [&](long long row0, int kt) {
         const int k0 = kt * TG_BK;
@@ -220,9 +231,9 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
                 const int k = kt * TG_BK + (t & 7) * 8, kc = k < a.K ? k : 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float2 mu = *reinterpret_cast<const float2 *>(a.xf + kc + 2 * e), sc = *reinterpret_cast<const float2 *>(a.xf + 2 * a.K + kc + 2 * e),
-                                 sh = *reinterpret_cast<const float2 *>(a.xf + 3 * a.K + kc + 2 * e), pp = *reinterpret_cast<const float2 *>(a.gf + 2 * a.K + kc + 2 * e),
-                                 qq = *reinterpret_cast<const float2 *>(a.gf + 3 * a.K + kc + 2 * e);
+                    const float2 mu = *reinterpret_cast<const float2 *>(cfs + kc + 2 * e), sc = *reinterpret_cast<const float2 *>(cfs + 2 * TG_XFK + kc + 2 * e),
+                                 sh = *reinterpret_cast<const float2 *>(cfs + 3 * TG_XFK + kc + 2 * e), pp = *reinterpret_cast<const float2 *>(cfs + 4 * TG_XFK + kc + 2 * e),
+                                 qq = *reinterpret_cast<const float2 *>(cfs + 5 * TG_XFK + kc + 2 * e);
 #pragma unroll
                     for (int i = 0; i < XI; ++i) {
                         const unsigned wz = e == 0 ? xr[i].x : e == 1 ? xr[i].y : e == 2 ? xr[i].z : xr[i].w;
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
                 }
             } else if constexpr (XF == 1) {   // the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
                 const int k = kt * TG_BK + (t & 7) * 8;      // chunk = (t + 256 i) & 7 = t & 7 for every i
-                const TgBnCoef cf = tg_bn_coef8(a.xf, a.K, k < a.K ? k : 0);
+                const TgBnCoef cf = tg_bn_coef8(cfs, TG_XFK, k < a.K ? k : 0);   // the (4, TG_XFK) table in LDS
 #pragma unroll
                 for (int i = 0; i < XI; ++i) {
                     const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
@@ -669,6 +680,7 @@ extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const voi
     PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldw >= K && ldy >= N,
                 PDM_E_BADARG, "tg_gemm_nt: K=%d N=%d ldx=%lld ldw=%lld ldy=%lld must be multiples of 8 and cover the rows", K, N, ldx, ldw, ldy);
     PDM_REQUIRE(tg_al16(X) && tg_al16(W) && tg_al16(Y), PDM_E_BADARG, "tg_gemm_nt: operands must be 16-byte aligned");
+    PDM_REQUIRE(!x_bn_coef || K <= TG_XFK, PDM_E_TOOLARGE, "tg_gemm_nt: x_bn_coef with K=%d (<= %d)", K, TG_XFK);
     const int bn = tg_bn_for(N);
     const int slots = tg_slots(R, N);
     const unsigned wgs = (unsigned)slots * (unsigned)((N + bn - 1) / bn);
@@ -704,6 +716,7 @@ extern "C" int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const 
                 "tg_gemm_nt_dy: K=%d N=%d and the strides must be multiples of 8 and cover the rows", K, N);
     PDM_REQUIRE(tg_al16(dZ) && tg_al16(Yp) && tg_al16(W) && tg_al16(dX) && tg_al16(dYout) && tg_al16(coef) && tg_al16(grads), PDM_E_BADARG,
                 "tg_gemm_nt_dy: operands must be 16-byte aligned");
+    PDM_REQUIRE(K <= TG_XFK, PDM_E_TOOLARGE, "tg_gemm_nt_dy: K=%d (<= %d)", K, TG_XFK);
     // tiles: 128 x 128 as pdm_tg_gemm_nt for wide outputs; 128 x 64 for N <= 64 (the 256-row tiles of the plain kernel would
     // hold 64 more registers of staged operands than a wave has left: two tensors travel per row here)
     const int bn = N <= 64 ? 64 : 128, bm = 128;

@@ -197,7 +197,7 @@ def _take_lazy_bn_backward(link, dyr, wt, want_dx):
     # per shape (tools/diag/lazy_bn_rate.py): the fused form wins 1.1-1.5x where the data gradient has at most two column tiles
     # (N <= 256) and rows of >= 64 bytes; 16-channel rows (0.69x) and three or more column tiles (every tile re-reads and
     # re-forms the operand: 0.72-0.81x) take the apply half of the operator and the plain contraction
-    if want_dx and K >= 32 and wt.shape[0] <= 256:
+    if want_dx and 32 <= K <= 512 and wt.shape[0] <= 256:
         dxr, dy_formed = tg.gemm_nt_dy(dyr, y_rows, coef, grads, wt)
         return dy_formed, dxr
     dy_formed = torch.empty_like(y_rows)
@@ -355,7 +355,7 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_lin
     """layer(relu(bn(x))) through _BnReluRowsGemm, or (None, None) when the form does not apply (the caller then runs the
     BatchNorm operator and the layer one after the other)."""
     from . import train_gemm as tg
-    if not (ENABLED and ROWS_GEMM and BN_IN_GEMM and x.is_cuda and _bf16_autocast() and layer.weight.dtype == torch.float32 and stats is not None
+    if not (ENABLED and ROWS_GEMM and BN_IN_GEMM and x.is_cuda and x.shape[1] <= 512 and _bf16_autocast() and layer.weight.dtype == torch.float32 and stats is not None
             and x.dtype == torch.bfloat16 and x.dim() in (2, 3, 4) and (applies(x, bn) or _padded_applies(x, bn))):
         return None, None
     if isinstance(layer, nn.Linear):
