@@ -365,6 +365,261 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     }
 }
 
+// The same contraction for the WIDE tiles (128 x 128) without a second operand stream, as a walk over STAGES (one k-step of one row
+// tile) with the X rows of two stages ahead in flight (two register sets that swap roles stage by stage): a wide layer has 4-8
+// k-steps per tile, and one 16 KB stage per workgroup in flight left the kernel waiting for memory at 3.1-3.7 TB/s (head layers
+// 172 -> 152 us).  The narrow tiles keep the loop above: this structure runs them 15-20 % slower (measured).
+template <int XF>
+__global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slots) {
+    constexpr int WN = 2, JT = 2;
+    constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
+    constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
+    constexpr int XI = BM * 8 / TG_T, WI = (BN * 8 + TG_T - 1) / TG_T;   // 16-byte chunks per thread
+    constexpr int CH = BN / 8;                                   // 16-byte chunks per output row
+    constexpr int YP = BN * 2 + 16;                              // pitch of the epilogue tile (8-byte writes down a column of rows)
+    constexpr int YB = BM * YP;
+    constexpr int MAIN = (XB + WB) > YB ? (XB + WB) : YB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN + 4 * BN * 2 * 4];
+    unsigned char *Xs = smem, *Ws = smem + XB;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+    const int ncol = (a.N + BN - 1) / BN;
+    const int col_tile = blockIdx.x % ncol;
+    const int slot = blockIdx.x / ncol;
+    const int col0 = col_tile * BN;
+    const int nk = (a.K + TG_BK - 1) / TG_BK;
+    const long long row_tiles = (a.R + BM - 1) / BM;
+
+    // XF: the per-channel coefficients of the BatchNorm sit in LDS for the whole launch (K <= TG_XFK, host check): read from
+    // global memory at the point of use they put an L2 round trip between the arrival of a stage's data and its LDS store
+    __shared__ __attribute__((aligned(16))) float cfs[XF == 2 ? 6 * TG_XFK : XF == 1 ? 4 * TG_XFK : 4];   // rows of TG_XFK: mean, -, scale, shift [, p, q]
+    if constexpr (XF != 0) {
+        for (int c = threadIdx.x; c < a.K; c += TG_T) {
+            cfs[c] = a.xf[c]; cfs[2 * TG_XFK + c] = a.xf[2 * a.K + c]; cfs[3 * TG_XFK + c] = a.xf[3 * a.K + c];
+            if constexpr (XF == 2) { cfs[4 * TG_XFK + c] = a.gf[2 * a.K + c]; cfs[5 * TG_XFK + c] = a.gf[3 * a.K + c]; }
+        }
+        __syncthreads();
+    }
+    // DEEP: the X rows of TWO stages ahead are in flight (two register sets that swap roles stage by stage) on the wide tiles
+    // without a second operand stream — a wide layer has 4-8 k-steps per tile, and one stage of 16 KB per workgroup in
+    // flight left the kernel waiting for memory at 3.1-3.7 TB/s.
+    constexpr bool DEEP = WN == 2 && JT == 2 && XF != 2;
+    uint4 xr[XI], xq[DEEP ? XI : 1], wr[WI], xa[XF == 2 ? XI : 1];
+    auto load_x = [&](uint4 (&xd)[XI], uint4 (&xad)[XF == 2 ? XI : 1], long long row0, int kt) {
+        const int k0 = kt * TG_BK;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+            const int k = k0 + chunk * 8;
+            const long long r = row0 + row;
+            xd[i] = (r < a.R && k < a.K) ? *reinterpret_cast<const uint4 *>(a.X + r * a.ldx + k) : make_uint4(0, 0, 0, 0);
+            if constexpr (XF == 2) xad[i] = (r < a.R && k < a.K) ? *reinterpret_cast<const uint4 *>(a.Xa + r * a.ldxa + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto load_w = [&](int kt) {
+        const int k0 = kt * TG_BK;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+            const int k = k0 + chunk * 8;
+            const int n = col0 + row;
+            wr[i] = (row < BN && n < a.N && k < a.K) ? *reinterpret_cast<const uint4 *>(a.W + (long long)n * a.ldw + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+            if (row < BN) *reinterpret_cast<uint4 *>(Ws + tg_off(row, chunk)) = wr[i];
+        }
+    };
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    constexpr int RPP = TG_T / CH;               // rows per pass of the workgroup in the store phase
+    const int chunk_o = t % CH;
+
+    // a stage = one k-step of one row tile; the workgroup walks (row tile slot, slot + slots, ...) x (k-step 0 .. nk - 1)
+    long long rt = slot;
+    int kt = 0;
+    auto after = [&](long long &r, int &k) { if (++k == nk) { k = 0; r += slots; } };
+    if (rt < row_tiles) {
+        load_x(xr, xa, rt * BM, 0); load_w(0);
+        if constexpr (DEEP) {
+            long long r1 = rt; int k1 = kt; after(r1, k1);
+            if (r1 < row_tiles) load_x(xq, xa, r1 * BM, k1);
+        }
+    }
+    bool w_resident = false;                     // nk == 1: the weights stay in LDS across row tiles
+    tg_f32x16 acc[2][JT];
+    // one stage, its X rows in `xc` (requested one stage ago, or two with DEEP)
+    auto stage = [&](uint4 (&xc)[XI], uint4 (&xac)[XF == 2 ? XI : 1]) {
+        const long long row0 = rt * BM;
+        if (kt == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        if constexpr (XF == 2) {   // BatchNorm + ReLU backward on the way in; column tile 0 also writes the formed gradient out
+            // two channels at a time over all of the thread's chunks (they share its eight channels): ten coefficient
+            // registers live instead of forty
+            const int k = kt * TG_BK + (t & 7) * 8, kc = k < a.K ? k : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 mu = *reinterpret_cast<const float2 *>(cfs + kc + 2 * e), sc = *reinterpret_cast<const float2 *>(cfs + 2 * TG_XFK + kc + 2 * e),
+                             sh = *reinterpret_cast<const float2 *>(cfs + 3 * TG_XFK + kc + 2 * e), pp = *reinterpret_cast<const float2 *>(cfs + 4 * TG_XFK + kc + 2 * e),
+                             qq = *reinterpret_cast<const float2 *>(cfs + 5 * TG_XFK + kc + 2 * e);
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const unsigned wz = e == 0 ? xc[i].x : e == 1 ? xc[i].y : e == 2 ? xc[i].z : xc[i].w;
+                    const unsigned wy = e == 0 ? xac[i].x : e == 1 ? xac[i].y : e == 2 ? xac[i].z : xac[i].w;
+                    const float d0 = __uint_as_float(wy << 16) - mu.x, d1 = __uint_as_float(wy & 0xffff0000u) - mu.y;
+                    const float g0 = fmaf(d0, sc.x, sh.x) > 0.f ? __uint_as_float(wz << 16) : 0.f;
+                    const float g1 = fmaf(d1, sc.y, sh.y) > 0.f ? __uint_as_float(wz & 0xffff0000u) : 0.f;
+                    const unsigned o = tg_pack2(sc.x * (g0 - pp.x - d0 * qq.x), sc.y * (g1 - pp.y - d1 * qq.y));
+                    if (e == 0) xc[i].x = o; else if (e == 1) xc[i].y = o; else if (e == 2) xc[i].z = o; else xc[i].w = o;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                const bool live = row0 + row < a.R && k < a.K;
+                const uint4 v = live ? xc[i] : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = v;
+                if (col_tile == 0 && live) *reinterpret_cast<uint4 *>(a.Xo + (row0 + row) * a.ldxo + k) = v;
+            }
+        } else if constexpr (XF == 1) {   // the producer's BatchNorm + ReLU, applied here instead of in a pass of its own
+            const int k = kt * TG_BK + (t & 7) * 8;      // chunk = (t + 256 i) & 7 = t & 7 for every i
+            const TgBnCoef cf = tg_bn_coef8(cfs, TG_XFK, k < a.K ? k : 0);   // the (4, TG_XFK) table in LDS
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = tg_bn_relu8(xc[i], cf, row0 + row < a.R && k < a.K);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int q = t + TG_T * i, row = q >> 3, chunk = q & 7;
+                *reinterpret_cast<uint4 *>(Xs + tg_off(row, chunk)) = xc[i];
+            }
+        }
+        if (!w_resident) store_w();
+        __syncthreads();
+        // the next loads travel behind the MFMAs (and, at a tile's last step, behind its epilogue)
+        long long r1 = rt; int k1 = kt; after(r1, k1);
+        if constexpr (DEEP) {
+            long long r2 = r1; int k2 = k1; after(r2, k2);
+            if (r2 < row_tiles) load_x(xc, xac, r2 * BM, k2);
+        } else {
+            if (r1 < row_tiles) load_x(xc, xac, r1 * BM, k1);
+        }
+        if (r1 < row_tiles && (nk > 1 || false)) load_w(k1);
+        const int rem = a.K - kt * TG_BK;
+        const int ksteps = rem >= TG_BK ? TG_BK / 16 : (rem + 15) / 16;   // 16-deep steps that hold data (K = 8: one, not four)
+        for (int s = 0; s < ksteps; ++s) {
+            const int chunk = 2 * s + (lane >> 5);
+            tg_bf16x8 af[2], bf[JT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + (lane & 31);
+                af[i] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Xs + tg_off(row, chunk)));
+            }
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int n = wn * JT * 32 + j * 32 + (lane & 31);
+                bf[j] = __builtin_bit_cast(tg_bf16x8, *reinterpret_cast<const uint4 *>(Ws + tg_off(n, chunk)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j)   // D[n][r] = sum_k W[n][k] X[r][k]: the weights as the A operand
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt == nk - 1) {
+            // ---- epilogue: bf16 (RNE) into an LDS tile [BM][pitch YP]; lane = output row, 4 registers = 4 consecutive channels
+            if (nk == 1 && XB + WB <= MAIN && YB <= XB) w_resident = true;      // the epilogue tile does not reach the weight stage
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wn * JT * 32 + j * 32 + 8 * g + 4 * (lane >> 5);
+                        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (XF != 2 && a.bias) {   // only the heads' last layers carry one: fetched here (L2) rather than held in 16 JT registers
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (col0 + col + e < a.N) b4[e] = tg_f32(tg_bf16(a.bias[col0 + col + e]));
+                        }
+                        uint2 v;
+                        v.x = tg_pack2(acc[i][j][4 * g] + b4[0], acc[i][j][4 * g + 1] + b4[1]);
+                        v.y = tg_pack2(acc[i][j][4 * g + 2] + b4[2], acc[i][j][4 * g + 3] + b4[3]);
+                        *reinterpret_cast<uint2 *>(smem + row * YP + col * 2) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < BM / RPP; ++i) {
+                const int row = t / CH + RPP * i;
+                const uint4 v = *reinterpret_cast<const uint4 *>(smem + row * YP + chunk_o * 16);
+                const long long r = row0 + row;
+                const int n = col0 + chunk_o * 8;
+                if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
+                if (XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                        s1[2 * e] += lo; s2[2 * e] = fmaf(lo, lo, s2[2 * e]);
+                        s1[2 * e + 1] += hi; s2[2 * e + 1] = fmaf(hi, hi, s2[2 * e + 1]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        rt = r1; kt = k1;
+    };
+    if constexpr (DEEP) {
+        while (rt < row_tiles) {
+            stage(xr, xa);
+            if (!(rt < row_tiles)) break;
+            stage(xq, xa);
+        }
+    } else {
+        while (rt < row_tiles) stage(xr, xa);
+    }
+    if (XF != 2 && a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
+        float *red = reinterpret_cast<float *>(smem + MAIN);       // [4 waves][BN columns] sums, then the same of squares
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int off = CH; off < 64; off <<= 1) {
+                s1[e] += __shfl_xor(s1[e], off, 64);
+                s2[e] += __shfl_xor(s2[e], off, 64);
+            }
+        }
+        if (lane < CH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[wave * BN + chunk_o * 8 + e] = s1[e];
+                red[4 * BN + wave * BN + chunk_o * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < BN && col0 + t < a.N) {
+            const float sa = ((red[t] + red[BN + t]) + red[2 * BN + t]) + red[3 * BN + t];
+            const float sb = ((red[4 * BN + t] + red[5 * BN + t]) + red[6 * BN + t]) + red[7 * BN + t];
+            float *o = a.stats + ((long long)slot * a.N + col0 + t) * 2;
+            o[0] = sa; o[1] = sb;
+        }
+    }
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------------------
 struct TgTnArgs {
     const unsigned short *dY; long long ldy;    // (R, N) bf16
@@ -694,7 +949,8 @@ extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const voi
     } while (0)
     if (bn == 32) TG_NT(1, 1);
     else if (bn == 64) TG_NT(1, 2);
-    else TG_NT(2, 2);
+    else if (x_bn_coef) hipLaunchKernelGGL((tg_nt_deep_kernel<1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    else hipLaunchKernelGGL((tg_nt_deep_kernel<0>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
 #undef TG_NT
     return check_launch("tg_gemm_nt");
 }
