@@ -54,6 +54,14 @@ __device__ __forceinline__ unsigned tg_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tg_bf16x2));
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by launch id.  This gives XCD x a CONTIGUOUS range of work ids, so that the
+// workgroups sharing an operand tile (the column tiles of one row tile; the dW tiles of one row slab) are neighbours in ONE
+// XCD's L2 instead of eight (bijective for any total: the first total % 8 XCDs take one more).
+__device__ __forceinline__ unsigned tg_xcd_contiguous(unsigned launch_id, unsigned total) {
+    const unsigned q = total >> 3, r = total & 7u, xcd = launch_id & 7u, i = launch_id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
 struct TgNtArgs {
     const unsigned short *X; long long ldx;     // (R, K) bf16, row stride ldx elements (multiple of 8)
     const unsigned short *W; long long ldw;     // (N, K) bf16
@@ -161,8 +169,9 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int ncol = (a.N + BN - 1) / BN;
-    const int col_tile = blockIdx.x % ncol;
-    const int slot = blockIdx.x / ncol;
+    const unsigned wg = ncol > 1 ? tg_xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;   // column tiles of a slot: one XCD
+    const int col_tile = wg % ncol;
+    const int slot = wg / ncol;
     const int col0 = col_tile * BN;
     const int nk = (a.K + TG_BK - 1) / TG_BK;
     const long long row_tiles = (a.R + BM - 1) / BM;
@@ -384,8 +393,9 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int ncol = (a.N + BN - 1) / BN;
-    const int col_tile = blockIdx.x % ncol;
-    const int slot = blockIdx.x / ncol;
+    const unsigned wg = ncol > 1 ? tg_xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;   // column tiles of a slot: one XCD
+    const int col_tile = wg % ncol;
+    const int slot = wg / ncol;
     const int col0 = col_tile * BN;
     const int nk = (a.K + TG_BK - 1) / TG_BK;
     const long long row_tiles = (a.R + BM - 1) / BM;
@@ -653,8 +663,12 @@ __global__ __launch_bounds__(TG_T) void tg_tn_kernel(TgTnArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nkt = (a.K + 127) / 128;
-    const int n0 = (blockIdx.x / nkt) * 128, k0 = (blockIdx.x % nkt) * 128;
-    const long long slab = blockIdx.y;
+    // one-dimensional grid of tiles x slabs; the dW tiles of one slab (they re-read its dY and X rows) are neighbours in one XCD
+    const unsigned ntile = (unsigned)(((a.N + 127) / 128) * nkt);
+    const unsigned wg = ntile > 1 ? tg_xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned tile = wg % ntile;
+    const int n0 = (tile / nkt) * 128, k0 = (tile % nkt) * 128;
+    const long long slab = wg / ntile;
     const long long r_begin = slab * a.rows_per_slab;
     const long long r_end = r_begin + a.rows_per_slab < a.R ? r_begin + a.rows_per_slab : a.R;
 
@@ -1044,8 +1058,8 @@ extern "C" int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void 
             else hipLaunchKernelGGL((tg_tn_narrow_kernel<64, false>), g, dim3(TG_T), 0, as_stream(stream), a);
         }
     } else
-    if (x_bn_coef) hipLaunchKernelGGL(tg_tn_kernel<true>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL(tg_tn_kernel<false>, dim3(tiles, (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+    if (x_bn_coef) hipLaunchKernelGGL(tg_tn_kernel<true>, dim3(tiles * (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(tg_tn_kernel<false>, dim3(tiles * (unsigned)used), dim3(TG_T), 0, as_stream(stream), a);
     int rc = check_launch("tg_wgrad");
     if (rc) return rc;
     const long long elems = (long long)N * K;
