@@ -179,6 +179,29 @@ __global__ void pdm_normalize_kernel(long long cells, int C, int W, int H, int D
     }
 }
 
+// The same for the channels-last layout with C * D a multiple of 4: a thread owns 16 bytes (the scalar form above pays a 64-bit
+// division per 4-byte element and streamed the 577 MB map at 2.9 TB/s).  Same arithmetic per element: x *= 1 / w where |w| > eps.
+__global__ __launch_bounds__(256) void pdm_normalize_cl4_kernel(long long nvec, int CD4, int D, float eps, float4 *__restrict__ grid,
+                                                                const float *__restrict__ wsum) {
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long long)gridDim.x * blockDim.x) {
+        const long long col = v / CD4;                       // (b, y, x) cell
+        float4 x = grid[v];
+        if (D == 1) {
+            const float ws = wsum[col];
+            if (fabsf(ws) > eps) { const float inv = 1.0f / ws; x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv; grid[v] = x; }
+        } else {
+            const int q0 = (int)(v - col * CD4) * 4;         // first of the four inner indices c * D + z
+            float *e = reinterpret_cast<float *>(&x);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ws = wsum[col * D + (q0 + i) % D];
+                if (fabsf(ws) > eps) e[i] *= 1.0f / ws;
+            }
+            grid[v] = x;
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -356,6 +379,13 @@ extern "C" int pdm_bev_normalize(void *stream, int B, int C, int W, int H, int D
     if (cells == 0 || C == 0) return 0;
     PDM_REQUIRE(grid && wsum, PDM_E_BADARG, "pdm_bev_normalize: null pointer");
     const long long total = cells * C;
+    if (layout == 1 && ((long long)C * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(grid) & 15) == 0) {
+        const long long nvec = total / 4;
+        const int vb = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
+        hipLaunchKernelGGL(pdm_normalize_cl4_kernel, dim3(vb), dim3(256), 0, as_stream(stream), nvec, C * D / 4, D, eps,
+                           reinterpret_cast<float4 *>(grid), wsum);
+        return check_launch("pdm_bev_normalize");
+    }
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(pdm_normalize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
                        (long long)B * H * W * D, C, W, H, D, layout, eps, grid, wsum);
