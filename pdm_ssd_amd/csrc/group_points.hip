@@ -476,6 +476,8 @@ __global__ __launch_bounds__(256) void group_concat_cl_kernel(long long total, i
 extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
                                       const float *feat_pm, const int *idx, void *out, int out_bf16, int ld);
 namespace pdm {
+// (Measured and dropped: a lane group per row with three aligned 16-byte loads per lane and hardware bf16 packing — 113 us per
+//  call against ~90: 33- and 65-chunk rows leave half a lane group idle and each lane fetches 48 bytes for 16 written.)
 // bf16 rows with ld % 8 == 0 (the padded form): a thread writes EIGHT consecutive channels of one row with one 16-byte store —
 // one index / centre lookup and one 64-bit division per 16 bytes instead of per 2 (the element form spent its time there).
 __global__ __launch_bounds__(256) void group_concat_cl8_kernel(long long total8, int n, int m, int c, int ns, int ld,
