@@ -432,34 +432,49 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int
                                                                const int *__restrict__ start_all, const unsigned short *__restrict__ ej_all,
                                                                const float *__restrict__ ew_all, float *__restrict__ dknown) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= m) return;
     const int *__restrict__ start = start_all + (size_t)b * (m + 1);
     const unsigned short *__restrict__ ej = ej_all + (size_t)b * ne;
     const float *__restrict__ ew = ew_all + (size_t)b * ne;
-    const int s = start[j], e = start[j + 1];
     if ((c2 & 7) == 0 && (ld & 7) == 0) {        // eight channels per lane: 16-byte reads of the gradient rows
-        for (int c0 = 0; c0 < c2; c0 += 512) {
-            const int ch = c0 + lane * 8;
-            if (ch < c2) {
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int p = s; p < e; ++p) {
-                    const float w = ew[p];
-                    const uint4 q = *reinterpret_cast<const uint4 *>(dx + ((size_t)b * n + ej[p]) * ld + ch);
-                    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+        // lpp lanes per known point (C2 / 8 rounded up to a power of two, <= 64): at C2 = 256 a wave serves two points instead of
+        // leaving half its lanes idle; four list entries are in flight per step (one dependent index + weight + row load at a
+        // time was a latency chain).  Same summation order per channel.
+        int lpp = 1;
+        while (lpp < (c2 >> 3) && lpp < 64) lpp <<= 1;
+        const int ppw = 64 / lpp;
+        const int j = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw + lane / lpp;
+        if (j >= m) return;
+        const int s = start[j], e = start[j + 1];
+        const unsigned short *__restrict__ dxb = dx + (size_t)b * n * ld;
+        auto fma8 = [](float (&acc)[8], float w, uint4 q) {
+            const unsigned u[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        acc[2 * t] = __fmaf_rn(w, __uint_as_float(u[t] << 16), acc[2 * t]);
-                        acc[2 * t + 1] = __fmaf_rn(w, __uint_as_float(u[t] & 0xffff0000u), acc[2 * t + 1]);
-                    }
-                }
-                float *o = dknown + ((size_t)b * m + j) * c2 + ch;
-                *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            for (int t = 0; t < 4; ++t) {
+                acc[2 * t] = __fmaf_rn(w, __uint_as_float(u[t] << 16), acc[2 * t]);
+                acc[2 * t + 1] = __fmaf_rn(w, __uint_as_float(u[t] & 0xffff0000u), acc[2 * t + 1]);
             }
+        };
+        for (int ch = (lane % lpp) * 8; ch < c2; ch += lpp * 8) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int p = s;
+            for (; p + 4 <= e; p += 4) {
+                const float w0 = ew[p], w1 = ew[p + 1], w2 = ew[p + 2], w3 = ew[p + 3];
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(dxb + (size_t)ej[p] * ld + ch),
+                            q1 = *reinterpret_cast<const uint4 *>(dxb + (size_t)ej[p + 1] * ld + ch),
+                            q2 = *reinterpret_cast<const uint4 *>(dxb + (size_t)ej[p + 2] * ld + ch),
+                            q3 = *reinterpret_cast<const uint4 *>(dxb + (size_t)ej[p + 3] * ld + ch);
+                fma8(acc, w0, q0); fma8(acc, w1, q1); fma8(acc, w2, q2); fma8(acc, w3, q3);
+            }
+            for (; p < e; ++p) fma8(acc, ew[p], *reinterpret_cast<const uint4 *>(dxb + (size_t)ej[p] * ld + ch));
+            float *o = dknown + ((size_t)b * m + j) * c2 + ch;
+            *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
         return;
     }
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= m) return;
+    const int s = start[j], e = start[j + 1];
     for (int c0 = 0; c0 < c2; c0 += 64) {
         const int ch = c0 + lane;
         if (ch < c2) {
@@ -525,7 +540,12 @@ extern "C" int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, in
                        start, ej, ew);
     int rc = check_launch("interp_concat_rows_grad(csr)");
     if (rc) return rc;
-    hipLaunchKernelGGL(interp_rows_grad_kernel, dim3((unsigned)((m + 3) / 4), (unsigned)b), dim3(256), 0, as_stream(stream), n, m, c2, ld, ne,
+    int lpp = 1;     // as in the kernel's eight-channel form: points per workgroup = 4 * 64 / lpp
+    if ((c2 & 7) == 0 && (ld & 7) == 0)
+        while (lpp < (c2 >> 3) && lpp < 64) lpp <<= 1;
+    else lpp = 64;
+    const int ppb = 4 * (64 / lpp);
+    hipLaunchKernelGGL(interp_rows_grad_kernel, dim3((unsigned)((m + ppb - 1) / ppb), (unsigned)b), dim3(256), 0, as_stream(stream), n, m, c2, ld, ne,
                        static_cast<const unsigned short *>(dx), start, ej, ew, dknown);
     return check_launch("interp_concat_rows_grad");
 }
