@@ -81,6 +81,14 @@ class PDMNeck(nn.Module):
             batch_dict['spatial_features_stride'] = self.stride
             batch_dict['pdm_weight_sum'] = wsum
             return batch_dict
+        if (self.normalize and self.layout == 1 and feat.is_cuda and pdm_ops.gather_supported(self.feature_dim, self.grid.D)
+                and getattr(self, 'use_gather', True) and (feat.requires_grad or sh.requires_grad)):
+            # training: the gather kernel forward (grid written once, normalised), the usual two kernels backward
+            grid, wsum = pdm_ops.pdm_gather_normalized(xyz.contiguous(), feat, sh, inv2s2, self.grid, self.dilation, self.degree)
+            batch_dict['spatial_features'] = grid.permute(0, 3, 1, 2)
+            batch_dict['spatial_features_stride'] = self.stride
+            batch_dict['pdm_weight_sum'] = wsum
+            return batch_dict
         grid, wsum = pdm_ops.pdm_scatter(xyz.contiguous(), feat, sh, inv2s2, self.grid, self.dilation,
                                          self.degree, self.layout)
         if self.normalize:

@@ -152,6 +152,47 @@ def pdm_gather(xyz, feat, sh, inv2s2, grid_spec, kernel, degree, normalize=True,
     return grid, wsum
 
 
+class PDMGatherNormalized(Function):
+    """Training form of the neck's grid with the GATHER kernel in the forward pass: (xyz, feat, sh, inv2s2) -> (grid / wsum, wsum),
+    channels-last.  Same sum as PDMScatter + BevNormalize (ascending point order per cell instead of the atomics' arrival order),
+    but the grid is written once — no 0.6 GB zero fill, no float atomics, no separate normalisation pass (1.0 -> 0.2 ms at
+    bs = 32).  Backward: pdm_bev_normalize_grad, then the gather-form gradient kernel pdm_scatter_bev_grad, as before."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, xyz, feat, sh, inv2s2, grid_spec: BevGrid, kernel: Tuple[int, int, int], degree: int, eps: float):
+        grid, wsum = pdm_gather(xyz, feat, sh, inv2s2, grid_spec, kernel, degree, normalize=True, eps=eps)
+        ctx.save_for_backward(xyz.contiguous(), feat.contiguous(), sh.contiguous(), inv2s2.contiguous(), grid, wsum)
+        ctx.spec = (grid_spec, tuple(kernel), degree, float(eps))
+        ctx.mark_non_differentiable(wsum)
+        return grid, wsum
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy, _dwsum=None):
+        xyz, feat, sh, inv2s2, y, wsum = ctx.saved_tensors
+        g, kernel, degree, eps = ctx.spec
+        B, P, _ = xyz.shape
+        C = feat.shape[2]
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(y)
+        dw = torch.empty_like(wsum)
+        s = _stream(y)
+        _native.call("pdm_bev_normalize_grad", s, B, C, g.W, g.H, g.D, eps, y.data_ptr(), wsum.data_ptr(), dy.data_ptr(),
+                     dx.data_ptr(), dw.data_ptr())
+        dfeat = torch.empty_like(feat)
+        dsh = torch.empty_like(sh)
+        dinv = torch.empty_like(inv2s2)
+        _native.call("pdm_scatter_bev_grad", s, B, P, C, degree, xyz.data_ptr(), feat.data_ptr(), sh.data_ptr(), inv2s2.data_ptr(),
+                     *g.floats(), g.W, g.H, g.D, *kernel, 1, dx.data_ptr(), dw.data_ptr(), dfeat.data_ptr(), dsh.data_ptr(),
+                     dinv.data_ptr())
+        return None, dfeat, dsh, dinv, None, None, None, None
+
+
+def pdm_gather_normalized(xyz, feat, sh, inv2s2, grid_spec, kernel, degree, eps=1e-6):
+    return PDMGatherNormalized.apply(xyz, feat, sh, inv2s2, grid_spec, tuple(kernel), degree, eps)
+
+
 def gather_supported(C, D):
     """D == 1, C <= 256: register accumulators.  Otherwise the LDS accumulator tile (64*D cells x C channels)
     must fit 64 KB."""

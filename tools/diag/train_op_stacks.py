@@ -1,4 +1,5 @@
 import sys, os, json
+sys.argv_filter = [a for a in sys.argv[1:]] or None
 sys.argv = ["bench.py", "--train", "--warmup", "4", "--no-cpu-baseline", "--train-profile", "/dev/null"]
 sys.path.insert(0, os.getcwd())
 import torch
@@ -24,5 +25,8 @@ for e in p.events():
         pass
 ka = p.key_averages(group_by_stack_n=6)
 for e in sorted(ka, key=lambda e: -e.device_time_total)[:400]:
-    if e.key.startswith("aten::gather") or e.key.startswith("aten::scatter") or "index" in e.key or e.key.startswith("aten::take"):
+    want = sys.argv_filter if hasattr(sys, "argv_filter") else None
+    hit = (e.key.startswith("aten::gather") or e.key.startswith("aten::scatter") or "index" in e.key or e.key.startswith("aten::take")) if not want \
+        else any(e.key.startswith(w) for w in want)
+    if hit and e.device_time_total > 0:
         print(e.key, round(e.device_time_total / 3e3, 3), "ms/step", e.count, [s for s in e.stack[:6]])
