@@ -61,10 +61,19 @@ __device__ __forceinline__ void ldv(const float *p, float (&v)[V]) {   // V cons
     }
 }
 
+template <class TD, int V>
+__device__ __forceinline__ void ld4bf_any(const TD *p, float (&v)[V]) {   // four bf16 -> fp32 (the mixed form; V == 4 there)
+    if constexpr (V == 4 && sizeof(TD) == 2) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(p);
+        v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+        v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+    }
+}
+
 // ---- CL: rows x C.  A workgroup walks rows blockIdx.x * RPP + k * gridDim.x * RPP; thread = (row in pass, V channels) --
 // MODE 0: sums of x and x^2.  MODE 1: sums of g and g * xhat with g = dy * [x scale + shift > 0] (or dy when !relu).
-template <class T, int MODE>
-__global__ __launch_bounds__(256) void bn_cl_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dy, long long rows, int C,
+template <class T, int MODE, class TD = T>
+__global__ __launch_bounds__(256) void bn_cl_reduce_kernel(const T *__restrict__ x, const TD *__restrict__ dy, long long rows, int C,
                                                            BnCoef k, int relu, float *__restrict__ partial) {
     constexpr int V = BnVec<T>::V;
     __shared__ float s_a[256 * V], s_b[256 * V];
@@ -93,7 +102,8 @@ __global__ __launch_bounds__(256) void bn_cl_reduce_kernel(const T *__restrict__
                 for (int i = 0; i < V; ++i) { const float d = xv[i] - mean[i]; a[i] += d; b[i] = fmaf(d, d, b[i]); }
             } else {
                 float gv[V];
-                BnVec<T>::load(dy + r * C + col, gv);
+                if constexpr (sizeof(TD) == sizeof(T)) BnVec<T>::load(reinterpret_cast<const T *>(dy) + r * C + col, gv);
+                else ld4bf_any(dy + r * C + col, gv);                      // mixed: fp32 x (V = 4), bf16 dy
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     const float d = xv[i] - mean[i];
@@ -146,6 +156,50 @@ __global__ __launch_bounds__(256) void bn_cl_apply_kernel(const T *__restrict__ 
             }
         }
         BnVec<T>::store(out + e * V, ov);
+    }
+}
+
+// ---- MIXED (dtype 2, rows x C): x (the BatchNorm's input, e.g. the fp32 depthwise map) fp32, the activation side — y forward, dy
+// backward — bf16, dx fp32; four channels per thread.  The arithmetic of the fp32 kernels with the conversion a bf16 consumer
+// (a contraction under autocast) would do anyway folded into the store / the load: y = bf16(relu(bn(x))) is what
+// `bn(x).relu().to(bf16)` gives, and a bf16 dy read as fp32 is exact — so results are bit for bit those of the fp32 operator
+// followed / preceded by the casts, without a 577 MB cast pass each way on the heat-map head's map.
+__device__ __forceinline__ void ld4bf(const bf16_t *p, float (&v)[4]) {
+    const uint2 q = *reinterpret_cast<const uint2 *>(p);
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_cl_apply_mixed_kernel(const float *__restrict__ x, const bf16_t *__restrict__ dy,
+                                                                void *__restrict__ out, long long nvec, int C, BnCoef k, int relu) {
+    const int tpr = C / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long long)gridDim.x * 256) {
+        const int col = (int)(e % tpr) * 4;
+        float xv[4], ov[4], sc[4], sh[4], mu[4];
+        BnVec<float>::load(x + e * 4, xv);
+        ldv<4>(k.scale + col, sc); ldv<4>(k.shift + col, sh); ldv<4>(k.mean + col, mu);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y = fmaf(xv[i] - mu[i], sc[i], sh[i]);
+                ov[i] = relu ? fmaxf(y, 0.f) : y;
+            }
+            uint2 w;
+            w.x = (unsigned)f2bf(ov[0]) | ((unsigned)f2bf(ov[1]) << 16);
+            w.y = (unsigned)f2bf(ov[2]) | ((unsigned)f2bf(ov[3]) << 16);
+            *reinterpret_cast<uint2 *>(static_cast<bf16_t *>(out) + e * 4) = w;
+        } else {
+            float gv[4], pp[4], qq[4];
+            ld4bf(dy + e * 4, gv);
+            ldv<4>(k.p + col, pp); ldv<4>(k.q + col, qq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = xv[i] - mu[i];
+                const float g = (!relu || fmaf(d, sc[i], sh[i]) > 0.f) ? gv[i] : 0.f;
+                ov[i] = sc[i] * (g - pp[i] - d * qq[i]);
+            }
+            BnVec<float>::store(static_cast<float *>(out) + e * 4, ov);
+        }
     }
 }
 
@@ -426,9 +480,10 @@ __global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const float *__rest
 }
 
 static int bn_check(const char *who, int dtype, int layout, long long n, int C, long long L, const void *p0, const void *p1) {
-    PDM_REQUIRE(dtype == 0 || dtype == 1, PDM_E_BADARG, "%s: dtype %d (0 = fp32, 1 = bf16)", who, dtype);
+    PDM_REQUIRE(dtype == 0 || dtype == 1 || (dtype == 2 && layout == 0), PDM_E_BADARG,
+                "%s: dtype %d (0 = fp32, 1 = bf16, 2 = fp32 x with bf16 y / dy, rows x C only)", who, dtype);
     PDM_REQUIRE(layout == 0 || layout == 1, PDM_E_BADARG, "%s: layout %d (0 = rows x C, 1 = n x C x L)", who, layout);
-    const int V = dtype ? 8 : 4;
+    const int V = dtype == 1 ? 8 : 4;
     PDM_REQUIRE(n >= 0 && C >= 1 && L >= 1, PDM_E_BADARG, "%s: n=%lld C=%d L=%lld", who, n, C, L);
     if (layout == 0) PDM_REQUIRE(C % V == 0 && C / V <= 256, PDM_E_BADARG, "%s: rows x C needs C a multiple of %d, at most %d", who, V, 256 * V);
     else PDM_REQUIRE(L % V == 0 && C <= 65535, PDM_E_BADARG, "%s: n x C x L needs L a multiple of %d", who, V);
@@ -468,12 +523,12 @@ extern "C" int pdm_bn_relu_forward(void *stream, int dtype, int layout, long lon
     const int parts = pdm_bn_parts(layout, n, C, L);
     BnCoef none{};
     none.pivot = coef + 3 * (size_t)C;   // parked in the shift row until the finalize kernel replaces it
-    const int V = dtype ? 8 : 4;
+    const int V = dtype == 1 ? 8 : 4;
     const long long nvec = n * C * L / V;
     const long long ag = (nvec + 255) / 256;
     const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
     if (layout == 0) {
-        if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, n, C, none, relu, partial);
+        if (dtype == 1) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, n, C, none, relu, partial);
         else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, n, C, none, relu, partial);
     } else {
         if (dtype) hipLaunchKernelGGL((bn_cf_reduce_kernel<bf16_t, 0>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, n, C, L, none, relu, partial);
@@ -483,7 +538,8 @@ extern "C" int pdm_bn_relu_forward(void *stream, int dtype, int layout, long lon
                        beta, eps, momentum, running_mean, running_var, coef);
     const BnCoef k = coef_of(coef, nullptr, C);
     if (layout == 0) {
-        if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, k, relu);
+        if (dtype == 2) hipLaunchKernelGGL((bn_cl_apply_mixed_kernel<0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const bf16_t *)nullptr, y, nvec, C, k, relu);
+        else if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, k, relu);
         else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, (float *)y, nvec, C, k, relu);
     } else {
         if (dtype) hipLaunchKernelGGL((bn_cf_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, L, k, relu);
@@ -533,14 +589,15 @@ static int bn_relu_backward_phases(const char *who, int phase, void *stream, int
     PDM_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, PDM_E_BADARG, "%s: dx must be 16-byte aligned", who);
     if (n == 0) return 0;
     const int parts = pdm_bn_parts(layout, n, C, L);
-    const int V = dtype ? 8 : 4;
+    const int V = dtype == 1 ? 8 : 4;
     const long long nvec = n * C * L / V;
     const long long ag = (nvec + 255) / 256;
     const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
     BnCoef k = coef_of(coef, nullptr, C);
     if (phase & 1) {
         if (layout == 0) {
-            if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, k, relu, partial);
+            if (dtype == 2) hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 1, bf16_t>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const bf16_t *)dy, n, C, k, relu, partial);
+            else if (dtype) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, k, relu, partial);
             else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 1>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, n, C, k, relu, partial);
         } else {
             if (dtype) hipLaunchKernelGGL((bn_cf_reduce_kernel<bf16_t, 1>), dim3(C, parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, n, C, L, k, relu, partial);
@@ -551,7 +608,8 @@ static int bn_relu_backward_phases(const char *who, int phase, void *stream, int
     if (phase & 2) {
         k = coef_of(coef, grads, C);
         if (layout == 0) {
-            if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, k, relu);
+            if (dtype == 2) hipLaunchKernelGGL((bn_cl_apply_mixed_kernel<1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const bf16_t *)dy, dx, nvec, C, k, relu);
+            else if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, k, relu);
             else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 1>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)dy, (float *)dx, nvec, C, k, relu);
         } else {
             if (dtype) hipLaunchKernelGGL((bn_cf_apply_kernel<bf16_t, 1>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)dy, (bf16_t *)dx, nvec, C, L, k, relu);

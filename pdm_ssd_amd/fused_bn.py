@@ -44,10 +44,14 @@ def _layout(x):
 class _BnRelu(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L, stats=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L, stats=None, out_bf16=False):
         C = x.shape[1]
         dtype = 1 if x.dtype == torch.bfloat16 else 0
-        y = torch.empty_like(x)
+        if out_bf16 and dtype == 0 and layout == 0:
+            # fp32 input, bf16 output (and bf16 gradient in, fp32 gradient out): what `bn(x).relu().to(bf16)` and its backward
+            # compute, bit for bit, without the two cast passes — for an fp32 map that a contraction under autocast reads next
+            dtype = 2
+        y = torch.empty_like(x, dtype=torch.bfloat16) if dtype == 2 else torch.empty_like(x)
         coef = torch.empty((4, C), dtype=torch.float32, device=x.device)
         parts = _native.lib().pdm_bn_parts(layout, n, C, L)
         if stats is not None and layout == 0:
@@ -72,14 +76,15 @@ class _BnRelu(Function):
     def backward(ctx, dy):
         x, coef = ctx.saved_tensors
         dtype, layout, n, C, L, relu, parts = ctx.meta
-        if dy.dtype != x.dtype or dy.stride() != x.stride():
-            dy = torch.empty_like(x).copy_(dy)       # same type and memory format as x
+        want = torch.bfloat16 if dtype == 2 else x.dtype
+        if dy.dtype != want or dy.stride() != x.stride():
+            dy = torch.empty_like(x, dtype=want).copy_(dy)       # the operator's gradient type, x's memory format
         dx = torch.empty_like(x)
         grads = torch.empty((4, C), dtype=torch.float32, device=x.device)
         partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
         _native.call("pdm_bn_relu_backward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
                      dy.data_ptr(), dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), relu)
-        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None, None
+        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None, None, None
 
 
 class _BnReluPool(Function):
@@ -147,7 +152,7 @@ def _padded_applies(x, bn):
             and x.dim() >= 2 and C % 8 != 0 and x.shape[1] == _round8(C) and _layout(x) is not None)
 
 
-def batch_norm_relu(x, bn, relu=True, stats=None):
+def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False):
     """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch.
     stats: the column sums the producing GEMM took of x ([tiles][C][2], rows_linear(..., want_stats=True)) or None."""
     if _padded_applies(x, bn):
@@ -168,7 +173,7 @@ def batch_norm_relu(x, bn, relu=True, stats=None):
     with torch.no_grad():
         bn.num_batches_tracked += 1
     return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L,
-                         stats if layout == 0 else None)
+                         stats if layout == 0 else None, bool(out_bf16))
 
 
 def _round8(v):
@@ -611,7 +616,11 @@ class TrainSequential(nn.Sequential):
                         x, stats, link = y, st, out_link
                         i += 3
                         continue
-                x = batch_norm_relu(x, m, relu, stats)
+                # an fp32 map (the heat-map head's depthwise output) that a bf16 contraction reads next: the BatchNorm writes bf16
+                to_bf16 = (x.dtype == torch.float32 and ROWS_GEMM and nxt is not None and _bf16_autocast()
+                           and (isinstance(nxt, nn.Linear) or (type(nxt) in (nn.Conv1d, nn.Conv2d) and all(k == 1 for k in nxt.kernel_size)
+                                                               and nxt.groups == 1)))
+                x = batch_norm_relu(x, m, relu, stats, out_bf16=to_bf16)
                 stats = link = None
                 i += 2 if relu else 1
                 continue

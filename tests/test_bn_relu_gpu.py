@@ -182,6 +182,7 @@ def test_bn_relu_max_pool_as_one_operator(dev, shape, dtype):
     assert float(y[:, 1].abs().max()) == 0.0 and float(xg.grad[:, 1].abs().max()) < 1e-3
 
 
+@pytest.mark.gpu
 def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
     """Conv -> BN -> ReLU -> Conv under bf16 autocast: with the BatchNorm + ReLU applied in the second contraction's load path
     (fused_bn._BnReluRowsGemm: the normalised tensor is never written) outputs, input gradient and every parameter
@@ -222,6 +223,7 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
 
 @pytest.mark.parametrize("widths,x_grad", [((16, 32, 20, 8), True), ((16, 32, 20, 8), False), ((24, 160, 136, 96), True),
                                            ((72, 256, 256, 16), True)])
+@pytest.mark.gpu
 def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths, x_grad):
     """Conv -> BN -> ReLU -> Conv -> BN -> ReLU -> Conv under bf16 autocast: with the BatchNorm + ReLU backward's elementwise half
     formed inside the data gradient of the layer before (pdm_tg_gemm_nt_dy, fused_bn.LAZY_BN_BACKWARD: the operator's pass
@@ -258,3 +260,32 @@ def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths,
     assert torch.equal(ya, yb) and (not x_grad or torch.equal(ga, gb))
     for k in pa:
         assert torch.isfinite(pa[k]).all() and torch.equal(pa[k], pb[k]), k
+
+
+@pytest.mark.gpu
+def test_bn_relu_fp32_in_bf16_out_equals_the_fp32_operator_with_casts(dev):
+    """The mixed form (fp32 input and input gradient, bf16 output and output gradient: pdm_bn_relu_forward / _backward with
+    dtype 2) against the fp32 operator followed by `.to(bf16)` and fed a bf16 gradient cast to fp32: outputs, input gradient,
+    dgamma, dbeta and running statistics BIT-identical."""
+    from pdm_ssd_amd import fused_bn
+    torch.manual_seed(3)
+    B, C, H, W = 2, 64, 24, 20
+    x0 = (torch.randn(B, C, H, W, device=dev) * 1.7 + 0.3).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, C, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    for mixed in (True, False):
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        torch.manual_seed(4)                      # the same parameters for both forms
+        with torch.no_grad():
+            bn.weight.uniform_(-1.0, 1.5); bn.bias.normal_(0, 0.3)
+        x = x0.clone().requires_grad_(True)
+        y = fused_bn.batch_norm_relu(x, bn, True, None, out_bf16=mixed)
+        if not mixed:
+            assert y.dtype == torch.float32
+            y = y.to(torch.bfloat16)
+        assert y.dtype == torch.bfloat16
+        y.backward(gy)
+        res.append((y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                    bn.running_var.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -49,6 +49,7 @@ def scene_boxes(B, M, seed):
     return gt
 
 
+@pytest.mark.gpu
 def test_point_head_targets_on_gpu_match_reference_fixture(dev):
     """points_in_boxes HIP kernel + batched target assignment == the reference's labels (oracle-backed fixture)."""
     ref = np.load(os.path.join(G, "ref_head.npz"))
@@ -64,6 +65,7 @@ def test_point_head_targets_on_gpu_match_reference_fixture(dev):
     assert abs(float(loss) - float(ref['loss'])) <= 1e-4 * abs(float(ref['loss']))
 
 
+@pytest.mark.gpu
 def test_point_head_fused_inference_equals_torch_layers(dev):
     torch.manual_seed(0)
     head = build_pdm_ssd().point_head.to(dev).eval()
@@ -84,6 +86,7 @@ def test_point_head_fused_inference_equals_torch_layers(dev):
     assert tuple(a['batch_box_preds'].shape) == (n, 7) and tuple(a['batch_cls_preds'].shape) == (n, 3)
 
 
+@pytest.mark.gpu
 def test_detector_training_contract_and_backward(dev):
     torch.manual_seed(1)
     model = build_pdm_ssd(SMALL).to(dev).train()
@@ -102,6 +105,7 @@ def test_detector_training_contract_and_backward(dev):
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
 
 
+@pytest.mark.gpu
 def test_training_step_issues_without_host_synchronisation(dev):
     """Forward + losses of a training step contain no blocking call (torch's sync debug mode raises at a size read back
     for a boolean-mask index, an .item(), a pageable host->device copy ...): the host can issue the backward ahead of
@@ -127,6 +131,7 @@ def test_training_step_issues_without_host_synchronisation(dev):
     assert torch.isfinite(ret['loss'])
 
 
+@pytest.mark.gpu
 def test_detector_eval_returns_nms_filtered_predictions(dev):
     torch.manual_seed(2)
     model = build_pdm_ssd(SMALL).to(dev).eval()
@@ -148,6 +153,7 @@ def test_detector_eval_returns_nms_filtered_predictions(dev):
         assert float(iou.max()) <= 0.1 + 1e-4                # survivors do not overlap beyond NMS_THRESH
 
 
+@pytest.mark.gpu
 def test_heatmap_head_fused_inference_equals_torch_layers(dev):
     """pdm_bev_depthwise3x3 + the per-cell MFMA row kernels against the torch convolutions of the same module, on a
     channels-last grid like the neck's (with empty cells and a border)."""
@@ -173,6 +179,7 @@ def test_heatmap_head_fused_inference_equals_torch_layers(dev):
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.gpu
 def test_depthwise3x3_hip_forward_backward_match_torch_conv(dev):
     """pdm_bev_depthwise3x3 (+ its mirrored-tap data gradient and pdm_bev_depthwise3x3_wgrad) against
     torch.nn.functional.conv2d(groups=C) in fp32: forward 1e-5, gradients 1e-4 (float atomics in the weight sum)."""
