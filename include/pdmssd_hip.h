@@ -440,6 +440,9 @@ int pdm_interp_concat_rows(void *stream, int b, int n, int m, int c2, int c1, in
                            const void *skip, int skip_bf16, const int *idx, const float *weight, void *out);
 int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
                                 const float *weight, float *dknown, void *workspace, size_t workspace_bytes);
+/* the same, the gradient of the known rows written as fp32 (out_bf16 = 0) or bf16 (1: the rounding a cast of the fp32 result would do) */
+int pdm_interp_concat_rows_grad_out(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
+                                    const float *weight, void *dknown, int out_bf16, void *workspace, size_t workspace_bytes);
 
 /* ---- bf16 contractions of the training path (csrc/train_gemm.hip) ---------------------------------------------------
  * The shared MLPs' 1x1 convolutions / Linear layers in TRAINING (reference: torch Conv2d / Linear inside

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "pdm_sa_mlp_packed": [_i] * 5 + [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_interp_concat_rows": [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "pdm_interp_concat_rows_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_interp_concat_rows_grad_out": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, ctypes.c_size_t],
     "pdm_tg_gemm_nt": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_tg_gemm_nt_dy": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong,
                           _vp, ctypes.c_longlong, _vp, _vp],

@@ -428,9 +428,11 @@ __global__ __launch_bounds__(256) void interp_concat_rows8_kernel(long long tota
 
 // d known[b, j, c] = sum over the CSR list of j of w * dx[b, i, c], c < C2: one wave per known point, lanes over channels,
 // every gradient row read contiguously, no atomics (fixed order: reproducible)
+template <bool OB>   // OB: dknown is written as bf16 (round to nearest even of the same fp32 sums) instead of fp32
 __global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int c2, int ld, int ne, const unsigned short *__restrict__ dx,
                                                                const int *__restrict__ start_all, const unsigned short *__restrict__ ej_all,
-                                                               const float *__restrict__ ew_all, float *__restrict__ dknown) {
+                                                               const float *__restrict__ ew_all, void *__restrict__ dknown_v) {
+    float *__restrict__ dknown = static_cast<float *>(dknown_v);
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int *__restrict__ start = start_all + (size_t)b * (m + 1);
     const unsigned short *__restrict__ ej = ej_all + (size_t)b * ne;
@@ -466,9 +468,16 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int
                 fma8(acc, w0, q0); fma8(acc, w1, q1); fma8(acc, w2, q2); fma8(acc, w3, q3);
             }
             for (; p < e; ++p) fma8(acc, ew[p], *reinterpret_cast<const uint4 *>(dxb + (size_t)ej[p] * ld + ch));
-            float *o = dknown + ((size_t)b * m + j) * c2 + ch;
-            *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            if constexpr (OB) {
+                uint4 o;
+                o.x = (unsigned)icr_bf16(acc[0]) | ((unsigned)icr_bf16(acc[1]) << 16); o.y = (unsigned)icr_bf16(acc[2]) | ((unsigned)icr_bf16(acc[3]) << 16);
+                o.z = (unsigned)icr_bf16(acc[4]) | ((unsigned)icr_bf16(acc[5]) << 16); o.w = (unsigned)icr_bf16(acc[6]) | ((unsigned)icr_bf16(acc[7]) << 16);
+                *reinterpret_cast<uint4 *>(static_cast<unsigned short *>(dknown_v) + ((size_t)b * m + j) * c2 + ch) = o;
+            } else {
+                float *o = dknown + ((size_t)b * m + j) * c2 + ch;
+                *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
         }
         return;
     }
@@ -481,7 +490,8 @@ __global__ __launch_bounds__(256) void interp_rows_grad_kernel(int n, int m, int
             float acc = 0.0f;
             for (int p = s; p < e; ++p)
                 acc = __fmaf_rn(ew[p], __uint_as_float((unsigned)dx[((size_t)b * n + ej[p]) * ld + ch] << 16), acc);
-            dknown[((size_t)b * m + j) * c2 + ch] = acc;
+            if constexpr (OB) static_cast<unsigned short *>(dknown_v)[((size_t)b * m + j) * c2 + ch] = icr_bf16(acc);
+            else dknown[((size_t)b * m + j) * c2 + ch] = acc;
         }
     }
 }
@@ -517,8 +527,15 @@ extern "C" int pdm_interp_concat_rows(void *stream, int b, int n, int m, int c2,
 
 // Its backward towards the known features: dx (B, n, ld) bf16 -> dknown (B, m, C2) fp32, fully written.  The skip features'
 // gradient is the column block dx[..., C2 : C2 + C1] itself.  workspace: pdm_three_interpolate_grad_ws_bytes(b, n, m).
+extern "C" int pdm_interp_concat_rows_grad_out(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
+                                               const float *weight, void *dknown, int out_bf16, void *workspace, size_t workspace_bytes);
 extern "C" int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
                                            const float *weight, float *dknown, void *workspace, size_t workspace_bytes) {
+    return pdm_interp_concat_rows_grad_out(stream, b, n, m, c2, ld, dx, idx, weight, dknown, 0, workspace, workspace_bytes);
+}
+// the same with the gradient of the known rows written as bf16 (out_bf16 = 1: the rounding a cast of the fp32 result would do)
+extern "C" int pdm_interp_concat_rows_grad_out(void *stream, int b, int n, int m, int c2, int ld, const void *dx, const int *idx,
+                                               const float *weight, void *dknown, int out_bf16, void *workspace, size_t workspace_bytes) {
     PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c2 >= 0 && ld >= c2, PDM_E_BADARG, "interp_concat_rows_grad: bad size");
     if (b == 0 || m == 0 || c2 == 0) return 0;
     PDM_REQUIRE(dknown && workspace && (n == 0 || (dx && idx && weight)), PDM_E_BADARG, "interp_concat_rows_grad: null pointer");
@@ -545,8 +562,12 @@ extern "C" int pdm_interp_concat_rows_grad(void *stream, int b, int n, int m, in
         while (lpp < (c2 >> 3) && lpp < 64) lpp <<= 1;
     else lpp = 64;
     const int ppb = 4 * (64 / lpp);
-    hipLaunchKernelGGL(interp_rows_grad_kernel, dim3((unsigned)((m + ppb - 1) / ppb), (unsigned)b), dim3(256), 0, as_stream(stream), n, m, c2, ld, ne,
-                       static_cast<const unsigned short *>(dx), start, ej, ew, dknown);
+    if (out_bf16)
+        hipLaunchKernelGGL(interp_rows_grad_kernel<true>, dim3((unsigned)((m + ppb - 1) / ppb), (unsigned)b), dim3(256), 0, as_stream(stream), n, m, c2, ld, ne,
+                           static_cast<const unsigned short *>(dx), start, ej, ew, dknown);
+    else
+        hipLaunchKernelGGL(interp_rows_grad_kernel<false>, dim3((unsigned)((m + ppb - 1) / ppb), (unsigned)b), dim3(256), 0, as_stream(stream), n, m, c2, ld, ne,
+                           static_cast<const unsigned short *>(dx), start, ej, ew, dknown);
     return check_launch("interp_concat_rows_grad");
 }
 

@@ -240,12 +240,13 @@ class InterpConcatRows(Function):
             rows = rows.to(torch.bfloat16).contiguous()
         dknown = dskip = None
         if ctx.needs_input_grad[0]:
-            dknown = torch.empty((B, m, C2), dtype=torch.float32, device=g.device)
+            ob = kdtype == torch.bfloat16        # written in the known rows' type (the kernel rounds as the cast would)
+            dknown = torch.empty((B, m, C2), dtype=torch.bfloat16 if ob else torch.float32, device=g.device)
             nbytes = _native.lib().pdm_three_interpolate_grad_ws_bytes(B, n, m)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
-            _native.call("pdm_interp_concat_rows_grad", torch.cuda.current_stream(g.device).cuda_stream, B, n, m, C2, ld, rows.data_ptr(),
-                         idx.data_ptr(), weight.data_ptr(), dknown.data_ptr(), ws.data_ptr(), nbytes)
-            if kdtype != torch.float32:
+            _native.call("pdm_interp_concat_rows_grad_out", torch.cuda.current_stream(g.device).cuda_stream, B, n, m, C2, ld, rows.data_ptr(),
+                         idx.data_ptr(), weight.data_ptr(), dknown.data_ptr(), 1 if ob else 0, ws.data_ptr(), nbytes)
+            if not ob and kdtype != torch.float32:
                 dknown = dknown.to(kdtype)
         if C1 and ctx.needs_input_grad[1]:
             dskip = rows[:, :, C2:C2 + C1]
