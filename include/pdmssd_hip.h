@@ -71,6 +71,9 @@ int pdm_group_concat_cl_grad(void *stream, int b, int n, int m, int c, int nsamp
  * ZEROS (padding to 16-byte rows for the bf16 contractions of csrc/train_gemm.hip, ld = 3 + C rounded up to 8). */
 int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
                            const float *feat_pm, const int *idx, void *out, int out_bf16, int ld);
+/* the same, source features fp32 (feat_bf16 = 0) or bf16 rows (1: with the bf16 result and ld % 8 == 0; a bf16 feature passes through exactly) */
+int pdm_group_concat_cl_ld_f(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                             const void *feat_pm, int feat_bf16, const int *idx, void *out, int out_bf16, int ld);
 int pdm_group_concat_cl_grad_ld(void *stream, int b, int n, int m, int c, int nsample, const void *grad, int grad_bf16, int ld,
                                 const int *idx, float *grad_feat_pm, void *workspace, size_t workspace_bytes);
 

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "pdm_group_concat_cl": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i],
     "pdm_group_concat_cl_grad": [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_group_concat_cl_ld": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i],
+    "pdm_group_concat_cl_ld_f": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i],
     "pdm_group_concat_cl_grad_ld": [_i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_sa_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused": [_i] * 5 + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _i, _i],

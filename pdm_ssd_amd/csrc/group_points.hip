@@ -480,10 +480,13 @@ namespace pdm {
 //  call against ~90: 33- and 65-chunk rows leave half a lane group idle and each lane fetches 48 bytes for 16 written.)
 // bf16 rows with ld % 8 == 0 (the padded form): a thread writes EIGHT consecutive channels of one row with one 16-byte store —
 // one index / centre lookup and one 64-bit division per 16 bytes instead of per 2 (the element form spent its time there).
+template <bool FB>   // FB: the source features are bf16 rows (passed through exactly) instead of fp32
 __global__ __launch_bounds__(256) void group_concat_cl8_kernel(long long total8, int n, int m, int c, int ns, int ld,
                                                                const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-                                                               const float *__restrict__ feat_pm, const int *__restrict__ idx,
+                                                               const void *__restrict__ feat_v, const int *__restrict__ idx,
                                                                unsigned short *__restrict__ out) {
+    const float *__restrict__ feat_pm = static_cast<const float *>(feat_v);
+    const unsigned short *__restrict__ feat_h = static_cast<const unsigned short *>(feat_v);
     const int w = 3 + c, cpr = ld >> 3;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
         const long long row = e / cpr;               // (b, centre, slot)
@@ -491,13 +494,14 @@ __global__ __launch_bounds__(256) void group_concat_cl8_kernel(long long total8,
         const long long bm = row / ns;
         const int b = (int)(bm / m);
         const int src = idx[row];
-        const float *__restrict__ f = feat_pm ? feat_pm + ((size_t)b * n + src) * c - 3 : nullptr;
+        const float *__restrict__ f = (!FB && feat_pm) ? feat_pm + ((size_t)b * n + src) * c - 3 : nullptr;
+        const unsigned short *__restrict__ fh = (FB && feat_h) ? feat_h + ((size_t)b * n + src) * c - 3 : nullptr;
         float v[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int ch = ch0 + t;
             if (ch < 3) v[t] = xyz[((size_t)b * n + src) * 3 + ch] - new_xyz[bm * 3 + ch];
-            else if (ch < w) v[t] = f[ch];
+            else if (ch < w) v[t] = FB ? __uint_as_float((unsigned)fh[ch] << 16) : f[ch];
             else v[t] = 0.0f;
         }
         uint4 o;
@@ -517,8 +521,19 @@ extern "C" int pdm_group_concat_cl(void *stream, int b, int n, int m, int c, int
 
 // The same with a row stride: out (B, M, ns, ld), ld >= 3 + C; the channels 3 + C .. ld - 1 are written as ZEROS, so the tensor
 // can feed a contraction over ld channels (16-byte rows for the bf16 MFMA kernels of train_gemm.hip: ld = round8(3 + C)).
+extern "C" int pdm_group_concat_cl_ld_f(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                                        const void *feat_pm, int feat_bf16, const int *idx, void *out, int out_bf16, int ld);
 extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
                                       const float *feat_pm, const int *idx, void *out, int out_bf16, int ld) {
+    return pdm_group_concat_cl_ld_f(stream, b, n, m, c, nsample, xyz, new_xyz, feat_pm, 0, idx, out, out_bf16, ld);
+}
+// the same with the source features as fp32 (feat_bf16 = 0) or bf16 rows (1: only with bf16 output and ld % 8 == 0 — a bf16 feature
+// passes into the bf16 result exactly, so this is the fp32 form without the cast of the features in front of it)
+extern "C" int pdm_group_concat_cl_ld_f(void *stream, int b, int n, int m, int c, int nsample, const float *xyz, const float *new_xyz,
+                                        const void *feat_v, int feat_bf16, const int *idx, void *out, int out_bf16, int ld) {
+    const float *feat_pm = static_cast<const float *>(feat_v);
+    PDM_REQUIRE(!feat_bf16 || (out_bf16 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0), PDM_E_BADARG,
+                "group_concat_cl: bf16 features need the bf16 result with ld a multiple of 8");
     PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 0 && nsample >= 0 && ld >= 3 + c, PDM_E_BADARG, "group_concat_cl: negative size or ld < 3 + c");
     const long long total = (long long)b * m * nsample * ld;
     if (total == 0) return 0;
@@ -527,8 +542,12 @@ extern "C" int pdm_group_concat_cl_ld(void *stream, int b, int n, int m, int c, 
     const int blocks = (int)(want < 256 * 64 ? want : 256 * 64);
     if (out_bf16 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         const long long total8 = total / 8, want8 = (total8 + 255) / 256;
-        hipLaunchKernelGGL(pdm::group_concat_cl8_kernel, dim3((unsigned)(want8 < 256 * 64 ? want8 : 256 * 64)), dim3(256), 0,
-                           pdm::as_stream(stream), total8, n, m, c, nsample, ld, xyz, new_xyz, feat_pm, idx, static_cast<unsigned short *>(out));
+        if (feat_bf16)
+            hipLaunchKernelGGL(pdm::group_concat_cl8_kernel<true>, dim3((unsigned)(want8 < 256 * 64 ? want8 : 256 * 64)), dim3(256), 0,
+                               pdm::as_stream(stream), total8, n, m, c, nsample, ld, xyz, new_xyz, feat_v, idx, static_cast<unsigned short *>(out));
+        else
+            hipLaunchKernelGGL(pdm::group_concat_cl8_kernel<false>, dim3((unsigned)(want8 < 256 * 64 ? want8 : 256 * 64)), dim3(256), 0,
+                               pdm::as_stream(stream), total8, n, m, c, nsample, ld, xyz, new_xyz, feat_v, idx, static_cast<unsigned short *>(out));
         return pdm::check_launch("group_concat_cl");
     }
     if (out_bf16)

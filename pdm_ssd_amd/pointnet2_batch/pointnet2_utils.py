@@ -358,18 +358,25 @@ class _FusedQueryAndGroupCL(Function):
     extra ones zero — by contract with fused_bn.rows_linear, whose first layer meets them with zero weight columns."""
 
     @staticmethod
-    @torch.amp.custom_fwd(**_FP32_FWD)
+    @torch.amp.custom_fwd(device_type="cuda")      # (no blanket fp32 cast: bf16 source features are read as they are, see below)
     def forward(ctx, radius, nsample, xyz, new_xyz, features, out_bf16, pad_to_8=False):
         from .. import _native
+        xyz, new_xyz = xyz.float(), new_xyz.float()
         B, N, _ = xyz.size()
         M = new_xyz.size(1)
         C = 0 if features is None else features.size(1)
         ld = (3 + C + 7) // 8 * 8 if pad_to_8 else 3 + C
-        idx = ball_query(radius, nsample, xyz, new_xyz)
+        with torch.autocast("cuda", enabled=False):
+            idx = ball_query(radius, nsample, xyz, new_xyz)
+        # bf16 features (the pooled output of the level before, under autocast) go into the bf16 result exactly: no fp32 copy
+        # of them in front of the kernel (six casts of the levels' feature tensors per training step)
+        feat_bf16 = features is not None and features.dtype == torch.bfloat16 and out_bf16 and ld % 8 == 0
+        if features is not None and not feat_bf16:
+            features = features.float()
         feat_pm = None if features is None else features.transpose(1, 2).contiguous()
         out = torch.empty((B, M, nsample, ld), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=xyz.device)
-        _native.call("pdm_group_concat_cl_ld", torch.cuda.current_stream(xyz.device).cuda_stream, B, N, M, C, nsample,
-                     xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat_pm is None else feat_pm.data_ptr(), idx.data_ptr(),
+        _native.call("pdm_group_concat_cl_ld_f", torch.cuda.current_stream(xyz.device).cuda_stream, B, N, M, C, nsample,
+                     xyz.data_ptr(), new_xyz.data_ptr(), 0 if feat_pm is None else feat_pm.data_ptr(), 1 if feat_bf16 else 0, idx.data_ptr(),
                      out.data_ptr(), 1 if out_bf16 else 0, ld)
         ctx.for_backwards = (idx, N, C, ld)
         return out.permute(0, 3, 1, 2)
