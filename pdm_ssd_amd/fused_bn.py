@@ -152,6 +152,18 @@ def _padded_applies(x, bn):
             and x.dim() >= 2 and C % 8 != 0 and x.shape[1] == _round8(C) and _layout(x) is not None)
 
 
+# BatchNorm's num_batches_tracked += 1 is one tiny launch per layer and step; inside TrainSequential._run the layers of a stack
+# are collected here and bumped with ONE multi-tensor add at the end of the stack (same values, ~26 launches fewer per step)
+_bump_later = []
+
+
+def _bump(bn):
+    if _bump_later and _bump_later[-1] is not None:
+        _bump_later[-1].append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
 def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False):
     """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch.
     stats: the column sums the producing GEMM took of x ([tiles][C][2], rows_linear(..., want_stats=True)) or None."""
@@ -164,14 +176,14 @@ def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False):
                           stats if layout == 0 else None)
         with torch.no_grad():
             bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
-            bn.num_batches_tracked += 1
+            _bump(bn)
         return y
     if not applies(x, bn):
         y = bn(x)
         return torch.relu(y) if relu else y
     layout, n, L = _layout(x)
     with torch.no_grad():
-        bn.num_batches_tracked += 1
+        _bump(bn)
     return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L,
                          stats if layout == 0 else None, bool(out_bf16))
 
@@ -384,7 +396,7 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_lin
     with torch.no_grad():
         if K != C:
             bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
-        bn.num_batches_tracked += 1
+        _bump(bn)
     return out
 
 
@@ -585,7 +597,7 @@ class TrainSequential(nn.Sequential):
             bn = mods[-2]
             if pool_applies(h, bn):
                 with torch.no_grad():
-                    bn.num_batches_tracked += 1
+                    _bump(bn)
                 return _BnReluPool.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
             h = self._run(h, mods[-2:])
         else:
@@ -599,6 +611,17 @@ class TrainSequential(nn.Sequential):
 
     @staticmethod
     def _run(x, mods):
+        _bump_later.append([])
+        try:
+            return TrainSequential._run_stack(x, mods)
+        finally:
+            counters = _bump_later.pop()
+            if counters:
+                with torch.no_grad():
+                    torch._foreach_add_(counters, 1)
+
+    @staticmethod
+    def _run_stack(x, mods):
         i = 0
         stats = None      # column sums of x taken by the GEMM that produced it, for the BatchNorm right behind it
         link = None       # shared with the autograd node that produced x (a rows GEMM): see _take_lazy_bn_backward
