@@ -43,11 +43,17 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_kernel(int H, int W, int 
 // L1's request rate).  Same fma order per output as the one-cell kernel (taps row by row, left to right): identical results.
 __global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W, int C4, const float4 *__restrict__ in,
                                                                    const float4 *__restrict__ w, const float4 *__restrict__ shift,
-                                                                   float4 *__restrict__ out, int relu) {
-    const int b = blockIdx.y;
+                                                                   float4 *__restrict__ out, int relu, unsigned wg_per_img) {
+    // one-dimensional grid of (image, group of strips).  Launch ids go round-robin over the 8 XCDs; XCD x takes a CONTIGUOUS
+    // range of work ids, i.e. bands of map rows: the rows above and below a strip then sit in the same L2 (in launch order the
+    // three readers of a map row were on three XCDs, and the map crossed the fabric ~3 times: 3.7 TB/s of map traffic).
+    const unsigned total = gridDim.x, q_ = total >> 3, r_ = total & 7u, xcd = blockIdx.x & 7u, i_ = blockIdx.x >> 3;
+    const unsigned wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + i_;
+    const int b = (int)(wg / wg_per_img);
+    const unsigned sx = wg % wg_per_img;
     const int spr = (W + 3) / 4;                       // strips per map row
     const int cq = threadIdx.x % C4, ls = threadIdx.x / C4;
-    const long long strip = (long long)blockIdx.x * (256 / C4) + ls;
+    const long long strip = (long long)sx * (256 / C4) + ls;
     if (strip >= (long long)H * spr || ls >= 256 / C4) return;
     const int y = (int)(strip / spr), x0 = (int)(strip - (long long)y * spr) * 4;
     const float4 *__restrict__ img = in + (size_t)b * H * W * C4;
@@ -103,9 +109,10 @@ extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, co
     const long long cells = (long long)H * W;
     if (W >= 8) {   // strips of four cells along x
         const long long strips = (long long)H * ((W + 3) / 4);
-        hipLaunchKernelGGL(depthwise3x3_cl_strip_kernel, dim3((unsigned)((strips + cells_per_wg - 1) / cells_per_wg), B), dim3(256), 0,
+        const unsigned wpi = (unsigned)((strips + cells_per_wg - 1) / cells_per_wg);
+        hipLaunchKernelGGL(depthwise3x3_cl_strip_kernel, dim3(wpi * (unsigned)B), dim3(256), 0,
                            as_stream(stream), H, W, C4, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(w),
-                           reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu);
+                           reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu, wpi);
         return check_launch("bev_depthwise3x3");
     }
     hipLaunchKernelGGL(depthwise3x3_cl_kernel, dim3((unsigned)((cells + cells_per_wg - 1) / cells_per_wg), B), dim3(256), 0,
@@ -126,7 +133,10 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_wgrad_kernel(int H, int W
                                                                    float *__restrict__ gw) {
     extern __shared__ float red[];   // (256 / C4) rows x 36 x C4 x 4 floats -> reduced over rows
     const int cq = threadIdx.x % C4, lc = threadIdx.x / C4, rows = 256 / C4;
-    const long long c_begin = (long long)blockIdx.x * cells_per_wg;
+    // (work ranges dealt so that XCD x takes a contiguous stretch of the map: neighbouring ranges share halo rows)
+    const unsigned total_ = gridDim.x, q_ = total_ >> 3, r_ = total_ & 7u, xcd_ = blockIdx.x & 7u, i_ = blockIdx.x >> 3;
+    const unsigned wg_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + i_;
+    const long long c_begin = (long long)wg_ * cells_per_wg;
     const long long c_end = c_begin + cells_per_wg < cells_total ? c_begin + cells_per_wg : cells_total;
     float4 acc[9];
 #pragma unroll
