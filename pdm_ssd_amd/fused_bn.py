@@ -44,7 +44,8 @@ def _layout(x):
 class _BnRelu(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L, stats=None, out_bf16=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu, layout, n, L, stats=None, out_bf16=False, link=None):
+        ctx.link = link      # shared with the rows GEMM node that produced x (TrainSequential._run): see backward
         C = x.shape[1]
         dtype = 1 if x.dtype == torch.bfloat16 else 0
         if out_bf16 and dtype == 0 and layout == 0:
@@ -79,12 +80,23 @@ class _BnRelu(Function):
         want = torch.bfloat16 if dtype == 2 else x.dtype
         if dy.dtype != want or dy.stride() != x.stride():
             dy = torch.empty_like(x, dtype=want).copy_(dy)       # the operator's gradient type, x's memory format
-        dx = torch.empty_like(x)
         grads = torch.empty((4, C), dtype=torch.float32, device=x.device)
         partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
-        _native.call("pdm_bn_relu_backward", torch.cuda.current_stream(x.device).cuda_stream, dtype, layout, n, C, L, x.data_ptr(),
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if ctx.link is not None and LAZY_BN_BACKWARD and dtype == 1 and layout == 0 and relu:
+            # x came straight from a rows GEMM node: only the gradient statistics are taken here; that node's data gradient
+            # forms dx while it reads dy and x (see _take_lazy_bn_backward — the same hand-over _BnReluRowsGemm uses)
+            from . import train_gemm as tg
+            xr, dyr = tg.row_view(x), tg.row_view(dy)
+            if xr is not None and dyr is not None and xr.shape == dyr.shape and xr.stride(0) == C and dyr.stride(0) == C:
+                _native.call("pdm_bn_relu_backward_stats", stream, 1, 0, n, C, 1, x.data_ptr(), dy.data_ptr(), coef.data_ptr(),
+                             grads.data_ptr(), partial.data_ptr(), 1)
+                ctx.link['lazy'] = (xr, coef, grads, dyr.data_ptr())
+                return dy, grads[0], grads[1], None, None, None, None, None, None, None, None, None, None, None
+        dx = torch.empty_like(x)
+        _native.call("pdm_bn_relu_backward", stream, dtype, layout, n, C, L, x.data_ptr(),
                      dy.data_ptr(), dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), relu)
-        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None, None, None
+        return dx, grads[0], grads[1], None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BnReluPool(Function):
@@ -164,7 +176,7 @@ def _bump(bn):
         bn.num_batches_tracked += 1
 
 
-def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False):
+def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False, link=None):
     """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch.
     stats: the column sums the producing GEMM took of x ([tiles][C][2], rows_linear(..., want_stats=True)) or None."""
     if _padded_applies(x, bn):
@@ -173,7 +185,7 @@ def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False):
         rm, rv = torch.cat([bn.running_mean, z]), torch.cat([bn.running_var, z + 1.0])
         layout, n, L = _layout(x)
         y = _BnRelu.apply(x, torch.cat([bn.weight, z]), torch.cat([bn.bias, z]), rm, rv, bn.eps, bn.momentum, relu, layout, n, L,
-                          stats if layout == 0 else None)
+                          stats if layout == 0 else None, False, link if layout == 0 else None)
         with torch.no_grad():
             bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
             _bump(bn)
@@ -185,7 +197,7 @@ def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False):
     with torch.no_grad():
         _bump(bn)
     return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu, layout, n, L,
-                         stats if layout == 0 else None, bool(out_bf16))
+                         stats if layout == 0 else None, bool(out_bf16), link if layout == 0 else None)
 
 
 def _round8(v):
@@ -643,7 +655,8 @@ class TrainSequential(nn.Sequential):
                 to_bf16 = (x.dtype == torch.float32 and ROWS_GEMM and nxt is not None and _bf16_autocast()
                            and (isinstance(nxt, nn.Linear) or (type(nxt) in (nn.Conv1d, nn.Conv2d) and all(k == 1 for k in nxt.kernel_size)
                                                                and nxt.groups == 1)))
-                x = batch_norm_relu(x, m, relu, stats, out_bf16=to_bf16)
+                # (stats is not None: x is the direct output of a rows GEMM node, which shares `link` with this operator)
+                x = batch_norm_relu(x, m, relu, stats, out_bf16=to_bf16, link=link if stats is not None else None)
                 stats = link = None
                 i += 2 if relu else 1
                 continue

@@ -221,22 +221,27 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
         assert torch.equal(ba[k], bb[k]), k
 
 
-@pytest.mark.parametrize("widths,x_grad", [((16, 32, 20, 8), True), ((16, 32, 20, 8), False), ((24, 160, 136, 96), True),
-                                           ((72, 256, 256, 16), True)])
+@pytest.mark.parametrize("widths,x_grad,end_bn", [((16, 32, 20, 8), True, False), ((16, 32, 20, 8), False, False),
+                                                  ((24, 160, 136, 96), True, False), ((72, 256, 256, 16), True, False),
+                                                  ((16, 32, 20, 8), True, True), ((24, 160, 136, 96), True, True),
+                                                  ((64, 128, 64, 256), True, True)])
 @pytest.mark.gpu
-def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths, x_grad):
+def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths, x_grad, end_bn):
     """Conv -> BN -> ReLU -> Conv -> BN -> ReLU -> Conv under bf16 autocast: with the BatchNorm + ReLU backward's elementwise half
     formed inside the data gradient of the layer before (pdm_tg_gemm_nt_dy, fused_bn.LAZY_BN_BACKWARD: the operator's pass
     over (dZ, Y) and one read of dY disappear) the input gradient and every parameter gradient are BIT-identical to the path
     that runs pdm_bn_relu_backward whole.  Narrow (128 x 64 tiles) and wide (128 x 128) outputs, padded widths, and a first
-    layer whose input needs no gradient (the apply half then runs on its own)."""
+    layer whose input needs no gradient (the apply half then runs on its own).  end_bn: the stack ENDS in BatchNorm + ReLU —
+    the stand-alone operator (_BnRelu) then leaves its elementwise half to the last contraction's data gradient the same way."""
     import copy
     from pdm_ssd_amd import fused_bn
     torch.manual_seed(11)
     c0, c1, c2, c3 = widths
+    tail = [torch.nn.Conv2d(c2, c3, 1, bias=False), torch.nn.BatchNorm2d(c3), torch.nn.ReLU()] if end_bn else \
+           [torch.nn.Conv2d(c2, c3, 1, bias=True)]
     net = fused_bn.TrainSequential(torch.nn.Conv2d(c0, c1, 1, bias=False), torch.nn.BatchNorm2d(c1), torch.nn.ReLU(),
                                    torch.nn.Conv2d(c1, c2, 1, bias=False), torch.nn.BatchNorm2d(c2), torch.nn.ReLU(),
-                                   torch.nn.Conv2d(c2, c3, 1, bias=True)).to(dev).train()
+                                   *tail).to(dev).train()
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
