@@ -16,7 +16,10 @@
 namespace pdm {
 
 constexpr int PG_TS = 8;         // tile edge in cells
-constexpr int PG_CHUNK = 32;     // points staged per pass
+#ifndef PG_CHUNK_N
+#define PG_CHUNK_N 32
+#endif
+constexpr int PG_CHUNK = PG_CHUNK_N;     // points staged per pass
 constexpr int PG_THREADS = 256;
 constexpr int PG_MAXSH = 16;
 
@@ -248,74 +251,119 @@ __global__ __launch_bounds__(PG_THREADS) void pdm_gather_kernel(
 // D == 1 form: the accumulator tile lives in registers.  Wave w owns tile rows 2w and 2w+1 (16 cells), lane l
 // owns channels l, l+64, ... (CPL per lane), so acc[16][CPL] never leaves the register file, an empty tile costs
 // nothing but its zero stores, and every store instruction of the epilogue is one 256-byte row segment.
+//
+// A tile of the bench workload holds a handful of points (1024 points x ~3 tiles each over 550 tiles), so a workgroup
+// is a chain of dependent round trips (list bounds -> list -> point rows -> stores) rather than arithmetic:
+//   - the list is rank-sorted from LDS into LDS (no store + reload of a sorted copy through L2);
+//   - a point reaches ~16 of the tile's 64 cells: phase 1 leaves the ballot of its non-zero weights beside them, and a
+//     wave skips a point that misses its two rows (and the 4-cell groups it misses) on scalar tests — adding a zero
+//     weight changes nothing, so the sums are those of the dense loop, bit for bit;
+//   - the per-cell weight sums are taken by 16 lanes of the wave from the same LDS rows, in the same order.
+#ifndef PG_LIST_N
+#define PG_LIST_N 1024
+#endif
+constexpr int PG_LIST = PG_LIST_N;    // list entries sorted in LDS; a longer list (never at the shipped sizes) sorts through global memory
+
+#ifndef PG_DIAG
+#define PG_DIAG 0                // timing builds (tools/diag/pdm_gather_rate.py): 1 no accumulation, 2 no weight arithmetic, 4 stores only, 8 no list (points tile*7.. of the sample)
+#endif
+
+typedef float pg_v2f __attribute__((ext_vector_type(2)));
+
+#ifndef PG_WAVES
+#define PG_WAVES_ATTR
+#else
+#define PG_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PG_WAVES, PG_WAVES)))
+#endif
 template <int CPL>
-__global__ __launch_bounds__(PG_THREADS) void pdm_gather_reg_kernel(
+__global__ __launch_bounds__(PG_THREADS) PG_WAVES_ATTR void pdm_gather_reg_kernel(
     int P, int C, int degree, PgGrid g, int ntiles, int cap, int normalize, float eps,
     const float *__restrict__ xyz, const float *__restrict__ feat, const float *__restrict__ sh,
     const float *__restrict__ inv2s2, const int *__restrict__ tile_start_all, const int *__restrict__ tile_pts_all,
     int *__restrict__ tile_sorted_all, float *__restrict__ grid, float *__restrict__ wsum_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NPAR = 4 + PG_MAXSH;
+    constexpr int CP2 = (CPL + 1) / 2;             // channel pairs per lane: (k, k + 1) of a pair are channels 64 k + lane, 64 (k + 1) + lane
     float *wgt = lds;                              // PG_CHUNK x 64 cells
     float *fbuf = wgt + PG_CHUNK * 64;             // PG_CHUNK x C
     float *par = fbuf + (size_t)PG_CHUNK * C;      // PG_CHUNK x NPAR : x, y, z, inv2s2, sh...
+    int *pbase = reinterpret_cast<int *>(par + PG_CHUNK * NPAR);                 // PG_CHUNK x 2: base cell (x, y), or a cell no tile reaches
+    unsigned *msk = reinterpret_cast<unsigned *>(pbase + PG_CHUNK * 2);          // PG_CHUNK x 2: ballot of the non-zero weights
+    int *lst = reinterpret_cast<int *>(msk + PG_CHUNK * 2);                      // PG_LIST unsorted, PG_LIST sorted
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx = tile % g.TW, ty = tile / g.TW;
     const int nsh = (degree + 1) * (degree + 1);
     const int *__restrict__ ts = tile_start_all + (size_t)b * (ntiles + 1);
-    const int s = ts[tile], e = ts[tile + 1];
-    int *tp = tile_sorted_all + (size_t)b * cap;
-    float acc[16][CPL], wacc[16];
+    const int s = PG_DIAG & 4 ? 0 : ts[tile], e = PG_DIAG & 4 ? 0 : ts[tile + 1];
+    const int *sorted = lst + PG_LIST;
+    pg_v2f acc[16][CP2];
+    float wsl = 0.0f;                              // lanes 0..15: weight sum of cell wave * 16 + lane
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        wacc[j] = 0.0f;
+    for (int j = 0; j < 16; ++j)
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) acc[j][k] = 0.0f;
-    }
-    if (e > s) {
+        for (int k = 0; k < CP2; ++k) acc[j][k] = pg_v2f{0.0f, 0.0f};
+    if (e > s && !(PG_DIAG & 8)) {   // distinct indices: rank = number of smaller entries
         const int *__restrict__ raw = tile_pts_all + (size_t)b * cap;
-        for (int i = s + tid; i < e; i += PG_THREADS) {  // distinct indices: rank = number of smaller entries
-            const int v = raw[i];
-            int rank = 0;
-            for (int j = s; j < e; ++j) rank += raw[j] < v;
-            tp[s + rank] = v;
+        if (e - s <= PG_LIST) {
+            for (int i = tid; i < e - s; i += PG_THREADS) lst[i] = raw[s + i];
+            __syncthreads();
+            for (int i = tid; i < e - s; i += PG_THREADS) {
+                const int v = lst[i];
+                int rank = 0;
+                for (int j = 0; j < e - s; ++j) rank += lst[j] < v;
+                lst[PG_LIST + rank] = v;
+            }
+        } else {
+            int *tp = tile_sorted_all + (size_t)b * cap;
+            for (int i = s + tid; i < e; i += PG_THREADS) {
+                const int v = raw[i];
+                int rank = 0;
+                for (int j = s; j < e; ++j) rank += raw[j] < v;
+                tp[s + rank] = v;
+            }
+            sorted = nullptr;
         }
     }
-    for (int c0 = s; c0 < e; c0 += PG_CHUNK) {
-        const int np = min(PG_CHUNK, e - c0);
+    const int *tpg = tile_sorted_all + (size_t)b * cap + s;
+    for (int c0 = 0; c0 < e - s; c0 += PG_CHUNK) {
+        const int np = min(PG_CHUNK, e - s - c0);
         __syncthreads();
+#define PG_POINT(q) (PG_DIAG & 8 ? (tile * 7 + c0 + (q)) % P : sorted ? sorted[c0 + (q)] : tpg[c0 + (q)])
         if ((C & 3) == 0) {
             const int C4 = C >> 2;
             for (int i = tid; i < np * C4; i += PG_THREADS) {
                 const int q = i / C4, c = i - q * C4;
                 reinterpret_cast<float4 *>(fbuf)[q * C4 + c] =
-                    reinterpret_cast<const float4 *>(feat + ((size_t)b * P + tp[c0 + q]) * C)[c];
+                    reinterpret_cast<const float4 *>(feat + ((size_t)b * P + PG_POINT(q)) * C)[c];
             }
         } else {
             for (int i = tid; i < np * C; i += PG_THREADS) {
                 const int q = i / C, c = i - q * C;
-                fbuf[q * C + c] = feat[((size_t)b * P + tp[c0 + q]) * C + c];
+                fbuf[q * C + c] = feat[((size_t)b * P + PG_POINT(q)) * C + c];
             }
         }
-        for (int i = tid; i < np * NPAR; i += PG_THREADS) {
-            const int q = i / NPAR, k = i - q * NPAR;
-            const size_t pi = (size_t)b * P + tp[c0 + q];
-            float v = 0.0f;
-            if (k < 3) v = xyz[pi * 3 + k];
-            else if (k == 3) v = inv2s2[pi];
-            else if (k - 4 < nsh) v = sh[pi * nsh + (k - 4)];
-            par[i] = v;
+        for (int i = tid; i < np * PG_MAXSH; i += PG_THREADS) {
+            const int q = i / PG_MAXSH, k = i - q * PG_MAXSH;
+            par[q * NPAR + 4 + k] = k < nsh ? sh[((size_t)b * P + PG_POINT(q)) * nsh + k] : 0.0f;
         }
-        __syncthreads();
-        for (int i = tid; i < np * 64; i += PG_THREADS) {   // weight of (point q, cell cl)
-            const int q = i >> 6, cl = i & 63;
-            const float *pp = par + q * NPAR;
-            const int gx = tx * PG_TS + (cl & 7), gy = ty * PG_TS + (cl >> 3);
+        if (tid < np) {
+            const size_t pi = (size_t)b * P + PG_POINT(tid);
+            const float px = xyz[pi * 3], py = xyz[pi * 3 + 1], pz = xyz[pi * 3 + 2];
+            par[tid * NPAR] = px; par[tid * NPAR + 1] = py; par[tid * NPAR + 2] = pz; par[tid * NPAR + 3] = inv2s2[pi];
             int bx = 0, by = 0, bz = 0;
-            const bool in = pg_base_cell(g, pp[0], pp[1], pp[2], bx, by, bz);
+            const bool in = pg_base_cell(g, px, py, pz, bx, by, bz) && abs(bz) <= g.kz / 2;
+            pbase[tid * 2] = in ? bx : -(1 << 28);
+            pbase[tid * 2 + 1] = by;
+        }
+#undef PG_POINT
+        __syncthreads();
+        for (int q = wave; q < np; q += PG_THREADS / 64) {   // weight of (point q, cell `lane`): one point per wave pass
+            const float *pp = par + q * NPAR;
+            const int gx = tx * PG_TS + (lane & 7), gy = ty * PG_TS + (lane >> 3);
+            const int bx = pbase[q * 2], by = pbase[q * 2 + 1];
             float w = 0.0f;
-            if (in && gx < g.W && gy < g.H && abs(gx - bx) <= g.kx / 2 && abs(gy - by) <= g.ky / 2 && abs(bz) <= g.kz / 2) {
+            if (!(PG_DIAG & 2) && gx < g.W && gy < g.H && abs(gx - bx) <= g.kx / 2 && abs(gy - by) <= g.ky / 2) {
                 const float ux = __fmaf_rn((float)gx + 0.5f, g.cx, g.ox) - pp[0];
                 const float uy = __fmaf_rn((float)gy + 0.5f, g.cy, g.oy) - pp[1];
                 const float uz = __fmaf_rn(0.5f, g.cz, g.oz) - pp[2];
@@ -334,38 +382,47 @@ __global__ __launch_bounds__(PG_THREADS) void pdm_gather_reg_kernel(
                 }
                 w = sacc * __expf(-r2 * pp[3]);
             }
-            wgt[i] = w;
+            wgt[q * 64 + lane] = w;
+            const unsigned long long m = __ballot(w != 0.0f);
+            if (lane == 0) { msk[q * 2] = (unsigned)m; msk[q * 2 + 1] = (unsigned)(m >> 32); }
         }
         __syncthreads();
+        if (PG_DIAG & 1) continue;
         for (int q = 0; q < np; ++q) {
-            float f[CPL];
+            const unsigned m16 = (__builtin_amdgcn_readfirstlane(msk[q * 2 + (wave >> 1)]) >> ((wave & 1) * 16)) & 0xffffu;
+            if (m16 == 0) continue;                                     // the point misses this wave's two rows
+            wsl += wgt[q * 64 + wave * 16 + (lane & 15)];
+            pg_v2f f[CP2];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) f[k] = (k * 64 + lane < C) ? fbuf[q * C + k * 64 + lane] : 0.0f;
+            for (int k = 0; k < CP2; ++k) {
+                f[k].x = (2 * k * 64 + lane < C) ? fbuf[q * C + 2 * k * 64 + lane] : 0.0f;
+                f[k].y = (2 * k + 1 < CPL && (2 * k + 1) * 64 + lane < C) ? fbuf[q * C + (2 * k + 1) * 64 + lane] : 0.0f;
+            }
             const float4 *wr = reinterpret_cast<const float4 *>(wgt + q * 64 + wave * 16);
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
+                if (!(m16 & (0xfu << (4 * j4)))) continue;
                 const float4 w4 = wr[j4];
                 const float w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    wacc[j4 * 4 + jj] += w[jj];
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) acc[j4 * 4 + jj][k] = fmaf(w[jj], f[k], acc[j4 * 4 + jj][k]);
-                }
+                    for (int k = 0; k < CP2; ++k)
+                        acc[j4 * 4 + jj][k] = __builtin_elementwise_fma(pg_v2f{w[jj], w[jj]}, f[k], acc[j4 * 4 + jj][k]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int gx = tx * PG_TS + (j & 7), gy = ty * PG_TS + wave * 2 + (j >> 3);
+        const float ws = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsl), j));
         if (gx >= g.W || gy >= g.H) continue;  // wave-uniform
         const size_t cell = ((size_t)b * g.H + gy) * g.W + gx;
-        const float ws = wacc[j];
         const float sc = (normalize && fabsf(ws) > eps) ? 1.0f / ws : 1.0f;
         float *dst = grid + cell * C;
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
-            if (k * 64 + lane < C) dst[k * 64 + lane] = acc[j][k] * sc;
+            if (k * 64 + lane < C) dst[k * 64 + lane] = (k & 1 ? acc[j][k >> 1].y : acc[j][k >> 1].x) * sc;
         if (lane == 0) wsum_out[cell] = ws;
     }
 }
@@ -406,7 +463,7 @@ extern "C" int pdm_gather_bev(void *stream, int B, int P, int C, int degree, con
     int *tile_sorted = tile_pts + (size_t)B * cap;
     const bool reg_form = D == 1 && C <= 256;
     const int ncell = PG_TS * PG_TS * D;
-    const size_t lds = reg_form ? ((size_t)PG_CHUNK * 64 + (size_t)PG_CHUNK * C + PG_CHUNK * (4 + PG_MAXSH)) * sizeof(float)
+    const size_t lds = reg_form ? ((size_t)PG_CHUNK * 64 + (size_t)PG_CHUNK * C + PG_CHUNK * (4 + PG_MAXSH) + PG_CHUNK * 4 + 2 * PG_LIST) * sizeof(float)
                                 : ((size_t)ncell * C + ncell + (size_t)ncell * PG_CHUNK + (size_t)PG_CHUNK * C +
                                    PG_CHUNK * (4 + PG_MAXSH)) * sizeof(float) + PG_CHUNK * 3 * sizeof(int);
     PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "pdm_gather_bev: C=%d D=%d need %zu bytes of LDS (use pdm_scatter_bev)", C, D, lds);
