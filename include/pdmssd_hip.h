@@ -535,7 +535,8 @@ int pdm_gather_bev(void *stream, int B, int P, int C, int degree, const float *x
                    int normalize, float eps, float *grid, float *wsum, void *workspace, size_t workspace_bytes);
 
 /* Backward of pdm_bev_normalize for layout 1 (channels-last): y = the normalised grid, dy its gradient ->
- * dx (B,H,W,C*D) and dwsum (B,H,W,D), both fully written. */
+ * dx (B,H,W,C*D) and dwsum (B,H,W,D), both fully written.  dx may be NULL (dwsum only: pdm_scatter_bev_grad_normalized
+ * applies the division on its own reads of dy). */
 int pdm_bev_normalize_grad(void *stream, int B, int C, int W, int H, int D, float eps, const float *y,
                            const float *wsum, const float *dy, float *dx, float *dwsum);
 
@@ -547,6 +548,14 @@ int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const fl
                          float icz, int W, int H, int D, int kx, int ky, int kz, int layout,
                          const float *dgrid, const float *dwsum, float *dfeat, float *dsh,
                          float *dinv2s2);
+/* The same for the NORMALISED map y = grid / wsum (where |wsum| > eps): dy = dL/dy as it arrives, wsum (B,H,W,D) as the
+ * forward left it, dwsum = pdm_bev_normalize_grad's second output (required).  No dL/dgrid tensor is formed. */
+int pdm_scatter_bev_grad_normalized(void *stream, int B, int P, int C, int degree, const float *xyz,
+                                    const float *feat, const float *sh, const float *inv2s2, float ox,
+                                    float oy, float oz, float cx, float cy, float cz, float icx, float icy,
+                                    float icz, int W, int H, int D, int kx, int ky, int kz, int layout,
+                                    const float *dy, const float *wsum, float eps, const float *dwsum,
+                                    float *dfeat, float *dsh, float *dinv2s2);
 
 /* SURVEY.md section 8(f) row N4 -- score-ranked (instance-aware) sampling instead of FPS.  The sampling code of the
  * PDM-SSD / IA-SSD lineage is absent from the reference snapshot; its analog there is torch.topk over per-point scores.

@@ -213,12 +213,14 @@ __global__ __launch_bounds__(PDM_WAVES * 64) void pdm_scatter_grad_kernel(
     int B, int P, int C, int degree, PdmGrid g, int layout, const float *__restrict__ xyz,
     const float *__restrict__ feat, const float *__restrict__ sh, const float *__restrict__ inv2s2,
     const float *__restrict__ dgrid, const float *__restrict__ dwsum, float *__restrict__ dfeat,
-    float *__restrict__ dsh, float *__restrict__ dinv2s2) {
-    __shared__ float s_w[PDM_WAVES][PDM_MAXK];
-    __shared__ float s_dw[PDM_WAVES][PDM_MAXK];
-    __shared__ int s_cell[PDM_WAVES][PDM_MAXK];
-    __shared__ int s_z[PDM_WAVES][PDM_MAXK];
+    float *__restrict__ dsh, float *__restrict__ dinv2s2, const float *__restrict__ nwsum, float neps) {
+    // per wave, K entries each (dynamic LDS sized to the window, so that residency is not capped by the largest one):
+    // weight, weight gradient, 1 / wsum of the cell (1 without nwsum), cell index (or -1), height bin
+    extern __shared__ __attribute__((aligned(16))) float sg_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Kw = g.kx * g.ky * g.kz;
+    float *s_w = sg_lds + (size_t)wave * 5 * Kw, *s_dw = s_w + Kw, *s_inv = s_dw + Kw;
+    int *s_cell = reinterpret_cast<int *>(s_inv + Kw), *s_z = s_cell + Kw;
     const long long pi = (long long)blockIdx.x * PDM_WAVES + wave;
     if (pi >= (long long)B * P) return;
     const int b = (int)(pi / P);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(PDM_WAVES * 64) void pdm_scatter_grad_kernel(
     for (int k = lane; k < K; k += 64) {
         int gx, gy, gz;
         const bool ok = dilate_cell(g, k, bx, by, bz, gx, gy, gz);
-        float w = 0.0f, dw0 = 0.0f;
+        float w = 0.0f, dw0 = 0.0f, inv = 1.0f;
         if (ok) {
             const float ux = __fmaf_rn((float)gx + 0.5f, g.cx, g.ox) - px;
             const float uy = __fmaf_rn((float)gy + 0.5f, g.cy, g.oy) - py;
@@ -262,36 +264,85 @@ __global__ __launch_bounds__(PDM_WAVES * 64) void pdm_scatter_grad_kernel(
                 s = a[0] * 0.28209479177387814f;
             }
             w = s * __expf(-r2 * is2);
-            if (dwsum) dw0 = dwsum[(((size_t)b * g.H + gy) * g.W + gx) * g.D + gz];
+            const size_t ci = (((size_t)b * g.H + gy) * g.W + gx) * g.D + gz;
+            if (dwsum) dw0 = dwsum[ci];
+            if (nwsum) { const float ws = nwsum[ci]; if (fabsf(ws) > neps) inv = 1.0f / ws; }
         }
-        s_w[wave][k] = w;
-        s_dw[wave][k] = dw0;
-        s_cell[wave][k] = ok ? gy * g.W + gx : -1;
-        s_z[wave][k] = gz;
+        s_w[k] = w;
+        s_inv[k] = inv;
+        s_dw[k] = dw0;
+        s_cell[k] = ok ? gy * g.W + gx : -1;
+        s_z[k] = gz;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 
     // dfeat[c] = sum_k w_k dgrid[k,c];  dw_k += sum_c dgrid[k,c] f[c]
     const float *__restrict__ f = feat + pi * C;
+    if (layout == 1 && g.D == 1 && (C & 1) == 0) {
+        // channels-last map, one height bin: a lane owns the channel pair (2 lane, 2 lane + 1) — one 8-byte load per cell covers
+        // 128 channels — and the rows of fourteen cells are requested before the first is consumed.  (One 4-byte load at a time,
+        // each consumed before the next was requested, made a wave a chain of 2 K round trips: 0.68 ms per step at bs = 32.)
+        const size_t HW = (size_t)g.H * g.W;
+        for (int c0 = 0; c0 < C; c0 += 128) {
+            const int c = c0 + 2 * lane;
+            const bool on = c < C;
+            const float2 fc = on ? *reinterpret_cast<const float2 *>(f + c) : make_float2(0.0f, 0.0f);
+            float2 acc = make_float2(0.0f, 0.0f);
+            constexpr int U = 14;
+            for (int k0 = 0; k0 < K; k0 += U) {
+                float2 dg[U];
+                int cells[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int k = k0 + j;
+                    cells[j] = k < K ? s_cell[k] : -1;
+                    dg[j] = make_float2(0.0f, 0.0f);
+                    if (cells[j] >= 0 && on) dg[j] = *reinterpret_cast<const float2 *>(dgrid + ((size_t)b * HW + cells[j]) * C + c);
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    if (cells[j] < 0) continue;         // wave-uniform
+                    const float inv = s_inv[k0 + j], w = s_w[k0 + j] * inv;     // dgrid is the gradient of grid / wsum with nwsum
+                    acc.x += w * dg[j].x;
+                    acc.y += w * dg[j].y;
+                    const float part = wave_sum(dg[j].x * fc.x + dg[j].y * fc.y);
+                    if (lane == 0) s_dw[k0 + j] += inv * part;
+                }
+            }
+            if (on) *reinterpret_cast<float2 *>(dfeat + pi * C + c) = acc;
+        }
+    } else
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + lane;
         const float fc = c < C ? f[c] : 0.0f;
         float acc = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const int cell = s_cell[wave][k];
-            if (cell < 0) continue;
-            const int gz = s_z[wave][k];
-            float dg = 0.0f;
-            if (c < C) {
-                const size_t q = (size_t)c * g.D + gz;
-                const size_t off = layout == 1 ? ((size_t)b * g.H * g.W + cell) * CD + q
-                                               : ((size_t)b * CD + q) * g.H * g.W + cell;
-                dg = dgrid[off];
+        // seven cells (a row of the 7 x 7 window) per pass, their loads issued together: one load at a time, each consumed
+        // before the next was requested, made a wave a chain of K round trips (0.68 ms per step at bs = 32)
+        constexpr int U = 7;
+        for (int k0 = 0; k0 < K; k0 += U) {
+            float dg[U];
+            int cells[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int k = k0 + j;
+                cells[j] = k < K ? s_cell[k] : -1;
+                dg[j] = 0.0f;
+                if (cells[j] >= 0 && c < C) {
+                    const size_t q = (size_t)c * g.D + s_z[k];
+                    const size_t off = layout == 1 ? ((size_t)b * g.H * g.W + cells[j]) * CD + q
+                                                   : ((size_t)b * CD + q) * g.H * g.W + cells[j];
+                    dg[j] = dgrid[off];
+                }
             }
-            acc += s_w[wave][k] * dg;
-            const float part = wave_sum(dg * fc);
-            if (lane == 0) s_dw[wave][k] += part;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (cells[j] < 0) continue;             // wave-uniform
+                const float inv = s_inv[k0 + j];
+                acc += s_w[k0 + j] * inv * dg[j];
+                const float part = wave_sum(dg[j] * fc);
+                if (lane == 0) s_dw[k0 + j] += inv * part;
+            }
         }
         if (c < C) dfeat[pi * C + c] = acc;
     }
@@ -304,7 +355,7 @@ __global__ __launch_bounds__(PDM_WAVES * 64) void pdm_scatter_grad_kernel(
     for (int t = 0; t < PDM_MAXSH; ++t) da[t] = 0.0f;
     float dis2 = 0.0f;
     for (int k = lane; k < K; k += 64) {
-        if (s_cell[wave][k] < 0) continue;
+        if (s_cell[k] < 0) continue;
         int gx, gy, gz;
         dilate_cell(g, k, bx, by, bz, gx, gy, gz);
         const float ux = __fmaf_rn((float)gx + 0.5f, g.cx, g.ox) - px;
@@ -319,11 +370,11 @@ __global__ __launch_bounds__(PDM_WAVES * 64) void pdm_scatter_grad_kernel(
             ny = sh_basis(degree, ux * inv, uy * inv, uz * inv, Y);
         }
         const float G = __expf(-r2 * is2);
-        const float dw = s_dw[wave][k];
+        const float dw = s_dw[k];
 #pragma unroll
         for (int t = 0; t < PDM_MAXSH; ++t)
             if (t < ny) da[t] += dw * G * Y[t];
-        dis2 += dw * s_w[wave][k] * (-r2);
+        dis2 += dw * s_w[k] * (-r2);
     }
 #pragma unroll
     for (int t = 0; t < PDM_MAXSH; ++t) {
@@ -414,10 +465,49 @@ __global__ __launch_bounds__(256) void pdm_normalize_grad_kernel(long long cells
                 const int q = c * D + z;
                 const float g = gg[q];
                 acc += g * yy[q];
-                xx[q] = g * inv;
+                if (dx) xx[q] = g * inv;
             }
             for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
             if (lane == 0) dwsum[cell * D + z] = on ? -inv * acc : 0.0f;
+        }
+    }
+}
+
+// The same for D == 1 and C a multiple of 4: LPC lanes (a power of two, <= 64) share a cell with 16-byte loads, a wave holds
+// 64 / LPC cells at a time and two such groups are in flight.  (One wave per cell with 4-byte loads streamed y and dy at
+// 3.8 TB/s.)  dx may be null.
+template <int LPC>
+__global__ __launch_bounds__(256) void pdm_normalize_grad_cl4_kernel(long long cells, int C4, float eps, const float4 *__restrict__ y,
+                                                                     const float *__restrict__ wsum, const float4 *__restrict__ dy,
+                                                                     float4 *__restrict__ dx, float *__restrict__ dwsum) {
+    constexpr int CPW = 64 / LPC;                           // cells per wave pass
+    const int lane = threadIdx.x & 63, sub = lane & (LPC - 1), slot = lane / LPC;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long c0 = wave0 * (2 * CPW); c0 < cells; c0 += nwaves * (2 * CPW)) {
+        float acc[2], inv[2];
+        bool on[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long cell = c0 + h * CPW + slot;
+            acc[h] = 0.0f; inv[h] = 1.0f; on[h] = false;
+            if (cell < cells) {
+                const float w = wsum[cell];
+                on[h] = fabsf(w) > eps;
+                if (on[h]) inv[h] = 1.0f / w;
+                for (int q = sub; q < C4; q += LPC) {
+                    const float4 g = dy[cell * C4 + q], v = y[cell * C4 + q];
+                    acc[h] += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+                    if (dx) dx[cell * C4 + q] = make_float4(g.x * inv[h], g.y * inv[h], g.z * inv[h], g.w * inv[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int off = LPC / 2; off >= 1; off >>= 1) acc[h] += __shfl_xor(acc[h], off, 64);
+            const long long cell = c0 + h * CPW + slot;
+            if (sub == 0 && cell < cells) dwsum[cell] = on[h] ? -inv[h] * acc[h] : 0.0f;
         }
     }
 }
@@ -427,19 +517,32 @@ extern "C" int pdm_bev_normalize_grad(void *stream, int B, int C, int W, int H, 
     PDM_REQUIRE(B >= 0 && C >= 0 && W > 0 && H > 0 && D > 0, PDM_E_BADARG, "pdm_bev_normalize_grad: bad size");
     const long long cells = (long long)B * H * W;
     if (cells == 0 || C == 0) return 0;
-    PDM_REQUIRE(y && wsum && dy && dx && dwsum, PDM_E_BADARG, "pdm_bev_normalize_grad: null pointer");
+    PDM_REQUIRE(y && wsum && dy && dwsum, PDM_E_BADARG, "pdm_bev_normalize_grad: null pointer");   // dx may be null: dwsum only
+    const auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (D == 1 && C % 4 == 0 && al16(y) && al16(dy) && al16(dx)) {
+        const int C4 = C / 4;
+        const int lpc = C4 >= 64 ? 64 : C4 > 16 ? 32 : C4 > 8 ? 16 : 8;
+        const long long per_wg = 4 * 2 * (64 / lpc), wgs = (cells + per_wg - 1) / per_wg;
+        const dim3 grid((unsigned)(wgs > 8192 ? 8192 : wgs));
+#define NG_LAUNCH(L) hipLaunchKernelGGL(pdm_normalize_grad_cl4_kernel<L>, grid, dim3(256), 0, as_stream(stream), cells, C4, eps, \
+                                        reinterpret_cast<const float4 *>(y), wsum, reinterpret_cast<const float4 *>(dy),            \
+                                        reinterpret_cast<float4 *>(dx), dwsum)
+        if (lpc == 64) NG_LAUNCH(64); else if (lpc == 32) NG_LAUNCH(32); else if (lpc == 16) NG_LAUNCH(16); else NG_LAUNCH(8);
+#undef NG_LAUNCH
+        return check_launch("pdm_bev_normalize_grad");
+    }
     const long long want = (cells + 3) / 4;
     hipLaunchKernelGGL(pdm_normalize_grad_kernel, dim3((unsigned)(want > 16384 ? 16384 : want)), dim3(256), 0, as_stream(stream),
                        cells, C, D, eps, y, wsum, dy, dx, dwsum);
     return check_launch("pdm_bev_normalize_grad");
 }
 
-extern "C" int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const float *xyz,
+static int scatter_bev_grad_launch(void *stream, int B, int P, int C, int degree, const float *xyz,
                                     const float *feat, const float *sh, const float *inv2s2,
                                     float ox, float oy, float oz, float cx, float cy, float cz,
                                     float icx, float icy, float icz, int W, int H, int D, int kx,
                                     int ky, int kz, int layout, const float *dgrid,
-                                    const float *dwsum, float *dfeat, float *dsh, float *dinv2s2) {
+                                    const float *dwsum, float *dfeat, float *dsh, float *dinv2s2, const float *nwsum, float neps) {
     int rc = check_grid_args("pdm_scatter_bev_grad", B, P, C, degree, W, H, D, kx, ky, kz, layout);
     if (rc) return rc;
     if ((long long)B * P == 0) return 0;
@@ -448,8 +551,33 @@ extern "C" int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degre
     PdmGrid g{ox, oy, oz, cx, cy, cz, icx, icy, icz, W, H, D, kx, ky, kz};
     const long long blocks = ((long long)B * P + PDM_WAVES - 1) / PDM_WAVES;
     PDM_REQUIRE(blocks < (1ll << 31), PDM_E_TOOLARGE, "pdm_scatter_bev_grad: too many points");
-    hipLaunchKernelGGL(pdm_scatter_grad_kernel, dim3((unsigned)blocks), dim3(PDM_WAVES * 64), 0,
+    const size_t lds = (size_t)PDM_WAVES * 5 * kx * ky * kz * sizeof(float);          // <= 40 KB at PDM_MAXK cells
+    hipLaunchKernelGGL(pdm_scatter_grad_kernel, dim3((unsigned)blocks), dim3(PDM_WAVES * 64), lds,
                        as_stream(stream), B, P, C, degree, g, layout, xyz, feat, sh, inv2s2, dgrid,
-                       dwsum, dfeat, dsh, dinv2s2);
+                       dwsum, dfeat, dsh, dinv2s2, nwsum, neps);
     return check_launch("pdm_scatter_bev_grad");
+}
+
+extern "C" int pdm_scatter_bev_grad(void *stream, int B, int P, int C, int degree, const float *xyz,
+                                    const float *feat, const float *sh, const float *inv2s2,
+                                    float ox, float oy, float oz, float cx, float cy, float cz,
+                                    float icx, float icy, float icz, int W, int H, int D, int kx,
+                                    int ky, int kz, int layout, const float *dgrid,
+                                    const float *dwsum, float *dfeat, float *dsh, float *dinv2s2) {
+    return scatter_bev_grad_launch(stream, B, P, C, degree, xyz, feat, sh, inv2s2, ox, oy, oz, cx, cy, cz, icx, icy, icz, W, H, D, kx, ky, kz,
+                                   layout, dgrid, dwsum, dfeat, dsh, dinv2s2, nullptr, 0.0f);
+}
+
+// The same gradient for the NORMALISED map y = grid / wsum (where |wsum| > eps): dgrid is dL/dy as it arrives, the division by
+// wsum is applied per cell on the way (wsum (B,H,W,D) as the forward left it), and dwsum = pdm_bev_normalize_grad's second output
+// (which may then be called with dx = null: no pass that writes dL/dgrid).
+extern "C" int pdm_scatter_bev_grad_normalized(void *stream, int B, int P, int C, int degree, const float *xyz,
+                                               const float *feat, const float *sh, const float *inv2s2,
+                                               float ox, float oy, float oz, float cx, float cy, float cz,
+                                               float icx, float icy, float icz, int W, int H, int D, int kx,
+                                               int ky, int kz, int layout, const float *dy, const float *wsum, float eps,
+                                               const float *dwsum, float *dfeat, float *dsh, float *dinv2s2) {
+    PDM_REQUIRE(wsum && dwsum, PDM_E_BADARG, "pdm_scatter_bev_grad_normalized: null pointer");
+    return scatter_bev_grad_launch(stream, B, P, C, degree, xyz, feat, sh, inv2s2, ox, oy, oz, cx, cy, cz, icx, icy, icz, W, H, D, kx, ky, kz,
+                                   layout, dy, dwsum, dfeat, dsh, dinv2s2, wsum, eps);
 }

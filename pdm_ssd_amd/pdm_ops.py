@@ -156,7 +156,8 @@ class PDMGatherNormalized(Function):
     """Training form of the neck's grid with the GATHER kernel in the forward pass: (xyz, feat, sh, inv2s2) -> (grid / wsum, wsum),
     channels-last.  Same sum as PDMScatter + BevNormalize (ascending point order per cell instead of the atomics' arrival order),
     but the grid is written once — no 0.6 GB zero fill, no float atomics, no separate normalisation pass (1.0 -> 0.2 ms at
-    bs = 32).  Backward: pdm_bev_normalize_grad, then the gather-form gradient kernel pdm_scatter_bev_grad, as before."""
+    bs = 32).  Backward: pdm_bev_normalize_grad for dL/dwsum only, then pdm_scatter_bev_grad_normalized, which divides by
+    wsum on its own reads of the incoming gradient — no dL/dgrid tensor (0.58 GB at bs = 32) is written or read."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -175,17 +176,16 @@ class PDMGatherNormalized(Function):
         B, P, _ = xyz.shape
         C = feat.shape[2]
         dy = dy.float().contiguous()
-        dx = torch.empty_like(y)
         dw = torch.empty_like(wsum)
         s = _stream(y)
         _native.call("pdm_bev_normalize_grad", s, B, C, g.W, g.H, g.D, eps, y.data_ptr(), wsum.data_ptr(), dy.data_ptr(),
-                     dx.data_ptr(), dw.data_ptr())
+                     0, dw.data_ptr())
         dfeat = torch.empty_like(feat)
         dsh = torch.empty_like(sh)
         dinv = torch.empty_like(inv2s2)
-        _native.call("pdm_scatter_bev_grad", s, B, P, C, degree, xyz.data_ptr(), feat.data_ptr(), sh.data_ptr(), inv2s2.data_ptr(),
-                     *g.floats(), g.W, g.H, g.D, *kernel, 1, dx.data_ptr(), dw.data_ptr(), dfeat.data_ptr(), dsh.data_ptr(),
-                     dinv.data_ptr())
+        _native.call("pdm_scatter_bev_grad_normalized", s, B, P, C, degree, xyz.data_ptr(), feat.data_ptr(), sh.data_ptr(),
+                     inv2s2.data_ptr(), *g.floats(), g.W, g.H, g.D, *kernel, 1, dy.data_ptr(), wsum.data_ptr(), eps, dw.data_ptr(),
+                     dfeat.data_ptr(), dsh.data_ptr(), dinv.data_ptr())
         return None, dfeat, dsh, dinv, None, None, None, None
 
 

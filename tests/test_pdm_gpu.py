@@ -87,10 +87,12 @@ def test_gather_matches_oracle(oracle, dev, degree, cell, kernel, C):
     assert torch.equal(again, got_n)
 
 
-def test_gather_dense_tile_and_edge_sizes(oracle, dev):
-    """Many points in one tile (several 32-point chunks, long sorted list), P = 1, P = 0 and B = 0."""
+@pytest.mark.parametrize("P", [700, 1500])
+def test_gather_dense_tile_and_edge_sizes(oracle, dev, P):
+    """Many points in one tile (several 32-point chunks; 700: a long list sorted in LDS, 1500: longer than the LDS list of
+    csrc/pdm_gather.hip, sorted through the workspace), P = 1, P = 0 and B = 0."""
     rng = np.random.default_rng(5)
-    B, P, C, degree, kernel, cell = 2, 700, 48, 2, (5, 5, 1), (0.8, 0.8, 4.0)
+    B, C, degree, kernel, cell = 2, 48, 2, (5, 5, 1), (0.8, 0.8, 4.0)
     xyz, feat, sh, inv2s2 = make_inputs(B, P, C, degree, seed=11, outliers=False)
     xyz[0, :, 0] = rng.uniform(10.0, 13.0, P); xyz[0, :, 1] = rng.uniform(-2.0, 1.0, P)   # sample 0: 4 x 4 cells
     g = pdm_ops.BevGrid(RANGE, cell)
@@ -139,6 +141,34 @@ def test_neck_eval_gather_equals_scatter_path(dev):
     sa, sb = a['spatial_features'], b['spatial_features']
     assert torch.allclose(sa, sb, rtol=2e-3, atol=2e-3 * float(sb.abs().max()))
     assert torch.allclose(a['pdm_weight_sum'], b['pdm_weight_sum'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,degree,kernel", [(128, 2, (7, 7, 1)), (70, 3, (5, 7, 1)), (200, 1, (3, 3, 1))])
+def test_training_gather_form_matches_scatter_and_normalize_autograd(dev, C, degree, kernel):
+    """pdm_gather_normalized (the neck's training form: gather kernel forward; backward = dL/dwsum pass + the gradient kernel
+    dividing by wsum on its own reads, no dL/dgrid tensor) against PDMScatter -> BevNormalize under autograd, whose backward the
+    oracle tests pin: the normalised map, the weight sums and the gradients of feat, sh and inv2s2 (which carry dL/dwsum)."""
+    B, P = 2, 600
+    xyz, feat, sh, inv2s2 = make_inputs(B, P, C, degree, seed=21)
+    sh[0, :40, :] *= 1e-4                                      # cells whose weight sum stays under eps: y = grid there
+    g = pdm_ops.BevGrid(RANGE, (0.8, 0.8, 4.0))
+    gy = torch.randn(B, g.H, g.W, C, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = []
+    for form in ("gather", "scatter"):
+        a = [T(v, dev).requires_grad_(i > 0) for i, v in enumerate((xyz, feat, sh, inv2s2))]
+        if form == "gather":
+            y, w = pdm_ops.pdm_gather_normalized(*a, g, kernel, degree, 1e-3)
+        else:
+            grid, w = pdm_ops.pdm_scatter(*a, g, kernel, degree, 1)
+            y = pdm_ops.bev_normalize(grid, w, C, g, 1e-3)
+        (y.view(B, g.H, g.W, C) * gy).sum().backward()
+        res.append((y.detach().view(B, g.H, g.W, C), w.detach().view(B, g.H, g.W), [t.grad for t in a[1:]]))
+    (ya, wa, ga), (yb, wb, gb) = res
+    assert float((wb.abs() <= 1e-3).float().mean()) > 0.05 and float((wb.abs() > 1e-3).float().mean()) > 0.05
+    torch.testing.assert_close(wa, wb, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ya, yb, rtol=1e-4, atol=1e-4 * float(yb.abs().max()))
+    for name, x, r in zip(("dfeat", "dsh", "dinv2s2"), ga, gb):
+        assert float((x - r).abs().max()) <= 2e-4 * float(r.abs().max()), name
 
 
 def test_scatter_linearity_and_zero_features(dev):
