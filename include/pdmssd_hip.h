@@ -479,6 +479,8 @@ size_t pdm_tg_colsum_ws_floats(long long R, int N);
 int pdm_tg_colsum(void *stream, long long R, int N, const void *Y, long long ld, float *out, float *scratch);
 /* W (N, K) fp32 -> bf16 Wb (N, ldb) and / or its transpose Wt (K, ldt); either may be null; pad columns zero */
 int pdm_tg_pack_weight(void *stream, int N, int K, const float *W, void *Wb, int ldb, void *Wt, int ldt);
+/* the pair a layer needs, every element written: Wb (rows_to, cols_to) = W zero padded, Wt (cols_to, rows_to) = its transpose */
+int pdm_tg_pack_weight_pair(void *stream, int N, int K, const float *W, void *Wb, void *Wt, int rows_to, int cols_to);
 
 
 /* ---- diagnostics (process-global tuning switches used by tools/diag/ A/B measurements; every setting gives

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "pdm_bn_finalize_stats": [ctypes.c_longlong, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_tg_colsum": [ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "pdm_tg_pack_weight": [_i, _i, _vp, _vp, _i, _vp, _i],
+    "pdm_tg_pack_weight_pair": [_i, _i, _vp, _vp, _vp, _i, _i],
     "pdm_tune_fps_variant": None,
     "pdm_tune_fused_waves": None,
     "pdm_tune_fused_tiles": None,

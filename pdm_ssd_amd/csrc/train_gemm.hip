@@ -869,16 +869,17 @@ static size_t tg_fold_scratch_floats(long long parts, long long elems) {
 }
 
 // W (N, K) fp32 -> Wb (N, ldb) bf16 and / or Wt (K, ldt) bf16 (transposed), zero padded to the strides
+// (rows_b rows of Wb and rows_t rows of Wt are written: rows >= N of Wb / >= K of Wt are zero padding too)
 __global__ __launch_bounds__(256) void tg_pack_weight_kernel(const float *__restrict__ W, int N, int K, unsigned short *__restrict__ Wb, int ldb,
-                                                             unsigned short *__restrict__ Wt, int ldt) {
+                                                             unsigned short *__restrict__ Wt, int ldt, int rows_b, int rows_t) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (Wb && e < (long long)N * ldb) {
+    if (Wb && e < (long long)rows_b * ldb) {
         const int n = (int)(e / ldb), k = (int)(e % ldb);
-        Wb[e] = k < K ? tg_bf16(W[(long long)n * K + k]) : (unsigned short)0;
+        Wb[e] = (n < N && k < K) ? tg_bf16(W[(long long)n * K + k]) : (unsigned short)0;
     }
-    if (Wt && e < (long long)K * ldt) {
+    if (Wt && e < (long long)rows_t * ldt) {
         const int k = (int)(e / ldt), n = (int)(e % ldt);
-        Wt[e] = n < N ? tg_bf16(W[(long long)n * K + k]) : (unsigned short)0;
+        Wt[e] = (k < K && n < N) ? tg_bf16(W[(long long)n * K + k]) : (unsigned short)0;
     }
 }
 
@@ -1105,6 +1106,18 @@ extern "C" int pdm_tg_pack_weight(void *stream, int N, int K, const float *W, vo
     if (Wb) elems = (long long)N * ldb;
     if (Wt && (long long)K * ldt > elems) elems = (long long)K * ldt;
     hipLaunchKernelGGL(tg_pack_weight_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, as_stream(stream), W, N, K,
-                       static_cast<unsigned short *>(Wb), ldb, static_cast<unsigned short *>(Wt), ldt);
+                       static_cast<unsigned short *>(Wb), ldb, static_cast<unsigned short *>(Wt), ldt, N, K);
     return check_launch("tg_pack_weight");
+}
+
+// The pair a layer of the training path needs, in one launch and WHOLE: Wb (rows_to, cols_to) = W zero padded, Wt (cols_to, rows_to)
+// = its transpose, every element written (no zero fill of the buffers in front).  rows_to >= N, cols_to >= K.
+extern "C" int pdm_tg_pack_weight_pair(void *stream, int N, int K, const float *W, void *Wb, void *Wt, int rows_to, int cols_to) {
+    PDM_REQUIRE(N >= 0 && K >= 0 && rows_to >= N && cols_to >= K, PDM_E_BADARG, "tg_pack_weight_pair: bad size");
+    if (rows_to == 0 || cols_to == 0) return 0;
+    PDM_REQUIRE(Wb && Wt && (W || N == 0 || K == 0), PDM_E_BADARG, "tg_pack_weight_pair: null pointer");
+    const long long elems = (long long)rows_to * cols_to;
+    hipLaunchKernelGGL(tg_pack_weight_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, as_stream(stream), W, N, K,
+                       static_cast<unsigned short *>(Wb), cols_to, static_cast<unsigned short *>(Wt), rows_to, rows_to, cols_to);
+    return check_launch("tg_pack_weight_pair");
 }

@@ -251,6 +251,7 @@ class _RowsGemm(Function):
     def forward(ctx, x, weight, bias, want_stats, keep_pad=False, link=None):
         from . import train_gemm as tg
         ctx.link = link
+        ctx.set_materialize_grads(False)     # no zero tensor (a fill launch per node and step) for the statistics output's gradient
         xr = tg.row_view(x)
         assert xr is not None
         if xr.dtype != torch.bfloat16:
@@ -276,6 +277,8 @@ class _RowsGemm(Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dstats=None):
         from . import train_gemm as tg
+        if dy is None:
+            return None, None, None, None, None, None
         xr, weight, wt = ctx.saved_tensors
         xshape, xdim, N, Np, K, Kw, has_bias, xdtype = ctx.geom
         R = xr.shape[0]
@@ -316,6 +319,7 @@ class _BnReluRowsGemm(Function):
                 in_link=None, out_link=None):
         from . import train_gemm as tg
         ctx.in_link, ctx.link = in_link, out_link
+        ctx.set_materialize_grads(False)
         xr = tg.row_view(x)
         R, K = xr.shape
         N = weight.shape[0]
@@ -344,6 +348,8 @@ class _BnReluRowsGemm(Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dstats=None):
         from . import train_gemm as tg
+        if dy is None:
+            return (None,) * 14
         xr, coef, weight, wt = ctx.saved_tensors
         xshape, xdim, N, Np, K, Kw, has_bias = ctx.geom
         R = xr.shape[0]

@@ -166,11 +166,14 @@ class PDMGatherNormalized(Function):
         ctx.save_for_backward(xyz.contiguous(), feat.contiguous(), sh.contiguous(), inv2s2.contiguous(), grid, wsum)
         ctx.spec = (grid_spec, tuple(kernel), degree, float(eps))
         ctx.mark_non_differentiable(wsum)
+        ctx.set_materialize_grads(False)     # no zero tensor for wsum's gradient
         return grid, wsum
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, _dwsum=None):
+        if dy is None:
+            return (None,) * 8
         xyz, feat, sh, inv2s2, y, wsum = ctx.saved_tensors
         g, kernel, degree, eps = ctx.spec
         B, P, _ = xyz.shape

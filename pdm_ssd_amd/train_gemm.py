@@ -62,10 +62,9 @@ def pack_weight_pair(w, rows_to, cols_to):
     assert w.dim() == 2 and w.is_cuda and w.dtype == torch.float32
     w = w.detach().contiguous()
     N, K = w.shape
-    alloc = torch.zeros if (rows_to != N or cols_to != K) else torch.empty
-    buf = alloc((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)
+    buf = torch.empty((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)     # the kernel writes the padding too
     wb, wt = buf[0].view(rows_to, cols_to), buf[1].view(cols_to, rows_to)
-    _native.call("pdm_tg_pack_weight", _stream(w), N, K, w.data_ptr(), wb.data_ptr(), cols_to, wt.data_ptr(), rows_to)
+    _native.call("pdm_tg_pack_weight_pair", _stream(w), N, K, w.data_ptr(), wb.data_ptr(), wt.data_ptr(), rows_to, cols_to)
     return wb, wt
 
 

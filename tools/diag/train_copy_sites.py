@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import bench
 
+MIN_BYTES = int(os.environ.get("MIN_BYTES", 1 << 20))     # MIN_BYTES=0: every call, listed by call count (the tiny launches)
 sites = collections.Counter()
 calls = collections.Counter()
 
@@ -20,7 +21,7 @@ def wrap(obj, name, size_of):
         out = orig(*a, **k)
         try:
             nbytes, changed = size_of(a, k, out)
-            if changed and nbytes >= (1 << 20):
+            if changed and nbytes >= MIN_BYTES:
                 key = f"{name:12s} {where()}"
                 sites[key] += nbytes; calls[key] += 1
         except Exception:
@@ -40,6 +41,11 @@ wrap(torch, "zeros", lambda a, k, o: (o.numel() * o.element_size(), True))
 wrap(torch, "zeros_like", lambda a, k, o: (o.numel() * o.element_size(), True))
 wrap(torch, "cat", lambda a, k, o: (o.numel() * o.element_size(), True))
 wrap(T, "new_zeros", lambda a, k, o: (o.numel() * o.element_size(), True))
+wrap(T, "fill_", lambda a, k, o: (o.numel() * o.element_size(), True))
+wrap(torch, "full", lambda a, k, o: (o.numel() * o.element_size(), True))
+wrap(torch, "ones", lambda a, k, o: (o.numel() * o.element_size(), True))
+wrap(T, "new_full", lambda a, k, o: (o.numel() * o.element_size(), True))
+wrap(T, "new_ones", lambda a, k, o: (o.numel() * o.element_size(), True))
 wrap(T, "reshape", lambda a, k, o: (o.numel() * o.element_size(), o.data_ptr() != a[0].data_ptr()))
 
 sys.argv = ["bench.py", "--train", "--steps", "1", "--warmup", "2", "--no-cpu-baseline"]
@@ -49,5 +55,6 @@ def tb(*a, **k):
     return orig_tb(*a, **k)
 bench.main()
 print("MB per 3 steps (2 warm-up + 1 timed), calls, site")
-for k, v in sites.most_common(40):
+order = sites.most_common(40) if MIN_BYTES else sorted(sites.items(), key=lambda kv: -calls[kv[0]])[:70]
+for k, v in order:
     print(f"{v / 1e6:10.1f} MB {calls[k]:5d}  {k}")
