@@ -329,7 +329,9 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
     # 27.3 ms per step against 26.2 eager — hipGraphLaunch of the ~1500-node graph costs the host 22.6 ms (18.2 for the eager
     # Python loop) and the device-side launch-to-launch latency of the ~600 tiny kernels does not drop.  Not the default.
     want_graph = args.train_graph and world == 1 and not args.train_profile and not args.train_host_profile
-    opt = torch.optim.AdamW(params, lr=1e-3, capturable=want_graph)
+    # torch's fused multi-tensor AdamW (one launch chain for all parameters; PDM_BENCH_ADAMW=foreach for the per-operation form:
+    # same update, 21.8 instead of 21.7 ms per step and 1 ms more host time)
+    opt = torch.optim.AdamW(params, lr=1e-3, capturable=want_graph, fused=os.environ.get("PDM_BENCH_ADAMW", "fused") == "fused" or None)
     gt_boxes = synthetic_gt_boxes(B, 12, 99 + rank, device)
     backbone = model.backbone_3d
 
