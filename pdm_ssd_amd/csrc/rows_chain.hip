@@ -83,6 +83,38 @@ __device__ __forceinline__ void rc_stash(const f4 (&r)[4], f4 *buf, int nmb, int
         if (i < nmb) buf[i * 256 + t] = r[i];
 }
 
+#ifndef RC_GLDS
+#define RC_GLDS 0   // 1: the weight chunks go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write, 20 VGPRs
+                    // fewer; hipcc places the four pieces at the chunk's start and one vmcnt(0) in front of its barrier, no wait in
+                    // front of the fragment reads).  Same results, measured SLOWER at a settled clock: point head 0.813 / 0.816 ->
+                    // 0.828 / 0.826 ms, heat-map cells chain 0.272 -> 0.287 ms (tools/diag/rows_chain_rate.py): the vmcnt(0) at every
+                    // chunk barrier also drains the next tile's row prefetch, and a piece costs more issue time beside 16 ds_reads
+                    // and 64 MFMAs than a global_load + ds_write pair.  Kept as a switch; the register-staged stream is the product.
+#endif
+#if RC_GLDS
+typedef __attribute__((address_space(3))) void *rc_lds_vp;
+// one 1 KB piece: lane l's 16 bytes from src_lane land at dst_wave + 16 l (dst_wave is wave-uniform)
+__device__ __forceinline__ void rc_glds(const f4 *src_lane, f4 *dst_wave) {
+    __builtin_amdgcn_global_load_lds((gf4c)src_lane, (rc_lds_vp)(uintptr_t)(unsigned)(uintptr_t)dst_wave, 16, 0, 0);
+}
+__device__ __forceinline__ void rc_fetch_lds(f4 *dst, const f4 *__restrict__ w, int nkb, int mb0, int kb0, int nmb, int t, int nkg = 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nmb && (nkg == 4 || (t >> 6) < nkg)) rc_glds(w + ((size_t)(mb0 + i) * nkb + kb0) * 64 + t, dst + i * 256 + (t & ~63));
+}
+__device__ __forceinline__ void rc_fetch_k16_lds(f4 *dst, const f4 *__restrict__ w, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rc_glds(w + (size_t)((t >> 6) * 4 + i) * 64 + (t & 63), dst + i * 256 + (t & ~63));
+}
+#define RC_FETCH(r, dst, ...) rc_fetch_lds(dst, __VA_ARGS__)
+#define RC_FETCH_K16(r, dst, w, t) rc_fetch_k16_lds(dst, w, t)
+#define RC_STASH(r, dst, n, t) ((void)0)      /* the pieces are on their way; the barrier behind this point waits for them */
+#else
+#define RC_FETCH(r, dst, ...) rc_fetch(r, __VA_ARGS__)
+#define RC_FETCH_K16(r, dst, w, t) rc_fetch_k16(r, w, t)
+#define RC_STASH(r, dst, n, t) rc_stash(r, dst, n, t)
+#endif
+
 // One layer: in[NKB] -> acc[NMB] (bias added, floored).  `p` = which LDS buffer holds this layer's first chunk.
 // next_*: the first chunk of the following layer (prefetched behind this layer's last chunk), next_w == nullptr: none.
 // an[]: the A fragments of the NEXT k-block, read from LDS one k-block ahead of the MFMAs that use them (on entry: k-block
@@ -104,7 +136,7 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
         int fn = 0;
         if (!(RC_DIAG & 2) && next_w) {
             fn = next_nmb < 4 ? next_nmb : 4;
-            rc_fetch(r, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
+            RC_FETCH(r, lds + (p ^ 1) * RC_CHUNK_F4, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
         }
         const f4 *buf = lds + p * RC_CHUNK_F4 + lane, *nbuf = lds + (p ^ 1) * RC_CHUNK_F4 + lane;
 #pragma unroll
@@ -116,7 +148,7 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
 #pragma unroll
                 for (int i = 0; i < 4; ++i) an[i] = buf[(i * 4 + kbi + 1) * 64];
             } else {
-                if (fn) rc_stash(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
+                if (fn) RC_STASH(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
 #if !(RC_DIAG & 1)
                 __syncthreads();
 #endif
@@ -146,13 +178,13 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
         } else if (c + 1 < NCH) {
             const int nm0 = ((c + 1) / KG) * 4, nk0 = ((c + 1) % KG) * 4;
             fn = NMB - nm0 < 4 ? NMB - nm0 : 4;
-            rc_fetch(r, w, NKB, nm0, nk0, fn, t, NKB - nk0 < 4 ? NKB - nk0 : 4);
+            RC_FETCH(r, lds + (p ^ 1) * RC_CHUNK_F4, w, NKB, nm0, nk0, fn, t, NKB - nk0 < 4 ? NKB - nk0 : 4);
         } else if (next_w && next_nkb < 0) {
             fn = 4;
-            rc_fetch_k16(r, next_w, t);
+            RC_FETCH_K16(r, lds + (p ^ 1) * RC_CHUNK_F4, next_w, t);
         } else if (next_w) {
             fn = next_nmb < 4 ? next_nmb : 4;
-            rc_fetch(r, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
+            RC_FETCH(r, lds + (p ^ 1) * RC_CHUNK_F4, next_w, next_nkb, 0, 0, fn, t, next_nkb < 4 ? next_nkb : 4);
         }
         // this chunk: nkg k-blocks x nmb output blocks
         const f4 *buf = lds + p * RC_CHUNK_F4 + lane, *nbuf = lds + (p ^ 1) * RC_CHUNK_F4 + lane;
@@ -167,7 +199,7 @@ __device__ __forceinline__ void rc_layer(const f4 (&in)[NKB], f4 (&acc)[NMB], co
                 for (int i = 0; i < 4; ++i)
                     if (i < nmb) an[i] = buf[(i * 4 + kbi + 1) * 64];
             } else {
-                if (fn) rc_stash(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
+                if (fn) RC_STASH(r, lds + (p ^ 1) * RC_CHUNK_F4, fn, t);
 #if !(RC_DIAG & 1)
                 __syncthreads();
 #endif
@@ -233,8 +265,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     // first chunk of layer 1 for the first tile; every later tile finds it prefetched behind the last chunk of the
     // tile before (the weights are the same for every tile), so the stream of chunks never stops at a tile boundary
     int p = 0;
-    rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
-    rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
+    RC_FETCH(r, lds, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
+    RC_STASH(r, lds, NK1 < 4 ? NK1 : 4, t);
     __syncthreads();
     f4 an[4];
     rc_first_fragments(an, lds, 0, lane);
@@ -507,11 +539,11 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
     // last chunk of the tile before.  The z rows of a tile are requested one tile ahead (see the loop).
     int p = 0;
     if constexpr (NK0 > 0) {
-        rc_fetch(r, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t, NK0 < 4 ? NK0 : 4);
-        rc_stash(r, lds, NK1 < 4 ? NK1 : 4, t);
+        RC_FETCH(r, lds, w1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t, NK0 < 4 ? NK0 : 4);
+        RC_STASH(r, lds, NK1 < 4 ? NK1 : 4, t);
     } else {
-        rc_fetch(r, w2, NK1, 0, 0, NK2 < 4 ? NK2 : 4, t, NK1 < 4 ? NK1 : 4);
-        rc_stash(r, lds, NK2 < 4 ? NK2 : 4, t);
+        RC_FETCH(r, lds, w2, NK1, 0, 0, NK2 < 4 ? NK2 : 4, t, NK1 < 4 ? NK1 : 4);
+        RC_STASH(r, lds, NK2 < 4 ? NK2 : 4, t);
     }
     __syncthreads();
     f4 an[4];
