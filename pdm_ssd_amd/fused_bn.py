@@ -41,6 +41,12 @@ def _layout(x):
     return None
 
 
+def _same_strides(a, b):
+    """Same memory layout: equal strides on every dimension longer than one (the stride of a length-1 dimension is free — the
+    (B, C, N, 1) gradients of the FP stacks arrive with 1 where the activation has C, which cost a 243 MB copy per step)."""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
 class _BnRelu(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -78,7 +84,7 @@ class _BnRelu(Function):
         x, coef = ctx.saved_tensors
         dtype, layout, n, C, L, relu, parts = ctx.meta
         want = torch.bfloat16 if dtype == 2 else x.dtype
-        if dy.dtype != want or dy.stride() != x.stride():
+        if dy.dtype != want or not _same_strides(dy, x):
             dy = torch.empty_like(x, dtype=want).copy_(dy)       # the operator's gradient type, x's memory format
         grads = torch.empty((4, C), dtype=torch.float32, device=x.device)
         partial = torch.empty((parts, C, 2), dtype=torch.float32, device=x.device)
