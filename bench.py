@@ -500,7 +500,7 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
         "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
         "config": {"workload": f"configs[3]: PDM-SSD train step (PointNet2MSG + PDM neck + hybrid head losses), bs={B}/GPU x {N} "
-                               "pts, 12 synthetic boxes per cloud, AdamW, DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
+                               "pts, 12 synthetic boxes per cloud, AdamW (torch fused multi-tensor), DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
                    "global_batch": world * B, "launch": launch,
                    "overlap": "none" if args.serial else "FPS chain of the next batch on a side stream"},
         "final_loss": float(loss.detach())}
