@@ -235,6 +235,44 @@ def reference_op_section(backbone, points, B, iters=5):
         ms, how = e0.elapsed_time(e1) / reps, "hipGraph replay of the whole sequence (device time incl. the 27 launch boundaries)"
     except Exception as e:
         print(f"[bench] API-exact sequence: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+    # The four SA levels are independent of each other once the sampled sets exist (the reference's coordinate chain): the same 26
+    # calls as four chains — one per level: its grid build, two searches, four copies — on four streams inside one hipGraph, fork and
+    # join only (no edge between chains).  Reported BESIDE the one-stream figure, not instead of it.
+    conc = None
+    try:
+        cur = torch.cuda.current_stream()
+        per = int(os.environ.get("PDM_BENCH_CHAIN", "2"))       # plan entries per chain: 2 = one chain per level, 1 = per (level, scale)
+        streams = [torch.cuda.Stream() for _ in range(len(plan) // per)]
+        def by_level():
+            for li, st in enumerate(streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    with pu.shared_search_grids():
+                        for radius, ns, x, nx, f, xt in plan[per * li:per * li + per]:
+                            idx = pu.ball_query(radius, ns, x, nx)
+                            pu.grouping_operation(xt, idx)
+                            pu.grouping_operation(f, idx)
+            for st in streams:
+                cur.wait_stream(st)
+        by_level()
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            cur = torch.cuda.current_stream()
+            by_level()
+        g2.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g2.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / 20
+        conc = {"ms_per_step": round(cms, 4), "GBps": round(mb / cms, 1), "frac_of_hbm_peak": round(mb / cms / HBM_PEAK_GBS, 4),
+                "timed_as": "hipGraph replay, the four SA levels as four independent chains on four streams (fork / join only)"}
+    except Exception as e:
+        print(f"[bench] API-exact sequence by level: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
     # (Measured and dropped: the same 26 calls with the 8 searches on a second stream, every group_points call behind the event of
     #  its own ball_query, replayed as one graph: 0.503 ms against 0.481 on one stream — the cross-branch edges cost more than the
     #  overlap of the latency-bound searches with the copies returns.)
@@ -260,6 +298,7 @@ def reference_op_section(backbone, points, B, iters=5):
             "alg_MB_per_step": round(mb, 2),
             "GBps": round(mb / ms, 1), "frac_of_hbm_peak": round(mb / ms / HBM_PEAK_GBS, 4),
             "frac_of_hbm_peak_sum_of_event_pairs": round(mb / ms_events / HBM_PEAK_GBS, 4),
+            "levels_concurrent": conc,
             "floor": {"ms": round(floor_ms, 4), "frac_of_hbm_peak": round(mb / floor_ms / HBM_PEAK_GBS, 4),
                       "how": f"{mb:.0f} MB / 6.2 TB/s (MI355X_MICROARCH.md: what plain 256-byte stores and a float4 copy reach) + "
                              f"{launches} launches x 1.5 us (dependent-launch boundary)"},
