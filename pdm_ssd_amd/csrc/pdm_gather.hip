@@ -17,7 +17,7 @@ namespace pdm {
 
 constexpr int PG_TS = 8;         // tile edge in cells
 #ifndef PG_CHUNK_N
-#define PG_CHUNK_N 32
+#define PG_CHUNK_N 16
 #endif
 constexpr int PG_CHUNK = PG_CHUNK_N;     // points staged per pass
 constexpr int PG_THREADS = 256;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(PG_THREADS) void pdm_gather_kernel(
 //     weight changes nothing, so the sums are those of the dense loop, bit for bit;
 //   - the per-cell weight sums are taken by 16 lanes of the wave from the same LDS rows, in the same order.
 #ifndef PG_LIST_N
-#define PG_LIST_N 1024
+#define PG_LIST_N 256
 #endif
 constexpr int PG_LIST = PG_LIST_N;    // list entries sorted in LDS; a longer list (never at the shipped sizes) sorts through global memory
 
@@ -270,13 +270,10 @@ constexpr int PG_LIST = PG_LIST_N;    // list entries sorted in LDS; a longer li
 
 typedef float pg_v2f __attribute__((ext_vector_type(2)));
 
-#ifndef PG_WAVES
-#define PG_WAVES_ATTR
-#else
-#define PG_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PG_WAVES, PG_WAVES)))
-#endif
+// 16-point stages, a 256-entry LDS list and 5 waves per SIMD for C <= 128 (96 VGPRs, 2 spills): five workgroups per CU instead of
+// four, 224 -> 212 us per call on the bench workload (same box, profiles/r03b_pdm_gather_diag.txt); six or more spill heavily.
 template <int CPL>
-__global__ __launch_bounds__(PG_THREADS) PG_WAVES_ATTR void pdm_gather_reg_kernel(
+__global__ __launch_bounds__(PG_THREADS, CPL <= 2 ? 5 : 1) void pdm_gather_reg_kernel(
     int P, int C, int degree, PgGrid g, int ntiles, int cap, int normalize, float eps,
     const float *__restrict__ xyz, const float *__restrict__ feat, const float *__restrict__ sh,
     const float *__restrict__ inv2s2, const int *__restrict__ tile_start_all, const int *__restrict__ tile_pts_all,

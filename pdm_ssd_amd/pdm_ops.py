@@ -202,4 +202,4 @@ def gather_supported(C, D):
     if D == 1 and C <= 256:
         return True
     ncell = 64 * D
-    return (ncell * C + ncell + ncell * 32 + 32 * C + 32 * 20) * 4 + 32 * 12 <= 64 * 1024
+    return (ncell * C + ncell + ncell * 16 + 16 * C + 16 * 20) * 4 + 16 * 12 <= 64 * 1024       # PG_CHUNK = 16 points staged per pass
