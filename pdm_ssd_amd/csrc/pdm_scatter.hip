@@ -209,7 +209,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Backward (gather): dfeat (B,P,C), dsh (B,P,nsh), dinv2s2 (B,P) fully written.
-__global__ __launch_bounds__(PDM_WAVES * 64) void pdm_scatter_grad_kernel(
+// (five waves per SIMD: 96 VGPRs, one spill — the kernel is a latency chain, 442 -> 419 us for the neck's backward; six spill 16)
+__global__ __launch_bounds__(PDM_WAVES * 64, 5) void pdm_scatter_grad_kernel(
     int B, int P, int C, int degree, PdmGrid g, int layout, const float *__restrict__ xyz,
     const float *__restrict__ feat, const float *__restrict__ sh, const float *__restrict__ inv2s2,
     const float *__restrict__ dgrid, const float *__restrict__ dwsum, float *__restrict__ dfeat,
