@@ -38,6 +38,7 @@ from pdm_ssd_amd.detector_config import PDM_SSD_CFG, build_pdm_ssd
 from pdm_ssd_amd.pipeline import PipelinedHotPath, overlapping_stream
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_GUIDE_COPY_GBS = 6290.0  # MI355X_MICROARCH.md: what a float4 device copy reaches — the achievable ceiling quoted beside the peak
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
 VALU_F32_PEAK_TFLOPS = 157.3  # same figure for the packed-fp32 vector pipe (256 CUs x 256 flop/clk x 2.4 GHz)
 NECK_CFG = PDM_SSD_CFG['MAP_TO_BEV']
@@ -318,9 +319,15 @@ def cpu_baseline(model, N, kind, frames=2, threads=None):
     cpu_oracle.build()
     m = copy.deepcopy(model).cpu().eval()
     gen = synthetic.uniform_clouds if kind == "uniform" else synthetic.lidar_like_clouds
-    clouds = gen(frames, N, 4321)
     all_threads = cpu_oracle.max_threads()
-    threads = all_threads if threads is None else threads
+    usable = usable_cpus()
+    if threads is None:
+        # All-cores leg.  The oracle's FPS (the dominant operator on the CPU: 4095 dependent iterations per cloud) is parallel over
+        # CLOUDS only, the other operators over clouds x centres: the sample holds one cloud per usable core (at most 64), so every
+        # core has a cloud to sample; threads beyond the cores this process may use (cgroup quota / affinity) add nothing.
+        threads = max(1, min(all_threads, usable))
+        frames = max(frames, min(threads, 64))
+    clouds = gen(frames, N, 4321)
     cpu_oracle.set_threads(threads)
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
@@ -334,8 +341,27 @@ def cpu_baseline(model, N, kind, frames=2, threads=None):
     cpu_oracle.set_threads(all_threads)
     torch.set_num_threads(all_threads)
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} cloud(s) x {N} pts, same step (oracle C operators with OpenMP + torch-CPU layers), "
+            "host": {"omp_max_threads": all_threads, "usable_cpus": usable, "os_cpu_count": os.cpu_count()},
+            "fps_parallelism": min(frames, threads),
+            "sample": f"{frames} cloud(s) x {N} pts, same step (oracle C operators with OpenMP + torch-CPU layers) on {threads} "
+                      f"thread(s): FPS parallel over clouds ({min(frames, threads)}-way), the other operators over clouds x centres; "
                       f"{dt:.1f} s wall; the reference itself has no CPU path for these operators"}
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota when one is set (a container that sees
+    128 CPUs but owns a 16-CPU share runs 128 OpenMP threads at the speed of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 # ----------------------------------------------------------------------------- training step (configs[3])
@@ -685,7 +711,44 @@ class Bench:
     def run(self):
         """One step: rotate the inputs (the pipeline's stages hold batches i, i+1, ...), then the step."""
         self._advance()
-        self._run()
+        out = self._run()
+        if out is not None:       # eager launch: fresh tensors every step (a graph replay writes self.static_out)
+            self.last_out = out
+
+    OUTPUTS = ("spatial_features", "point_features", "batch_box_preds", "bev_heatmap")
+
+    def outputs(self):
+        """The four result tensors of the LAST run(): the captured step's static outputs under hipGraph replay."""
+        return self.static_out if self.mode == "hipGraph" else self.last_out
+
+    def consumed_batch(self):
+        """The batch the last run() processed (what _advance() put into stage 0)."""
+        return self.batches[(self.step_no - 1) % self.NBATCH]
+
+    def verify(self, steps=2):
+        """Untimed self-check of the object that is timed: `steps` more run() calls (input rotation + the pipelined,
+        possibly graph-replayed step); after each, the step's outputs must equal BIT FOR BIT what the plain serial
+        detector loop returns for the batch that step consumed (backbone -> neck -> dense head -> point head on the
+        current stream: the reference's pcdet/models/detectors/point_rcnn.py:9-11).  Same kernels either way, so any
+        difference is a stale buffer or a missing stream edge.  Returns the `verified` block of the bench line or
+        raises AssertionError."""
+        with torch.no_grad():
+            for s in range(steps):
+                self.run()
+                torch.cuda.synchronize()
+                got = [t.clone() for t in self.outputs()]
+                want = self.step_serial(self.consumed_batch())
+                torch.cuda.synchronize()
+                for name, g, w in zip(self.OUTPUTS, got, want):
+                    assert g.data_ptr() != w.data_ptr(), f"{name}: serial result aliases the step's output"
+                    assert g.shape == w.shape, f"{name}: shape {tuple(g.shape)} vs serial {tuple(w.shape)}"
+                    if not torch.equal(g, w):
+                        bad = int((g != w).sum())
+                        raise AssertionError(f"step {self.step_no} ({self.mode}, depth {self.depth}): {name} differs from the "
+                                             f"serial detector in {bad} of {g.numel()} elements "
+                                             f"(max |diff| {float((g.float() - w.float()).abs().max()):.3e})")
+        return {"vs_serial": "bit-equal", "steps": steps, "outputs": list(self.OUTPUTS),
+                "launch": self.mode, "pipeline_depth": 1 if self.serial else self.depth}
 
     def timed(self, steps, warmup, barrier=lambda: torch.cuda.synchronize()):
         with torch.no_grad():
@@ -843,6 +906,14 @@ def main():
     LAUNCH_MODE[1] = None if bench.hoisting is None else [d["use_pre"] for d in bench.hoisting]
     if not args.serial:
         bench.pipe.check_sampling()   # N > 16384: no cooperating FPS workgroup gave up waiting for a peer
+    # untimed: the timed object (rotation + pipelined step under graph replay) against the serial detector, on every rank
+    try:
+        verified = bench.verify(2)
+    except AssertionError as e:
+        print(f"[bench] rank {rank}: VERIFICATION FAILED: {e}", file=sys.stderr, flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     if rank != 0:
         if world > 1:
@@ -1040,7 +1111,7 @@ def main():
     roofline_hbm = {"bound": "hbm", "kernel": "pdm::group_points_rows_kernel + pdm::group_points_lds_kernel + pdm::group_points_v4_kernel "
                     "(all launches of pdm_group_points, the API-exact operator)",
                     "achieved": round(gp_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gp_gbs / HBM_PEAK_GBS, 4),
-                    "frac_of_measured_copy": round(gp_gbs / copy_gbs, 4),
+                    "frac_of_measured_copy": round(gp_gbs / copy_gbs, 4), "frac_of_guide_copy": round(gp_gbs / HBM_GUIDE_COPY_GBS, 4),
                     "traffic": pmc_traffic(("pdm::group_points_v4_kernel", "pdm::group_points_lds_kernel", "pdm::group_points_rows_kernel")),
                     "launches_per_step": gp["calls_per_step"], "avg_launch_us": round(gp_launch_s * 1e6, 2),
                     "alg_bytes_per_launch": int(gp_launch_bytes)}
@@ -1052,11 +1123,24 @@ def main():
         roofline_pdm = {"bound": "hbm", "kernel": "pdm::pdm_bin_kernel + pdm::pdm_gather_reg_kernel (pdm_gather_bev, the inference "
                         "form of the PDM scatter; atomics form under pdm_neck_forms)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_gbs, 4),
+                        "frac_of_guide_copy": round(gbs / HBM_GUIDE_COPY_GBS, 4),
                         "traffic": pmc_traffic(("pdm::pdm_gather_reg_kernel",), together=("pdm::pdm_bin_kernel",)),
                         "traffic_unit": "HBM bytes per call (PMC): bin kernel + gather kernel",
                         "launches_per_step": o["calls_per_step"], "avg_launch_us": round(o["ms_per_step"] * 1e3 / o["calls_per_step"], 2),
                         "alg_bytes_per_launch": int(o["alg_MB_per_step"] * 1e6 / o["calls_per_step"])}
     refops["frac_of_measured_copy"] = round(refops["GBps"] / copy_gbs, 4)
+    refops["frac_of_guide_copy"] = round(refops["GBps"] / HBM_GUIDE_COPY_GBS, 4)
+    # BASELINE's metric is "frames/sec ...; ball_query HBM GB/s": the target block's figure travels INSIDE `roofline` too (the
+    # driver's parsed record keeps `roofline`, `config` and `cpu_baseline` whole and only the names of the other keys)
+    if roofline is not None:
+        lc = refops.get("levels_concurrent") or {}
+        roofline["hbm_target_block"] = {
+            "what": "north_star target: the API-exact ball_query + group_points calls of PointNet2MSG's four SA levels (8 + 16 launches "
+                    "+ the grid builds a new batch needs) at bs=%d x %d pts, index-exact; bytes = SURVEY D4" % (B, N),
+            "alg_MB": refops["alg_MB_per_step"], "ms": refops["ms_per_step"], "GBps": refops["GBps"],
+            "frac_of_hbm_peak": refops["frac_of_hbm_peak"], "frac_of_guide_copy": refops["frac_of_guide_copy"],
+            "ms_concurrent": lc.get("ms_per_step"), "frac_concurrent": lc.get("frac_of_hbm_peak"),
+            "timed_as": refops["timed_as"], "target": 0.60}
 
     cpu = cpu1 = None
     if not args.no_cpu_baseline:
@@ -1092,6 +1176,7 @@ def main():
                 t = b2.timed(max(10, args.steps), 3)
                 n = max(10, args.steps)
                 extras["lidar_like_clouds"] = {"ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(B * n / t, 1),
+                                               "verified": verify_or_message(b2),
                                                "workload": f"same step, bs={B} x {N} pts, lidar-like clouds (ring structure + ground "
                                                            "plane: 1.2-5.6 distinct neighbours per ball instead of 1)"}
                 del b2
@@ -1106,6 +1191,7 @@ def main():
                     "workload": "configs[4]: 65536 pts/cloud, bs=16, lidar-like, same full forward; level-1 FPS as 3 resumable "
                                 "segments of 4 cooperating workgroups per cloud",
                     "ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(16 * n / t, 1), "launch": b5.mode,
+                    "verified": verify_or_message(b5),
                     "pdm_neck_forms": pdm_atomics_section(model, bd5)}
                 del b5, bd5
                 torch.cuda.empty_cache()
@@ -1118,7 +1204,7 @@ def main():
                 t = b8.timed(n, 3)
                 extras["bs8"] = {"workload": f"configs[1] shape: bs=8 x {N} pts, {args.clouds} clouds, same full forward, depth "
                                              f"{b8.depth}", "ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(8 * n / t, 1),
-                                 "launch": b8.mode}
+                                 "launch": b8.mode, "verified": verify_or_message(b8)}
                 del b8
                 torch.cuda.empty_cache()
     # rebuilt if deleted above: only its attributes are needed for the line
@@ -1142,6 +1228,7 @@ def main():
                                "streams under the feature half of batch i; every step does one full batch of every "
                                "kind of work (pdm_ssd_amd/pipeline.py)"),
                    "ms_per_step_eager_serial": round(serial_ms, 4),
+                   "verified": verified,
                    "sa_first_layer_hoisted": LAUNCH_MODE[1]},
         "roofline": roofline,
         "roofline_fps": roofline_fps,
@@ -1149,6 +1236,7 @@ def main():
         "roofline_hbm": roofline_hbm,
         "roofline_pdm": roofline_pdm,
         "hbm_copy_measured_GBps": round(copy_gbs, 1),
+        "hbm_copy_guide_GBps": HBM_GUIDE_COPY_GBS,
         "traffic_source": pmc_src,
         "mlp_flops": flop_summary,
         "mfma_entry_points": mfma_blocks,
@@ -1167,6 +1255,15 @@ def main():
 
 
 LAUNCH_MODE = [None, None]
+
+
+def verify_or_message(b, steps=2):
+    """`verified` block of an EXTRA configuration: a failure there is reported in its block (the headline's own check
+    exits non-zero instead)."""
+    try:
+        return b.verify(steps)
+    except AssertionError as e:
+        return {"vs_serial": "FAILED", "error": str(e)}
 
 
 def mlp_flops_linear(seq):

@@ -560,11 +560,12 @@ extern "C" int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, i
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n, gamma, beta, eps,
                        momentum, running_mean, running_var, coef, 1);   // the producer's sums are plain sums: pivot 0
     const BnCoef k = coef_of(coef, nullptr, C);
-    const int V = dtype ? 8 : 4;
+    const int V = dtype == 1 ? 8 : 4;     // dtype 2 = fp32 x, bf16 y: four elements per thread like the fp32 form
     const long long nvec = n * C / V;
     const long long ag = (nvec + 255) / 256;
     const dim3 agrid((unsigned)(ag > 16384 ? 16384 : ag));
-    if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, k, relu);
+    if (dtype == 2) hipLaunchKernelGGL((bn_cl_apply_mixed_kernel<0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const bf16_t *)nullptr, y, nvec, C, k, relu);
+    else if (dtype) hipLaunchKernelGGL((bn_cl_apply_kernel<bf16_t, 0>), agrid, dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, (bf16_t *)y, nvec, C, k, relu);
     else hipLaunchKernelGGL((bn_cl_apply_kernel<float, 0>), agrid, dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, (float *)y, nvec, C, k, relu);
     return check_launch("bn_relu_forward_stats");
 }

@@ -100,7 +100,7 @@ class PointHeadTemplate(nn.Module):
         fg_flat = fg.view(-1)
         classes = picked[:, -1].long()
         cls_flat = torch.where(fg_flat, torch.ones_like(classes) if self.num_class == 1 else classes, cls_labels.view(-1))
-        box_labels = part_labels = None
+        box_labels = part_labels = labels_ok = None
         flat_xyz = xyz.reshape(-1, 3)
         if ret_box_labels:
             # (a background point's row is encoded against a box that is not its own — possibly a zero-sized padding
@@ -114,13 +114,17 @@ class PointHeadTemplate(nn.Module):
             # instead of a silently wrong target — found at the trainer's first look at the loss, no read-back per step.
             ok = self.box_coder.class_range_ok(torch.where(fg_flat, classes, torch.ones_like(classes)))
             box_labels = torch.where(ok, box_labels, torch.full_like(box_labels, float('nan')))
+            # (WeightedSmoothL1Loss reads a NaN TARGET as "ignore this element", so the poisoned labels alone would train on
+            #  with a zero box loss: the 0-dim flag travels with the targets and get_box_layer_loss turns the loss itself NaN)
+            labels_ok = ok
         if ret_part_labels:
             local = flat_xyz - picked[:, 0:3]
             c, s = torch.cos(-picked[:, 6]), torch.sin(-picked[:, 6])
             local = torch.stack((local[:, 0] * c - local[:, 1] * s, local[:, 0] * s + local[:, 1] * c, local[:, 2]), dim=-1)
             part = local / picked[:, 3:6] + 0.5
             part_labels = torch.where(fg_flat[:, None], part, torch.zeros_like(part))
-        return {'point_cls_labels': cls_flat, 'point_box_labels': box_labels, 'point_part_labels': part_labels}
+        return {'point_cls_labels': cls_flat, 'point_box_labels': box_labels, 'point_part_labels': part_labels,
+                'point_box_labels_ok': labels_ok}
 
     def _assign_ragged(self, points, gt_boxes, extend_gt_boxes, ret_box_labels, ret_part_labels, set_ignore_flag,
                        use_ball_constraint, central_radius):
@@ -129,6 +133,7 @@ class PointHeadTemplate(nn.Module):
         cls_all = points.new_zeros(points.shape[0]).long()
         box_all = gt_boxes.new_zeros((points.shape[0], 8)) if ret_box_labels else None
         part_all = gt_boxes.new_zeros((points.shape[0], 3)) if ret_part_labels else None
+        ok_all = None
         for k in range(B):
             sel = (points[:, 0] == k).nonzero().view(-1)
             sub = torch.cat((points.new_zeros((sel.numel(), 1)), points[sel, 1:4]), dim=1)
@@ -137,9 +142,11 @@ class PointHeadTemplate(nn.Module):
             cls_all[sel] = t['point_cls_labels']
             if ret_box_labels:
                 box_all[sel] = t['point_box_labels']
+                ok_all = t['point_box_labels_ok'] if ok_all is None else ok_all & t['point_box_labels_ok']
             if ret_part_labels:
                 part_all[sel] = t['point_part_labels']
-        return {'point_cls_labels': cls_all, 'point_box_labels': box_all, 'point_part_labels': part_all}
+        return {'point_cls_labels': cls_all, 'point_box_labels': box_all, 'point_part_labels': part_all,
+                'point_box_labels_ok': ok_all}
 
     # ------------------------------------------------------------------ losses
 
@@ -173,6 +180,9 @@ class PointHeadTemplate(nn.Module):
         else:   # the functional forms take no weights argument
             loss = (self.reg_loss_func(preds, labels, reduction='none') * reg_weights[:, None]).sum()
         loss = loss * _get(_get(self.model_cfg, 'LOSS_CONFIG'), 'LOSS_WEIGHTS')['point_box_weight']
+        ok = self.forward_ret_dict.get('point_box_labels_ok')
+        if ok is not None:   # a foreground class outside the coder's mean-size table (the reference asserts): NaN loss, NaN gradients
+            loss = torch.where(ok, loss, loss.new_full((), float('nan')))
         tb_dict = {} if tb_dict is None else tb_dict
         tb_dict.update({'point_loss_box': loss.detach()})
         return loss, tb_dict

@@ -147,7 +147,11 @@ class _PointnetSAModuleBase(nn.Module):
         for grouper, mlp in zip(self.groupers, self.mlps):
             if CHANNELS_LAST_TRAINING and isinstance(grouper, pointnet2_utils.QueryAndGroup):
                 grouper.channels_last = True   # the grouped tensor is born NHWC (bf16 under autocast): no copies
-                grouper.pad_to_8 = rows_path   # 16-byte rows for the bf16 MFMA layers (zero channels up to a multiple of 8)
+                # 16-byte rows for the bf16 MFMA layers (zero channels up to a multiple of 8) — only for the consumer that
+                # knows about the padding: TrainSequential's training stack.  In eval mode, under no_grad, with a plain
+                # nn.Sequential or avg_pool the torch layers see exactly 3 + C channels.
+                grouper.pad_to_8 = bool(rows_path and self.training and torch.is_grad_enabled()
+                                        and isinstance(mlp, TrainSequential) and self.pool_method == 'max_pool')
             x = grouper(xyz, new_xyz, features)
             if CHANNELS_LAST_TRAINING:
                 x = x.contiguous(memory_format=torch.channels_last)

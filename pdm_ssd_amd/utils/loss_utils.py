@@ -25,6 +25,9 @@ class SigmoidFocalClassificationLoss(nn.Module):
 
     def forward(self, input, target, weights):
         """input / target (B, #anchors, #classes) logits / one-hot, weights (B, #anchors) -> unreduced loss."""
+        if target.dtype != input.dtype:   # mixed dtypes promote, as the reference's arithmetic form does (lerp would raise)
+            dt = torch.promote_types(input.dtype, target.dtype)
+            input, target = input.to(dt), target.to(dt)
         p = torch.sigmoid(input)
         miss = torch.lerp(p, 1.0 - p, target)                   # t (1 - p) + (1 - t) p
         balance = (1.0 - self.alpha) + target * (2.0 * self.alpha - 1.0)

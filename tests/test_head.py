@@ -96,6 +96,15 @@ def test_class_outside_the_coder_table_poisons_the_box_targets(ref, cpu_points_i
           'point_coords': torch.from_numpy(ref['point_coords']), 'gt_boxes': torch.from_numpy(gt)}
     head(bd)
     assert torch.isnan(head.forward_ret_dict['point_box_labels']).all()
+    # ... and the LOSS: WeightedSmoothL1Loss treats a NaN target as "ignore", so the flag must reach the loss itself
+    loss, tb = head.get_loss()
+    assert not torch.isfinite(loss), "a foreground class outside the mean-size table must not train on silently"
+    assert not torch.isfinite(tb['point_loss_box']) and torch.isfinite(tb['point_loss_cls'])
+    # in-range classes: finite as before
+    head2 = make_head(ref, "attr").train()
+    bd2 = dict(bd, gt_boxes=torch.from_numpy(ref['gt_boxes']))
+    head2(bd2)
+    assert bool(head2.forward_ret_dict['point_box_labels_ok']) and torch.isfinite(head2.get_loss()[0])
     # the direct call keeps the reference's assert
     coder = box_coder_utils.PointResidualCoder(code_size=8, use_mean_size=True, mean_size=[[3.9, 1.6, 1.56], [0.8, 0.6, 1.73]])
     with pytest.raises(AssertionError):
@@ -142,6 +151,11 @@ def test_gaussian_targets_and_losses(ref):
     sf = loss_utils.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0)
     got = sf(torch.from_numpy(ref['sfl_x']), torch.from_numpy(ref['sfl_t']), torch.from_numpy(ref['sfl_w']))
     np.testing.assert_allclose(got.numpy(), ref['sfl_out'], rtol=1e-5, atol=1e-7)
+    # mixed dtypes promote as the reference's arithmetic form does (fp32 one-hot targets with bf16 logits)
+    xb = torch.from_numpy(ref['sfl_x']).to(torch.bfloat16)
+    mixed = sf(xb, torch.from_numpy(ref['sfl_t']), torch.from_numpy(ref['sfl_w']))
+    assert mixed.dtype == torch.float32
+    np.testing.assert_allclose(mixed.numpy(), sf(xb.float(), torch.from_numpy(ref['sfl_t']), torch.from_numpy(ref['sfl_w'])).numpy(), rtol=1e-6)
 
 
 def test_heatmap_head_targets_and_loss():

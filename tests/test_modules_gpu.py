@@ -51,6 +51,35 @@ def test_sa_module_msg(dev):
     np.testing.assert_allclose(nf.cpu().numpy(), ref_feat, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", ["eval_grad", "train_nograd", "plain_sequential", "avg_pool"])
+def test_sa_module_under_bf16_autocast_outside_the_training_stack(dev, mode):
+    """The grouped tensor is born with round8(3 + C) channels only for the consumer that knows about the zero padding
+    (TrainSequential's training stack with max-pool).  Eval mode with autograd on, training mode under no_grad, a plain
+    nn.Sequential MLP and avg_pool all hand the torch layers exactly 3 + C channels (1 + 3 = 4 and 96 + 3 = 99 here: neither
+    a multiple of 8) and must run, with the features of the fp32 graph to bf16 accuracy."""
+    torch.manual_seed(0)
+    kw = {'pool_method': 'avg_pool'} if mode == "avg_pool" else {}
+    sa = pm.PointnetSAModuleMSG(npoint=128, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[96, 32, 32], [96, 32, 48]], **kw)
+    randomize_bn(sa, 3)
+    if mode == "plain_sequential":
+        sa.mlps = torch.nn.ModuleList(torch.nn.Sequential(*list(m)) for m in sa.mlps)
+    sa = sa.to(dev)
+    sa.train(mode in ("train_nograd", "plain_sequential", "avg_pool"))
+    cl = synthetic.lidar_like_clouds(2, 1024, 3)
+    xyz = torch.from_numpy(np.ascontiguousarray(cl[:, :, :3])).to(dev)
+    feat = torch.randn(2, 96, 1024, device=dev)
+    ref_mod = copy.deepcopy(sa)
+    sa.use_fused = False                      # (eval + no_grad would take the fused inference kernels: not the case here)
+    ctx = torch.no_grad() if mode == "train_nograd" else torch.enable_grad()
+    with ctx, torch.autocast("cuda", dtype=torch.bfloat16):
+        nx, nf = sa(xyz, feat)
+    assert tuple(nf.shape) == (2, 80, 128) and torch.isfinite(nf.float()).all()
+    ref_mod.use_fused = False
+    with ctx:
+        _, want = ref_mod(xyz, feat)          # the same module in fp32 (same batch statistics in training mode)
+    torch.testing.assert_close(nf.float(), want.float(), rtol=0.05, atol=0.05)
+
+
 def test_fp_module(dev):
     from oracle import cpu_backbone
     torch.manual_seed(1)
