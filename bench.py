@@ -128,7 +128,7 @@ class OpTimer:
             self._orig(name, stream, *args)
             e1.record(s)
             ints = [x for x in args if isinstance(x, (int, float))]
-            if name == "pdm_rows_mlp_fused":   # one entry point, several kernels: keep its shapes apart (fused.rows_tag)
+            if name in ("pdm_rows_mlp_fused", "pdm_rows_mlp_fused_pair"):   # one entry point, several kernels: keep its shapes apart (fused.rows_tag)
                 name = f"{name}[{args[3]} layers, {args[1]} in, {args[0]} rows]"
             self.records.append((name, ints, e0, e1))
 
@@ -1022,6 +1022,7 @@ def main():
                   "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
                   "pdm_fp_mlp_fused_pre": ("pdm::fp_chain_kernel", "pdm::fp_mlp_fused_kernel"),   # FP1-2 chain, FP3-4 tiled
                   "pdm_bev_head_fused": ("pdm::rows_chain_kernel<8, 4, 4, 1, true>",),
+                  "pdm_rows_mlp_fused_pair": ("pdm::rows_chain_pair_kernel",),     # the point head's two stacks in one launch
                   "pdm_rows_mlp_fused": ("pdm::rows_chain_kernel", "pdm::fp_mlp_fused_kernel", "pdm::rows_gemm_kernel<false>")}
 
     def kernels_of(op):

@@ -221,6 +221,17 @@ int pdm_rows_mlp_fused(void *stream, int rows, int cin, const float *in_pm, int 
                        const float *wpack, const float *bias, int relu_last, float *out_pm, int out_stride,
                        int cout);
 
+/* Two per-row MLPs of EQUAL widths (one dims table) over the SAME rows: out_a = MLP_a(in), out_b = MLP_b(in) — the point
+ * head's class and box stacks, one module with two chains on one input
+ * (/root/reference/pcdet/models/dense_heads/point_head_box.py:7-60, forward :85-86).  One launch where an instantiation
+ * exists (128 -> 256 -> 256 -> <= 16 over >= 8192 rows: the rows are read once), otherwise two pdm_rows_mlp_fused calls;
+ * bit-identical outputs either way. */
+int pdm_rows_mlp_fused_pair(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims,
+                            const float *wpack_a, const float *bias_a, const float *wpack_b, const float *bias_b,
+                            int relu_last, float *out_a, int out_stride_a, int cout_a, float *out_b, int out_stride_b,
+                            int cout_b);
+int pdm_tune_fused_pair(int on);   /* 0: always two launches (A/B and tests); returns the previous setting */
+
 /* The same SA scale / FP module with the wide part of the FIRST layer hoisted out of the per-pair (per-fine-
  * point) loop — algebraically identical, fp32 rounding order differs (tests: <= 1e-4 of the oracle):
  *   SA:  W1 [f_nb ; x_nb - c] = z[nb] + W1[:, xyz] (x_nb - c),   z = W1[:, features] f  over the n source points;

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "pdm_stack_vector_pool_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "pdm_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
+    "pdm_rows_mlp_fused_pair": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused_pre": [_i] * 4 + [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_sa_pack": [_i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
@@ -112,6 +113,7 @@ _SIGNATURES = {
     "pdm_tune_group_rows": None,
     "pdm_tune_fused_gemm": None,
     "pdm_tune_fused_chain": None,
+    "pdm_tune_fused_pair": None,
     "pdm_tune_fp_chain_pad_lds": None,
     "pdm_tune_rows_chain_wg_per_cu": None,
     "pdm_tune_rows_chain_xcd": None,

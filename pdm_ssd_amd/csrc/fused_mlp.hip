@@ -1131,7 +1131,11 @@ int rows_gemm_launch(void *stream, int rows, int cin, const float *in_pm, int k0
                      const float *bias, int relu_last, float *out_pm, int out_stride, int cout);   // rows_gemm.hip
 int rows_chain_launch(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims, const float *wpack,
                       const float *bias, int relu_last, float *out_pm, int out_stride, int cout, int *launched);   // rows_chain.hip
+int rows_chain_pair_launch(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims, const float *wpack_a,
+                           const float *bias_a, const float *wpack_b, const float *bias_b, int relu_last, float *out_a, int out_stride_a,
+                           int cout_a, float *out_b, int out_stride_b, int cout_b, int *launched);   // rows_chain.hip
 static int g_fused_chain = 1;       // 0: many-row MLPs go through the general chain kernel instead of rows_chain.hip
+static int g_fused_pair = 1;        // 0: pdm_rows_mlp_fused_pair always runs its two chains as two launches
 int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride, const float *skip_pm,
                     const int *idx, const float *weight, const int *dims, const float *wpack, const float *bias, float *out_pm,
                     int out_stride, int cout, int *launched);
@@ -1219,6 +1223,7 @@ static void allow_lds(const void *fn, size_t bytes) {
 extern "C" int pdm_tune_fused_lds_cap(int bytes) { const int old = g_fused_lds_cap; if (bytes >= 16 * 1024 && bytes <= 160 * 1024) g_fused_lds_cap = bytes; return old; }
 extern "C" int pdm_tune_fused_swz(int on) { const int old = g_fused_swz; g_fused_swz = on != 0; return old; }
 extern "C" int pdm_tune_fused_chain(int on) { const int old = g_fused_chain; g_fused_chain = on != 0; return old; }
+extern "C" int pdm_tune_fused_pair(int on) { const int old = g_fused_pair; g_fused_pair = on != 0; return old; }
 extern "C" int pdm_tune_fused_gemm(int on) { const int old = g_fused_gemm; g_fused_gemm = on != 0; return old; }
 extern "C" int pdm_tune_fused_reg(int on) { const int old = g_fused_reg; g_fused_reg = on != 0; return old; }
 extern "C" int pdm_tune_fused_wg_per_cu(int n) { const int old = g_fused_wg_per_cu; if (n > 0) g_fused_wg_per_cu = n; return old; }
@@ -1467,4 +1472,29 @@ extern "C" int pdm_rows_mlp_fused(void *stream, int rows, int cin, const float *
         return rows_gemm_launch(stream, rows, cin, in_pm, dims[0], dims[1], wpack, bias, relu_last, out_pm, out_stride, cout);
     return fp_fused_launch(stream, 2, relu_last, 1, rows, 1, 0, cin, nullptr, nullptr, 0, in_pm, nullptr, nullptr, nlayers,
                            dims, wpack, bias, out_pm, out_stride, cout);
+}
+
+// Two per-row MLPs of EQUAL widths over the SAME rows (the point head's class and box stacks: one module with two
+// make_fc_layers chains on one input, /root/reference/pcdet/models/dense_heads/point_head_box.py:7-60, :85-86):
+//   out_a[r] = MLP_a(in[r]),  out_b[r] = MLP_b(in[r]);  dims / packing as pdm_rows_mlp_fused, cout_* <= dims[nlayers].
+// One launch where rows_chain.hip has an instantiation (the rows are read once), otherwise two pdm_rows_mlp_fused calls;
+// the results are bit-identical either way.
+extern "C" int pdm_rows_mlp_fused_pair(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims,
+                                       const float *wpack_a, const float *bias_a, const float *wpack_b, const float *bias_b,
+                                       int relu_last, float *out_a, int out_stride_a, int cout_a, float *out_b, int out_stride_b,
+                                       int cout_b) {
+    PDM_REQUIRE(rows >= 0 && cin >= 1, PDM_E_BADARG, "rows_mlp_fused_pair: rows=%d cin=%d", rows, cin);
+    if (g_fused_chain && g_fused_pair && dims && in_pm && wpack_a && bias_a && wpack_b && bias_b && out_a && out_b && out_a != out_b &&
+        nlayers == 3 && cout_a > 0 && cout_b > 0 && cout_a <= dims[nlayers] && cout_b <= dims[nlayers] && cout_a <= out_stride_a &&
+        cout_b <= out_stride_b && out_stride_a % 4 == 0 && out_stride_b % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(out_a) | reinterpret_cast<uintptr_t>(out_b) | reinterpret_cast<uintptr_t>(wpack_a) |
+          reinterpret_cast<uintptr_t>(wpack_b) | reinterpret_cast<uintptr_t>(bias_a) | reinterpret_cast<uintptr_t>(bias_b) |
+          reinterpret_cast<uintptr_t>(in_pm)) & 15) == 0) {
+        int launched = 0;
+        const int rc = rows_chain_pair_launch(stream, rows, cin, in_pm, nlayers, dims, wpack_a, bias_a, wpack_b, bias_b, relu_last, out_a,
+                                              out_stride_a, cout_a, out_b, out_stride_b, cout_b, &launched);
+        if (rc || launched) return rc;
+    }
+    if (int rc = pdm_rows_mlp_fused(stream, rows, cin, in_pm, nlayers, dims, wpack_a, bias_a, relu_last, out_a, out_stride_a, cout_a)) return rc;
+    return pdm_rows_mlp_fused(stream, rows, cin, in_pm, nlayers, dims, wpack_b, bias_b, relu_last, out_b, out_stride_b, cout_b);
 }

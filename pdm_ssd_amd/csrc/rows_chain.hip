@@ -438,6 +438,96 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     }
 }
 
+// ---- two chains over the SAME rows in one launch (the point head's class and box branches) --------------------------------
+// /root/reference/pcdet/models/dense_heads/point_head_box.py:7-60 is one module with two make_fc_layers stacks on one input:
+// here a wave keeps its tile's input fragments in registers, runs branch A's three layers, then branch B's, and the weight
+// chunks of the six layers form ONE continuous stream (A1 A2 A3 B1 B2 B3 A1 ...).  Against two launches of rows_chain_kernel:
+// the rows are read once (268 MB per launch at the bench shape), a workgroup's slow first tile is paid once, one launch
+// boundary less.  Every layer is rc_layer as above, so both outputs are bit-identical to the two-launch form.
+struct RowsChainPairArgs {
+    int rows, in_stride;
+    const float *in;
+    const float *wpack[2], *bias[2];   // branch A, branch B: the same widths (dims), packed as for rows_chain_kernel
+    int woff[3], boff[3];
+    float *out[2];
+    int out_stride[2], cout[2], relu_last;
+};
+
+template <int NK0, int NK1, int NK2, int NK3>
+__global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_pair_kernel(RowsChainPairArgs a) {
+    static_assert(NK1 > 0 && NK2 > 0 && NK3 > 0, "rows_chain_pair: three layers");
+    __shared__ __attribute__((aligned(16))) f4 lds[2 * RC_CHUNK_F4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int pos = lane & 15, g = lane >> 4;
+    const f4 *wa1 = reinterpret_cast<const f4 *>(a.wpack[0] + a.woff[0]), *wa2 = reinterpret_cast<const f4 *>(a.wpack[0] + a.woff[1]),
+             *wa3 = reinterpret_cast<const f4 *>(a.wpack[0] + a.woff[2]);
+    const f4 *wb1 = reinterpret_cast<const f4 *>(a.wpack[1] + a.woff[0]), *wb2 = reinterpret_cast<const f4 *>(a.wpack[1] + a.woff[1]),
+             *wb3 = reinterpret_cast<const f4 *>(a.wpack[1] + a.woff[2]);
+    const float neg_inf = -__builtin_inff();
+    const float last_floor = a.relu_last ? 0.0f : neg_inf;
+    f4 r[4];
+    const long long ntiles = ((long long)a.rows + 63) / 64;
+    int p = 0;
+    RC_FETCH(r, lds, wa1, NK0, 0, 0, NK1 < 4 ? NK1 : 4, t);
+    RC_STASH(r, lds, NK1 < 4 ? NK1 : 4, t);
+    __syncthreads();
+    f4 an[4];
+    rc_first_fragments(an, lds, 0, lane);
+    f4 xn[NK0];
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        // (weight pointers through an empty asm: see rows_chain_kernel)
+        asm volatile("" : "+s"(wa1), "+s"(wa2), "+s"(wa3), "+s"(wb1), "+s"(wb2), "+s"(wb3));
+        long long row = tl * 64 + 16 * wave + pos;
+        const bool live = row < a.rows;
+        if (!live) row = a.rows - 1;
+        f4 x0[NK0];
+        if (tl != (long long)blockIdx.x) {
+#pragma unroll
+            for (int kb = 0; kb < NK0; ++kb) x0[kb] = xn[kb];   // requested under the previous tile's branch B
+        } else {
+            const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
+        }
+        auto store = [&](int br, auto &y) {
+            if (!live) return;
+            float *__restrict__ orow = a.out[br] + (size_t)row * a.out_stride[br];
+            const int cout = a.cout[br];
+#pragma unroll
+            for (int mb = 0; mb < NK3; ++mb) {
+                const int c0 = 16 * mb + 4 * g;
+                if (c0 + 4 <= cout) *reinterpret_cast<f4 *>(orow + c0) = y[mb];
+                else {
+                    if (c0 < cout) orow[c0] = y[mb].x;
+                    if (c0 + 1 < cout) orow[c0 + 1] = y[mb].y;
+                    if (c0 + 2 < cout) orow[c0 + 2] = y[mb].z;
+                }
+            }
+        };
+        {   // branch A (x0 stays live for branch B: it takes the place the next tile's rows hold in rows_chain_kernel)
+            f4 x1[NK1], x2[NK2], x3[NK3];
+            rc_layer<NK0, NK1>(x0, x1, wa1, a.bias[0] + a.boff[0], lds, p, 0.0f, wa2, NK1, NK2, t, lane, r, an);
+            rc_layer<NK1, NK2>(x1, x2, wa2, a.bias[0] + a.boff[1], lds, p, 0.0f, wa3, rc_next_nkb(NK2, NK3), NK3, t, lane, r, an);
+            rc_layer<NK2, NK3>(x2, x3, wa3, a.bias[0] + a.boff[2], lds, p, last_floor, wb1, NK0, NK1, t, lane, r, an);
+            store(0, x3);
+        }
+        {   // branch B
+            f4 x1[NK1], x2[NK2], x3[NK3];
+            rc_layer<NK0, NK1>(x0, x1, wb1, a.bias[1] + a.boff[0], lds, p, 0.0f, wb2, NK1, NK2, t, lane, r, an);
+            {   // the next tile's input rows: in flight under this branch's second (largest) layer
+                long long nrow = (tl + gridDim.x) * 64 + 16 * wave + pos;
+                if (nrow >= a.rows) nrow = a.rows - 1;
+                const float *__restrict__ nsrc = a.in + (size_t)nrow * a.in_stride + 4 * g;
+#pragma unroll
+                for (int kb = 0; kb < NK0; ++kb) xn[kb] = *reinterpret_cast<const f4 *>(nsrc + 16 * kb);
+            }
+            rc_layer<NK1, NK2>(x1, x2, wb2, a.bias[1] + a.boff[1], lds, p, 0.0f, wb3, rc_next_nkb(NK2, NK3), NK3, t, lane, r, an);
+            rc_layer<NK2, NK3>(x2, x3, wb3, a.bias[1] + a.boff[2], lds, p, last_floor, wa1, NK0, NK1, t, lane, r, an);
+            store(1, x3);
+        }
+    }
+}
+
 // ---- FP module in the hoisted form, chain in registers ---------------------------------------------------------------
 //   h1[r] = relu(sum_k w_k z[idx_k[r]] + W1s skip[r] + b1),   out[r] = relu(W2 h1[r] + b2)
 // (fused_mlp.hip "pre" form: z = W1[:, known] f was made over the m known points of each cloud.)  Same ownership as
@@ -708,6 +798,34 @@ int rows_chain_launch(void *stream, int rows, int cin, const float *in_pm, int n
     RC_TRY(8, 16, 16, 1)    // point head: 128 -> 256 -> 256 -> <= 16 (class logits, box code)
     RC_TRY(8, 4, 4, 1)      // heat-map head per-cell stack: 128 -> 64 -> 64 -> <= 16
 #undef RC_TRY
+    return 0;
+}
+
+// Two three-layer chains of equal widths over the same rows in one launch.  Returns 1 in *launched when an instantiation fits.
+int rows_chain_pair_launch(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims, const float *wpack_a,
+                           const float *bias_a, const float *wpack_b, const float *bias_b, int relu_last, float *out_a, int out_stride_a,
+                           int cout_a, float *out_b, int out_stride_b, int cout_b, int *launched) {
+    *launched = 0;
+    if (rows < 8192 || cin % 16 != 0 || nlayers != 3 || dims[0] != cin) return 0;
+    RowsChainPairArgs a{};
+    a.rows = rows; a.in_stride = cin; a.in = in_pm;
+    a.wpack[0] = wpack_a; a.bias[0] = bias_a; a.wpack[1] = wpack_b; a.bias[1] = bias_b;
+    int wo = 0, bo = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        a.woff[l] = wo; a.boff[l] = bo;
+        wo += dims[l] * dims[l + 1];
+        bo += dims[l + 1];
+    }
+    a.out[0] = out_a; a.out_stride[0] = out_stride_a; a.cout[0] = cout_a;
+    a.out[1] = out_b; a.out_stride[1] = out_stride_b; a.cout[1] = cout_b;
+    a.relu_last = relu_last;
+    const long long tiles = ((long long)rows + 63) / 64;
+    const int grid = (int)(tiles < 256 * g_rc_wg_per_cu ? tiles : 256 * g_rc_wg_per_cu);
+    if (rc_shape_is(nlayers, dims, 8, 16, 16, 1)) {   // point head: 128 -> 256 -> 256 -> <= 16, class logits and box code
+        hipLaunchKernelGGL((rows_chain_pair_kernel<8, 16, 16, 1>), dim3(grid), dim3(RC_THREADS), 0, as_stream(stream), a);
+        *launched = 1;
+        return check_launch("rows_mlp_fused_pair(chain)");
+    }
     return 0;
 }
 

@@ -87,8 +87,12 @@ class PointHeadBox(PointHeadTemplate):
                 ncls, nbox = self.num_class, self.box_coder.code_size
                 cls = torch.empty((1, rows.shape[1], (ncls + 3) // 4 * 4), dtype=torch.float32, device=rows.device)
                 box = torch.empty((1, rows.shape[1], (nbox + 3) // 4 * 4), dtype=torch.float32, device=rows.device)
-                fused.rows_forward(pc, rows, cls, relu_last=False)
-                fused.rows_forward(pb, rows, box, relu_last=False)
+                if list(pc.dims) == list(pb.dims) and getattr(self, 'use_pair', True):
+                    # one launch for both stacks (the rows are read once); bit-identical to the two calls below
+                    fused.rows_forward_pair(pc, pb, rows, cls, box, relu_last=False)
+                else:
+                    fused.rows_forward(pc, rows, cls, relu_last=False)
+                    fused.rows_forward(pb, rows, box, relu_last=False)
                 return cls[0, :, :ncls], box[0, :, :nbox]
         return self.cls_layers(point_features), self.box_layers(point_features)
 

@@ -229,6 +229,21 @@ def rows_forward(pk, in_pm, out_pm, relu_last=True):
                  out_pm.shape[-1], pk.cout)
 
 
+def rows_forward_pair(pk_a, pk_b, in_pm, out_a, out_b, relu_last=True):
+    """Two per-row MLPs of equal widths over the same rows (the point head's class and box stacks): one launch where
+    rows_chain.hip has an instantiation, two otherwise — bit-identical to two rows_forward calls either way."""
+    cin = in_pm.shape[-1]
+    rows = in_pm.numel() // cin
+    assert pk_a.cin == cin == pk_b.cin and in_pm.is_contiguous() and out_a.is_contiguous() and out_b.is_contiguous()
+    assert pk_a.nlayers == pk_b.nlayers and list(pk_a.dims) == list(pk_b.dims), "rows_forward_pair: the two stacks must have equal (padded) widths"
+    tag = f"pdm_rows_mlp_fused_pair[{pk_a.nlayers} layers, {cin} in, {rows} rows]"    # bench.py's OpTimer forms the same name
+    _count(tag, rows, pk_a)
+    _count(tag, rows, pk_b)
+    _native.call("pdm_rows_mlp_fused_pair", _stream(in_pm), rows, cin, in_pm.data_ptr(), pk_a.nlayers, pk_a.dims_ptr,
+                 pk_a.wpack.data_ptr(), pk_a.bias.data_ptr(), pk_b.wpack.data_ptr(), pk_b.bias.data_ptr(), 1 if relu_last else 0,
+                 out_a.data_ptr(), out_a.shape[-1], pk_a.cout, out_b.data_ptr(), out_b.shape[-1], pk_b.cout)
+
+
 def sa_scale_forward_pre(pk, xyz, new_xyz, z, z_coff, idx, out_pm, out_coff):
     """SA scale whose first layer's feature part was applied to the source points: z (B,N,width)."""
     B, N, _ = xyz.shape

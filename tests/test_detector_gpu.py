@@ -87,6 +87,51 @@ def test_point_head_fused_inference_equals_torch_layers(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [8192, 8192 + 37, 3 * 16384 + 1])
+def test_point_head_one_launch_equals_two_launches(dev, n):
+    """The class and box stacks of the point head as ONE launch (pdm_rows_mlp_fused_pair: a wave keeps its 16 rows' input
+    fragments and runs both chains, six layers of one continuous weight stream) against the two-launch form: the same
+    per-layer arithmetic, so logits, box codes, decoded boxes and scores are BIT-identical — ragged last tile and several
+    tiles per workgroup included."""
+    from pdm_ssd_amd import _native
+    torch.manual_seed(3)
+    head = build_pdm_ssd().point_head.to(dev).eval()
+    for m in head.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    bd = {'batch_size': 1, 'point_features': torch.randn(n, 128, device=dev),
+          'point_coords': torch.cat([torch.zeros(n, 1, device=dev), torch.rand(n, 3, device=dev) * 40], dim=1)}
+    calls = []
+    orig = _native.call
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    _native.call = spy
+    cap = _native.lib().pdm_tune_rows_chain_wg_per_cu(1 if n > 16384 else 12)   # 256 workgroups for 769 tiles: several tiles each
+    try:
+        with torch.no_grad():
+            one = head(dict(bd))
+            first = list(calls); calls.clear()
+            head.use_pair = False
+            two = head(dict(bd))
+            second = list(calls); calls.clear()
+            old = _native.lib().pdm_tune_fused_pair(0)          # the entry point's own two-launch route
+            head.use_pair = True
+            three = head(dict(bd))
+            _native.lib().pdm_tune_fused_pair(old)
+    finally:
+        _native.call = orig
+        _native.lib().pdm_tune_rows_chain_wg_per_cu(cap)
+    assert first.count("pdm_rows_mlp_fused_pair") == 1 and first.count("pdm_rows_mlp_fused") == 0
+    assert second.count("pdm_rows_mlp_fused") == 2 and second.count("pdm_rows_mlp_fused_pair") == 0
+    for k in ('batch_cls_preds', 'batch_box_preds', 'point_cls_scores'):
+        assert torch.isfinite(one[k]).all()
+        assert torch.equal(one[k], two[k]), k
+        assert torch.equal(one[k], three[k]), k
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_detector_training_contract_and_backward(dev):
     torch.manual_seed(1)
     model = build_pdm_ssd(SMALL).to(dev).train()
