@@ -506,7 +506,12 @@ int pdm_tune_fused_reg(int on);         /* register-resident SA form for small s
 int pdm_tune_fused_gemm(int on);        /* LDS-tiled GEMM for single-layer rows / two-layer FP with tiny skip */
 int pdm_tune_fused_chain(int on);       /* register-resident chain kernels (rows_chain.hip) for many-row MLPs and FP modules 1-2 */
 int pdm_tune_fused_swz(int on);         /* XOR-swizzled LDS tiles in the general chain kernels */
-int pdm_tune_bq_quad(int on);           /* four centres per wave in the grid ball query */
+int pdm_tune_bq_quad(int form);         /* grid ball query: 1 four centres per wave (default), 2 one centre per lane, 3 per cloud by density (lane form for sparse, quad form for dense clouds), 0 one wave per centre; same indices */
+int pdm_tune_bq_dense_ppc(int hundredths); /* form 3: points per occupied grid cell (x 100) from which a cloud counts as dense (default 300) */
+int pdm_tune_grid_split(int min_n);     /* search-grid build: clouds of >= min_n points scatter from many workgroups (default 0 = never: measured slower) */
+int pdm_tune_bq_small_waves(int w);     /* exhaustive ball query with <= 32768 centres in the call: waves per workgroup, 4 or 16 (default) */
+int pdm_tune_bq_cpw(int centres);       /* lane form: centres per wave, 16 (default) / 32 / 64 */
+int pdm_tune_bq_heavy(int candidates);  /* lane form: centres with more candidates than this take the whole-wave path (default 96) */
 int pdm_tune_group_rows(int packed);    /* group_points LDS form: 0 heuristics; variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel in plain unit order) | rows per workgroup << 4 | parts of L << 8 | threads / 256 << 16 | index quads per lane and pass << 20 */
 int pdm_tune_rows_chain_wg_per_cu(int n); /* grid cap of the many-row chain kernels = 256 CUs x n workgroups (default 12; 2 resident) */
 int pdm_tune_rows_chain_xcd(int on);   /* heat-map chain kernel: contiguous patch range per XCD (default) / launch order */

@@ -110,6 +110,11 @@ _SIGNATURES = {
     "pdm_tune_fused_lds_cap": None,
     "pdm_tune_fused_reg": None,
     "pdm_tune_bq_quad": None,
+    "pdm_tune_bq_heavy": None,
+    "pdm_tune_bq_cpw": None,
+    "pdm_tune_bq_small_waves": None,
+    "pdm_tune_bq_dense_ppc": None,
+    "pdm_tune_grid_split": None,
     "pdm_tune_group_rows": None,
     "pdm_tune_fused_gemm": None,
     "pdm_tune_fused_chain": None,

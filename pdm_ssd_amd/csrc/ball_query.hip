@@ -23,15 +23,17 @@ constexpr int BQ_TILE = 2048;  // points per LDS tile (24 KB)
 // chain of ~150 cycles per step and centre), so four centres per wave quadruple that chain; with few centres in the
 // call (the deeper SA levels: 32 x 256 and 32 x 64) one centre per wave gives four times the waves and a quarter of the
 // chain: 13.7 -> measured in profiles/r03_api_ops_device.txt.  Many centres: four per wave share each staged point.
-template <int BQ_CPW>
-__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
+// NW = waves per workgroup: every workgroup stages every tile of its cloud, so with few centres per cloud (SA3: 256 centres
+// over 1024 points) 4-wave workgroups read the cloud 64 times over; 16 waves share one staging.
+template <int BQ_CPW, int NW = BQ_WAVES>
+__global__ __launch_bounds__(NW * 64) void ball_query_wave_kernel(
     int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
     const float *__restrict__ xyz, int *__restrict__ idx) {
     __shared__ float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int j0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW;  // first centre of this wave
+    const int j0 = (blockIdx.x * NW + wave) * BQ_CPW;  // first centre of this wave
     const float *__restrict__ pts = xyz + (size_t)b * n * 3;
     const unsigned long long below = (1ull << lane) - 1ull;
 
@@ -55,15 +57,16 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
             // chain of up to 24 dependent round trips for a tile: most of the 8 us this kernel took on a 1024-point cloud)
             const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(pts + (size_t)base * 3);
             const int nq = tile * 3 / 4;            // tile % 4 == 0 here (n % 4 == 0, BQ_TILE % 4 == 0)
-            float4 v[6];
+            constexpr int NU = (BQ_TILE * 3 / 4 + NW * 64 - 1) / (NW * 64);
+            float4 v[NU];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int q = threadIdx.x + u * BQ_WAVES * 64;
+            for (int u = 0; u < NU; ++u) {
+                const int q = threadIdx.x + u * NW * 64;
                 if (q < nq) v[u] = p4[q];
             }
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int q = threadIdx.x + u * BQ_WAVES * 64;
+            for (int u = 0; u < NU; ++u) {
+                const int q = threadIdx.x + u * NW * 64;
                 if (q < nq) {
                     const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
                 }
             }
         } else {
-            for (int i = threadIdx.x; i < tile * 3; i += BQ_WAVES * 64) {
+            for (int i = threadIdx.x; i < tile * 3; i += NW * 64) {
                 const float v = pts[(size_t)base * 3 + i];
                 const int pnt = i / 3, comp = i - pnt * 3;
                 (comp == 0 ? sx : comp == 1 ? sy : sz)[pnt] = v;
@@ -143,6 +146,9 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_wave_kernel(
 
 using namespace pdm;
 
+static int g_bq_small_waves = 16;   // exhaustive scan with few centres: waves per workgroup (4 or 16)
+extern "C" int pdm_tune_bq_small_waves(int w) { const int old = g_bq_small_waves; if (w == 4 || w == 16) g_bq_small_waves = w; return old; }
+
 extern "C" int pdm_ball_query(void *stream, int b, int n, int m, float radius, int nsample,
                               const float *new_xyz, const float *xyz, int *idx) {
     PDM_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, PDM_E_BADARG,
@@ -151,7 +157,11 @@ extern "C" int pdm_ball_query(void *stream, int b, int n, int m, float radius, i
     PDM_REQUIRE(new_xyz && xyz && idx, PDM_E_BADARG, "ball_query: null pointer");
     PDM_REQUIRE(b <= 65535, PDM_E_TOOLARGE, "ball_query: b=%d exceeds grid", b);
     const float radius2 = radius * radius;  // ball_query_gpu.cu:29 (fp32 product)
-    if ((long long)b * m <= 32768) {
+    if ((long long)b * m <= 32768 && g_bq_small_waves == 16 && m >= 64) {
+        dim3 grid(divup(m, 16), b);
+        hipLaunchKernelGGL((ball_query_wave_kernel<1, 16>), grid, dim3(16 * 64), 0, as_stream(stream), n,
+                           m, radius2, nsample, new_xyz, xyz, idx);
+    } else if ((long long)b * m <= 32768) {
         dim3 grid(divup(m, BQ_WAVES), b);
         hipLaunchKernelGGL(ball_query_wave_kernel<1>, grid, dim3(BQ_WAVES * 64), 0, as_stream(stream), n,
                            m, radius2, nsample, new_xyz, xyz, idx);

@@ -26,12 +26,17 @@ __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(
 // pass(es) and the scatter pass re-read nothing (round 2 read the cloud three times through strided 4-byte loads; the
 // build is one workgroup per cloud, i.e. a latency chain, and was 30 us of the 100 us of an SA level's neighbour search).
 constexpr int BQG_PPT = 16;
-template <bool CACHED>
+// SPLIT (round 4): the kernel stops behind the scan and leaves a second copy of the cell starts (`cursor_all`) for
+// bq_grid_scatter_kernel, which places the points from MANY workgroups per cloud: the scatter is 16 stores of 16 bytes
+// per thread to 64 different lines per wave-instruction — 8.5 of the 28 us of a 16384-point build when one compute
+// unit issues all of them (s_memtime phase table, profiles/r04c_grid_build_phase.txt).
+template <bool CACHED, bool SPLIT = false>
 __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float radius, int max_cells,
                                                                     const float *__restrict__ xyz_all,
                                                                     float *__restrict__ hdr_all,
                                                                     int *__restrict__ cell_start_all,
-                                                                    float4 *__restrict__ sorted_all) {
+                                                                    float4 *__restrict__ sorted_all,
+                                                                    int *__restrict__ cursor_all = nullptr, int want_density = 0) {
     __shared__ int hist[BQG_CAP];
     __shared__ float red[6][BQG_BUILD_T / 64];
     __shared__ int wsum[BQG_BUILD_T / 64];
@@ -42,6 +47,12 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
     const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
     int *__restrict__ cell_start = cell_start_all + (size_t)b * (BQG_CAP + 1);
     float4 *__restrict__ sorted = sorted_all + (size_t)b * n;
+#ifdef BQG_DIAG   // phase stamps (shader cycles since the start) in the unused header floats 8..15: tools/diag/grid_build_phase.py
+    const long long t_start = __builtin_amdgcn_s_memtime();
+#define BQG_STAMP(i) do { __syncthreads(); if (tid == 0) hdr_all[(size_t)b * BQG_HDR + 9 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); } while (0)
+#else
+#define BQG_STAMP(i) ((void)0)
+#endif
 
     // ---- bounding box
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -111,6 +122,7 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
     }
     __syncthreads();
     GridHdr H = sh;
+    BQG_STAMP(0);   // loads + bounding box + cell size
 
     // ---- histogram.  Nearest-neighbour mode (radius == 0: the cell size is free): a cell budget of n/2 assumes the
     // points fill their bounding box; a flat scene (LiDAR: a few metres of height over 70 x 80 m) leaves most cells
@@ -171,8 +183,21 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
         H = sh;
         __syncthreads();
     }
+    BQG_STAMP(1);   // histogram
+    // points per OCCUPIED cell -> header float 8: the query kernel picks its form per cloud from it (a handful of candidates per
+    // ball: one centre per lane; dense scenes: four centres per wave with the whole-wave path behind it)
+    if (want_density) {   // (kernel argument: uniform; ~1 us)
+        int ne = 0;
+        for (int c = tid; c < H.ncells; c += BQG_BUILD_T) ne += hist[c] > 0 ? 1 : 0;
+        for (int off = 32; off >= 1; off >>= 1) ne += __shfl_xor(ne, off, 64);
+        if (tid == 0) s_nonempty = 0;
+        __syncthreads();
+        if (lane == 0 && ne) atomicAdd(&s_nonempty, ne);
+        __syncthreads();
+    }
     if (tid == 0) {
         float *hp = hdr_all + (size_t)b * BQG_HDR;
+        hp[8] = want_density ? (float)n / (float)(s_nonempty > 0 ? s_nonempty : 1) : 1e30f;   // not measured: "dense" (the quad form)
         hp[0] = H.minx; hp[1] = H.miny; hp[2] = H.minz; hp[3] = H.inv_h;
         reinterpret_cast<int *>(hp)[4] = H.gx; reinterpret_cast<int *>(hp)[5] = H.gy;
         reinterpret_cast<int *>(hp)[6] = H.gz; reinterpret_cast<int *>(hp)[7] = H.ncells;
@@ -204,11 +229,20 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
     for (int c = c0; c < c1; ++c) {
         const int cnt = hist[c];
         hist[c] = run;
-        cell_start[c] = run;
         run += cnt;
     }
     if (tid == 0) cell_start[H.ncells] = n;
     __syncthreads();
+    // the starts leave through coalesced stores (a thread's own block of cells is `per` words apart from its neighbour's:
+    // written from the loop above, the 14 k cell starts of a KITTI-range cloud took 4 of the scan's 6 us)
+    for (int c = tid; c < H.ncells; c += BQG_BUILD_T) {
+        const int v = hist[c];
+        cell_start[c] = v;
+        if constexpr (SPLIT) cursor_all[(size_t)b * (BQG_CAP + 1) + c] = v;
+    }
+    if constexpr (SPLIT) return;
+    __syncthreads();
+    BQG_STAMP(2);   // scan
 
     // ---- scatter into cell order (order inside a cell is arbitrary; the query does not depend on it)
     if constexpr (CACHED) {
@@ -232,6 +266,43 @@ __global__ __launch_bounds__(BQG_BUILD_T) void bq_grid_build_kernel(int n, float
             const int slot = atomicAdd(&hist[(cz * H.gy + cy) * H.gx + cx], 1);
             sorted[slot] = make_float4(x, y, z, __int_as_float(k));
         }
+    }
+    BQG_STAMP(3);   // scatter issued (stores may still be in flight)
+}
+
+// Scatter half of the split build: (cloud, slab of points) per workgroup, a slot from the cloud's cursor table (device-scope
+// atomic), the point written in cell order.  Order inside a cell is arbitrary, as in the one-kernel build: no query depends on it.
+constexpr int BQG_SC_T = 256, BQG_SC_PPT = 4;
+__global__ __launch_bounds__(BQG_SC_T) void bq_grid_scatter_kernel(int n, const float *__restrict__ xyz_all, const float *__restrict__ hdr_all,
+                                                                   int *__restrict__ cursor_all, float4 *__restrict__ sorted_all) {
+    const int b = blockIdx.y;
+    const float *hp = hdr_all + (size_t)b * BQG_HDR;
+    const float minx = hp[0], miny = hp[1], minz = hp[2], inv_h = hp[3];
+    const int gx = reinterpret_cast<const int *>(hp)[4], gy = reinterpret_cast<const int *>(hp)[5], gz = reinterpret_cast<const int *>(hp)[6];
+    const float *__restrict__ xyz = xyz_all + (size_t)b * n * 3;
+    int *__restrict__ cursor = cursor_all + (size_t)b * (BQG_CAP + 1);
+    float4 *__restrict__ sorted = sorted_all + (size_t)b * n;
+    const int k0 = blockIdx.x * (BQG_SC_T * BQG_SC_PPT) + threadIdx.x;
+    float px[BQG_SC_PPT], py[BQG_SC_PPT], pz[BQG_SC_PPT];
+    int slot[BQG_SC_PPT];
+#pragma unroll
+    for (int i = 0; i < BQG_SC_PPT; ++i) {
+        const int k = k0 + i * BQG_SC_T;
+        px[i] = py[i] = pz[i] = 0.f;
+        if (k < n) { px[i] = xyz[(size_t)k * 3 + 0]; py[i] = xyz[(size_t)k * 3 + 1]; pz[i] = xyz[(size_t)k * 3 + 2]; }
+    }
+#pragma unroll
+    for (int i = 0; i < BQG_SC_PPT; ++i) {
+        slot[i] = 0;
+        if (k0 + i * BQG_SC_T < n) {
+            const int cx = cell_of(px[i], minx, inv_h, gx), cy = cell_of(py[i], miny, inv_h, gy), cz = cell_of(pz[i], minz, inv_h, gz);
+            slot[i] = atomicAdd(&cursor[(cz * gy + cy) * gx + cx], 1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BQG_SC_PPT; ++i) {
+        const int k = k0 + i * BQG_SC_T;
+        if (k < n) sorted[slot[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
     }
 }
 
@@ -396,11 +467,10 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_kernel(
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
 
-__global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query4_kernel(
-    int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
+__device__ __forceinline__ void bq_quad_body(
+    unsigned int *bitmap_all, int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
     const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
     const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
-    extern __shared__ unsigned int bitmap_all[];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -492,16 +562,211 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query4_kernel(
     }
 }
 
+__global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query4_kernel(
+    int n, int m, float radius, int nsample, int wpl, const float *__restrict__ new_xyz,
+    const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+    const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
+    extern __shared__ unsigned int bitmap_all[];
+    bq_quad_body(bitmap_all, n, m, radius, nsample, wpl, new_xyz, hdr_all, cell_start_all, sorted_all, idx);
+}
+
+// One centre per LANE (round 4).  The quad kernel above spends ~400 wave-instructions on four centres (run table,
+// prefix sums, candidate -> run resolution and the by-index ranking as DPP chains) and is bound by instruction issue:
+// 131072 centres of an SA1 call = 13 M wave-instructions = 30 us.  Here a lane owns a centre outright: the <= BQL_ROWS
+// (z, y) rows of its search box are held as (first candidate number, array offset) pairs in registers, the candidates
+// of all rows are numbered consecutively and fetched BQL_U at a time (independent 16-byte loads, all in flight), and
+// the hits go into the lane's own LDS list kept in ascending index order (insertion; a full list only takes a smaller
+// index) — so one pass of instructions serves 64 centres and the answer is still the first `nsample` hits BY INDEX,
+// whatever the visiting order.  A centre with more than `heavy` candidates (dense scenes) is left to the whole-wave
+// path (bq_centre_wave: 64 candidates per step, bitmap) afterwards.  Same indices on every path.
+#ifndef BQL_U_N
+#define BQL_U_N 4
+#endif
+constexpr int BQL_ROWS = 9, BQL_U = BQL_U_N;   // 9 = the 3 x 3 rows of a box that spans three cells per axis (an MSG level's larger radius on the
+                                         // grid sized for its smaller one); more rows than that are walked in batches of 9
+__device__ __forceinline__ void bq_lane_body(
+    unsigned int *bitmap_all, int n, int m, float radius, int nsample, int wpl, int heavy, int cpw, const float *__restrict__ new_xyz,
+    const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+    const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
+    // cpw = centres per wave (16 / 32 / 64: lanes past it only take part in the whole-wave path).  Fewer centres per wave = more
+    // waves for the same centres: the lane phase is a chain of dependent loads, and the heavy centres of a wave are answered one
+    // after the other (dense lidar scenes: 310 us for an SA1 call at 64 per wave against 118 for the quad kernel).
+    // bitmap_all: per wave ONE region of max(wpl * 64, cpw * LS) words that holds the cpw hit lists of LS words during the lane
+    // phase of a group of centres and the whole-wave path's bitmap behind it (cleared when a group has heavy centres): with a
+    // region each, the workgroup took twice the LDS and the quad form sharing the kernel lost residency (693 against 632 us on
+    // lidar-like clouds)
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int LS = nsample | 1;                    // odd stride: slot s of the 64 lanes' lists spreads over the banks
+    const int RW = max(wpl * 64, cpw * LS);
+    unsigned int *bm = bitmap_all + (size_t)wave * RW;
+    int *list = reinterpret_cast<int *>(bm) + (size_t)(lane < cpw ? lane : 0) * LS;
+    const BqGrid G = bq_grid_of(b, n, hdr_all, cell_start_all, sorted_all);
+    const float radius2 = radius * radius;
+    const float absr = fabsf(radius);
+    const int ngroups = (m + cpw - 1) / cpw;
+    const bool vec_out = (nsample & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
+    for (int jg = blockIdx.x * BQG_QWAVES + wave; jg < ngroups; jg += gridDim.x * BQG_QWAVES) {
+        const int j = jg * cpw + lane;
+        const bool live = lane < cpw && j < m;
+        const float *c3 = new_xyz + ((size_t)b * m + (live ? j : m - 1)) * 3;
+        const float cx = c3[0], cy = c3[1], cz = c3[2];
+        const float rx = search_halfwidth(cx, absr), ry = search_halfwidth(cy, absr), rz = search_halfwidth(cz, absr);
+        const int x0 = cell_of(cx - rx, G.minx, G.inv_h, G.gx), x1 = cell_of(cx + rx, G.minx, G.inv_h, G.gx);
+        const int y0 = cell_of(cy - ry, G.miny, G.inv_h, G.gy), y1 = cell_of(cy + ry, G.miny, G.inv_h, G.gy);
+        const int z0 = cell_of(cz - rz, G.minz, G.inv_h, G.gz), z1 = cell_of(cz + rz, G.minz, G.inv_h, G.gz);
+        const int ny = y1 - y0 + 1;
+        const int nrows = live ? ny * (z1 - z0 + 1) : 0;
+        bool slow = false;
+        int c = 0, seen = 0;                             // hits in the list (<= nsample), candidates visited so far
+        for (int r0 = 0; __any(!slow && r0 < nrows); r0 += BQL_ROWS) {
+            const bool on = !slow && r0 < nrows;
+            // run bounds of the batch's rows at once: 2 * BQL_ROWS independent loads
+            int rb[BQL_ROWS], re[BQL_ROWS];
+#pragma unroll
+            for (int r = 0; r < BQL_ROWS; ++r) {
+                rb[r] = 0; re[r] = 0;
+                if (on && r0 + r < nrows) {
+                    const int rr = r0 + r;
+                    const int base = ((z0 + rr / ny) * G.gy + (y0 + rr % ny)) * G.gx;
+                    rb[r] = G.cell_start[base + x0];
+                    re[r] = G.cell_start[base + x1 + 1];
+                }
+            }
+            // candidate numbering: row r holds candidates [pre[r], pre[r + 1]); off[r] = array index of candidate t minus t
+            int pre[BQL_ROWS], off[BQL_ROWS], total = 0;
+#pragma unroll
+            for (int r = 0; r < BQL_ROWS; ++r) {
+                pre[r] = r0 + r < nrows ? total : 0x7FFFFFFF;     // rows past the box never match
+                off[r] = rb[r] - total;
+                total += re[r] - rb[r];
+            }
+            seen += total;
+            if (on && seen > heavy) slow = true;              // too many candidates for a lane: the whole-wave path redoes this centre
+            if (slow || !on) total = 0;
+            for (int t0 = 0; __any(t0 < total); t0 += BQL_U) {
+                float4 q[BQL_U];
+#pragma unroll
+                for (int u = 0; u < BQL_U; ++u) {
+                    const int t = t0 + u;
+                    int o = off[0];
+#pragma unroll
+                    for (int r = 1; r < BQL_ROWS; ++r) o = t >= pre[r] ? off[r] : o;
+                    q[u] = t < total ? G.sorted[o + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < BQL_U; ++u) {
+                    const float d2 = sqdist(cx - q[u].x, cy - q[u].y, cz - q[u].z);
+                    if (t0 + u < total && d2 < radius2) {
+                        const int k = __float_as_int(q[u].w);
+                        int i = -1;
+                        if (c < nsample) i = c++;
+                        else if (k < list[nsample - 1]) i = nsample - 1;
+                        if (i >= 0) {
+                            while (i > 0) {
+                                const int prev = list[i - 1];
+                                if (prev < k) break;
+                                list[i] = prev;
+                                --i;
+                            }
+                            list[i] = k;
+                        }
+                    }
+                }
+            }
+        }
+        if (live && !slow) {
+            // ball_query_gpu.cu:41-45: slots past the hits hold the first hit; an empty ball's row is all zeros
+            int *out = idx + ((size_t)b * m + j) * nsample;
+            const int first = c > 0 ? list[0] : 0;
+            if (vec_out) {
+                for (int s0 = 0; s0 < nsample; s0 += 4) {
+                    int4 v;
+                    v.x = s0 < c ? list[s0] : first; v.y = s0 + 1 < c ? list[s0 + 1] : first;
+                    v.z = s0 + 2 < c ? list[s0 + 2] : first; v.w = s0 + 3 < c ? list[s0 + 3] : first;
+                    *reinterpret_cast<int4 *>(out + s0) = v;
+                }
+            } else {
+                for (int s0 = 0; s0 < nsample; ++s0) out[s0] = s0 < c ? list[s0] : first;
+            }
+        }
+        // heavy centres: whole-wave path, one after the other
+        unsigned long long todo = __ballot(slow);
+        if (todo != 0ull) {      // the lists of this group are written out: the region becomes the (clean) bitmap
+            __builtin_amdgcn_wave_barrier();
+            for (int w = lane; w < wpl * 64; w += 64) bm[w] = 0u;
+            __builtin_amdgcn_wave_barrier();
+        }
+        while (todo != 0ull) {   // wave-uniform
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cx), src));
+            const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), src));
+            const float sz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cz), src));
+            bq_centre_wave(G, sx, sy, sz, radius2, absr, nsample, wpl, bm, idx + ((size_t)b * m + jg * cpw + src) * nsample, lane);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_lane_kernel(
+    int n, int m, float radius, int nsample, int wpl, int heavy, int cpw, const float *__restrict__ new_xyz,
+    const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+    const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
+    extern __shared__ unsigned int bitmap_all[];
+    bq_lane_body(bitmap_all, n, m, radius, nsample, wpl, heavy, cpw, new_xyz, hdr_all, cell_start_all, sorted_all, idx);
+}
+
+// The form is chosen per CLOUD from the density the build left in its header (points per occupied cell): sparse clouds (a handful
+// of candidates per ball: BASELINE's uniform KITTI-range clouds) take the lane form, dense ones (lidar-like: hundreds of
+// candidates in the near field) the quad form — measured on the API-exact block at bs = 32: uniform 473 (quad) / 452 (lane) us,
+// lidar-like 642 (quad) / 713-943 (lane).  The grid is sized for the quad form; surplus workgroups of the lane form leave at once.
+#ifndef BQL_MINWG
+#define BQL_MINWG 7
+#endif
+#if BQL_MINWG
+__global__ __launch_bounds__(BQG_QWAVES * 64, BQL_MINWG) void bq_grid_query_auto_kernel(
+#else
+__global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_auto_kernel(
+#endif
+    int n, int m, float radius, int nsample, int wpl, int heavy, int cpw, float dense_ppc, const float *__restrict__ new_xyz,
+    const float *__restrict__ hdr_all, const int *__restrict__ cell_start_all,
+    const float4 *__restrict__ sorted_all, int *__restrict__ idx) {
+    extern __shared__ unsigned int bitmap_all[];
+    const float ppc = hdr_all[(size_t)blockIdx.y * BQG_HDR + 8];
+    if (ppc >= dense_ppc) bq_quad_body(bitmap_all, n, m, radius, nsample, wpl, new_xyz, hdr_all, cell_start_all, sorted_all, idx);
+    else bq_lane_body(bitmap_all, n, m, radius, nsample, wpl, heavy, cpw, new_xyz, hdr_all, cell_start_all, sorted_all, idx);
+}
+
+// Query form.  1 (default): four centres per wave (round 2's kernel).  2: one centre per lane (round 4).  3: per cloud by the density
+// the build measures (lane for sparse, quad for dense clouds).  0: one wave per centre (round 1).  All return the same indices.
+// Measured on the API-exact block of the bench (8 ball_query + 16 group_points, bs = 32, same process, profiles/r04h_ball_query_forms.txt):
+// uniform KITTI-range clouds quad 462-473 us, lane 456-462, by density 461-477; lidar-like clouds quad 623-634, lane 716-960 (a
+// wave answers its heavy centres one after the other), by density 683-704 (FPS-sampled levels of a dense scene count as sparse by
+// points per cell and still hold dozens of candidates per ball).  2-3 % on the sparse case against 10-50 % on the dense one: the
+// quad form stays the default.
+static int g_bq_quad = 1;
+// clouds of at least this many points (<= 16384) scatter from many workgroups; 0 = never (the default: MEASURED SLOWER — the
+// cursor atomics of 64 lanes land in 64 different lines and run at ~20 G atomics/s chip-wide, so bq_grid_scatter_kernel takes
+// 28 us for 32 x 16384 points where the one-workgroup scatter phase takes 8.5; profiles/r04d_api_block_split_build.txt)
+static int g_grid_split_min_n = 0;
 int launch_grid_build(hipStream_t stream, int b, int n, float radius, int max_cells, const float *xyz,
                       const GridWs &ws) {
     if (max_cells > BQG_CAP) max_cells = BQG_CAP;
     if (max_cells < 1) max_cells = 1;
+    if (g_grid_split_min_n > 0 && n >= g_grid_split_min_n && n <= BQG_PPT * BQG_BUILD_T) {
+        hipLaunchKernelGGL((bq_grid_build_kernel<true, true>), dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
+                           ws.hdr, ws.cell_start, ws.sorted, ws.cursor, g_bq_quad == 3);
+        hipLaunchKernelGGL(bq_grid_scatter_kernel, dim3(divup(n, BQG_SC_T * BQG_SC_PPT), b), dim3(BQG_SC_T), 0, stream, n, xyz, ws.hdr,
+                           ws.cursor, ws.sorted);
+        return check_launch("grid_build(split)");
+    }
+    const int dens = g_bq_quad == 3;
     if (n <= BQG_PPT * BQG_BUILD_T)
         hipLaunchKernelGGL(bq_grid_build_kernel<true>, dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
-                           ws.hdr, ws.cell_start, ws.sorted);
+                           ws.hdr, ws.cell_start, ws.sorted, nullptr, dens);
     else
         hipLaunchKernelGGL(bq_grid_build_kernel<false>, dim3(b), dim3(BQG_BUILD_T), 0, stream, n, radius, max_cells, xyz,
-                           ws.hdr, ws.cell_start, ws.sorted);
+                           ws.hdr, ws.cell_start, ws.sorted, nullptr, dens);
     return check_launch("grid_build");
 }
 
@@ -513,8 +778,15 @@ extern "C" size_t pdm_ball_query_grid_workspace_bytes(int b, int n) {
     return grid_workspace_bytes(b, n);
 }
 
-static int g_bq_quad = 1;   // 0: one wave per centre (round 1's query kernel)
-extern "C" int pdm_tune_bq_quad(int on) { const int old = g_bq_quad; g_bq_quad = on != 0; return old; }
+extern "C" int pdm_tune_bq_quad(int on) { const int old = pdm::g_bq_quad; pdm::g_bq_quad = on < 0 ? 0 : on > 3 ? 3 : on; return old; }
+using pdm::g_bq_quad;
+static float g_bq_dense_ppc = 3.0f;   // form 3: points per occupied cell from which a cloud counts as dense
+extern "C" int pdm_tune_bq_dense_ppc(int hundredths) { const int old = (int)(g_bq_dense_ppc * 100.0f + 0.5f); if (hundredths >= 0) g_bq_dense_ppc = hundredths / 100.0f; return old; }
+extern "C" int pdm_tune_grid_split(int min_n) { const int old = pdm::g_grid_split_min_n; pdm::g_grid_split_min_n = min_n; return old; }
+static int g_bq_cpw = 16;    // lane form: centres per wave (16, 32 or 64)
+extern "C" int pdm_tune_bq_cpw(int v) { const int old = g_bq_cpw; if (v == 16 || v == 32 || v == 64) g_bq_cpw = v; return old; }
+static int g_bq_heavy = 96;  // lane form: a centre with more candidates than this goes to the whole-wave path
+extern "C" int pdm_tune_bq_heavy(int v) { const int old = g_bq_heavy; if (v >= 0) g_bq_heavy = v; return old; }
 
 // The search grid of a point set, built once and shared by every query over it: both radii of an SA level's ball
 // queries and the three-NN of the FP module whose known set it is.  Any grid gives exact answers (the cell size only
@@ -537,11 +809,30 @@ static int bq_query_launch(void *stream, int b, int n, int m, float radius, int 
     const int wpl = (n + 2047) / 2048;  // bitmap words per lane: 64 lanes x wpl words x 32 bits >= n
     const size_t lds = (size_t)BQG_QWAVES * wpl * 64 * sizeof(unsigned int);
     PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "ball_query_grid: n=%d needs %zu bytes of LDS bitmap", n, lds);
+    const int cpw = g_bq_cpw;
+    const size_t lists = (size_t)BQG_QWAVES * cpw * (nsample | 1) * sizeof(int);
+    const size_t lds_lane = lds > lists ? lds : lists;     // one region per wave: hit lists, then the whole-wave path's bitmap
+    if (g_bq_quad == 3 && lds_lane <= 64 * 1024) {
+        const int per_sample = divup(divup(m, 4), BQG_QWAVES);    // the quad form's work items; the lane form needs a quarter (cpw = 16) or less
+        const int cap = (256 * 16 + b - 1) / b;
+        dim3 grid(per_sample < cap ? per_sample : cap, b);
+        hipLaunchKernelGGL(bq_grid_query_auto_kernel, grid, dim3(BQG_QWAVES * 64), lds_lane, as_stream(stream), n, m, radius, nsample, wpl,
+                           g_bq_heavy, cpw, g_bq_dense_ppc, new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
+        return check_launch("ball_query_grid(query, auto)");
+    }
+    if (g_bq_quad == 2 && lds_lane <= 64 * 1024) {
+        const int per_sample = divup(divup(m, cpw), BQG_QWAVES);
+        const int cap = (256 * 16 + b - 1) / b;
+        dim3 grid(per_sample < cap ? per_sample : cap, b);
+        hipLaunchKernelGGL(bq_grid_query_lane_kernel, grid, dim3(BQG_QWAVES * 64), lds_lane, as_stream(stream), n, m, radius, nsample, wpl,
+                           g_bq_heavy, cpw, new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
+        return check_launch("ball_query_grid(query, lane)");
+    }
     const int units = g_bq_quad ? divup(m, 4) : m;           // work items per sample: quads of centres or centres
     const int per_sample = divup(units, BQG_QWAVES);
     const int cap = (256 * 16 + b - 1) / b;  // about 16 four-wave workgroups per CU in total; waves loop beyond that
     dim3 grid(per_sample < cap ? per_sample : cap, b);
-    if (g_bq_quad)
+    if (g_bq_quad)     // (1, or 2 / 3 where the lane form's lists do not fit the LDS)
         hipLaunchKernelGGL(bq_grid_query4_kernel, grid, dim3(BQG_QWAVES * 64), lds, as_stream(stream), n, m, radius, nsample, wpl,
                            new_xyz, ws.hdr, ws.cell_start, ws.sorted, idx);
     else

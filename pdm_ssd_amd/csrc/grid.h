@@ -30,12 +30,14 @@ __device__ __forceinline__ float search_halfwidth(float c, float absr) {
 // workspace bytes / carve-up shared by both users
 static inline size_t grid_workspace_bytes(int b, int n) {
     if (b <= 0 || n <= 0) return 0;
-    return (size_t)b * (BQG_HDR * sizeof(float) + (size_t)(BQG_CAP + 1) * sizeof(int) + (size_t)n * sizeof(float4)) + 64;
+    // (the second (BQG_CAP + 1)-int table per sample: the running cursors of the split build's scatter kernel)
+    return (size_t)b * (BQG_HDR * sizeof(float) + 2 * (size_t)(BQG_CAP + 1) * sizeof(int) + (size_t)n * sizeof(float4)) + 64;
 }
 struct GridWs {
     float4 *sorted;
     float *hdr;
     int *cell_start;
+    int *cursor;
 };
 static inline GridWs grid_carve(void *workspace, int b, int n) {
     GridWs w;
@@ -43,6 +45,7 @@ static inline GridWs grid_carve(void *workspace, int b, int n) {
     w.sorted = reinterpret_cast<float4 *>(base);
     w.hdr = reinterpret_cast<float *>(w.sorted + (size_t)b * n);
     w.cell_start = reinterpret_cast<int *>(w.hdr + (size_t)b * BQG_HDR);
+    w.cursor = w.cell_start + (size_t)b * (BQG_CAP + 1);
     return w;
 }
 

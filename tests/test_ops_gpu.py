@@ -594,12 +594,16 @@ def test_shared_search_grid_scope_is_safe(oracle, dev):
         _native.call = orig
 
 
-@pytest.mark.parametrize("quad", [1, 0])
-def test_ball_query_grid_quad_and_wave_kernels_agree_with_oracle(oracle, dev, quad):
-    """Four centres per wave (DPP rows) and one centre per wave: same indices as the oracle on clouds whose balls
-    hold 0 .. far more than 16 candidates (dense lidar near field, duplicated points, a lattice, radius 0 and huge)."""
+@pytest.mark.parametrize("quad,heavy,cpw", [(3, 96, 16), (2, 96, 16), (2, 0, 16), (2, 100000, 32), (2, 7, 64), (2, 96, 64), (1, 96, 16), (0, 96, 16)])
+def test_ball_query_grid_quad_and_wave_kernels_agree_with_oracle(oracle, dev, quad, heavy, cpw):
+    """One centre per lane (hits kept in index order in a per-lane list; centres with many candidates or rows handed to
+    the whole-wave path — threshold 0: every centre takes that path, 100000: none does unless its box has too many rows),
+    four centres per wave (DPP rows) and one centre per wave: same indices as the oracle on clouds whose balls hold
+    0 .. far more than 16 candidates (dense lidar near field, duplicated points, a lattice, radius 0 and huge)."""
     from pdm_ssd_amd import _native
     old = _native.lib().pdm_tune_bq_quad(quad)
+    old_heavy = _native.lib().pdm_tune_bq_heavy(heavy)
+    old_cpw = _native.lib().pdm_tune_bq_cpw(cpw)
     try:
         lid = clouds("lidar", 2, 8192, seed=203)
         dup = np.concatenate([lid[:, :4096], lid[:, :4096]], axis=1)
@@ -612,3 +616,5 @@ def test_ball_query_grid_quad_and_wave_kernels_agree_with_oracle(oracle, dev, qu
                 np.testing.assert_array_equal(got.cpu().numpy(), oracle.ball_query(r, ns, xyz_np, new_np), err_msg=f"r={r} ns={ns} m={m}")
     finally:
         _native.lib().pdm_tune_bq_quad(old)
+        _native.lib().pdm_tune_bq_heavy(old_heavy)
+        _native.lib().pdm_tune_bq_cpw(old_cpw)
