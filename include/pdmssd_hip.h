@@ -232,6 +232,16 @@ int pdm_rows_mlp_fused_pair(void *stream, int rows, int cin, const float *in_pm,
                             int cout_b);
 int pdm_tune_fused_pair(int on);   /* 0: always two launches (A/B and tests); returns the previous setting */
 
+/* OPT-IN: the same three-layer per-row MLP with fp32 EMULATED on the bf16 matrix pipe — every fp32 operand split into three
+ * bf16 pieces (8 + 8 + 8 significand bits), a product formed from the six leading partial products on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (3/8 of the fp32-MFMA pipe time; dropped terms <= 2^-24 |a b|).
+ * Only dims = {128, 256, 256, 16} (the point head's stacks, point_head_box.py:7-60); `wstream` = the pre-split weights in
+ * consumption order (pdm_ssd_amd/fused.py::PackedMLPx3, pdm_rows_mlp_x3_stream_bytes bytes), bias fp32 padded. */
+int pdm_rows_mlp_x3(void *stream, int rows, int cin, const float *in_pm, int nlayers, const int *dims, const void *wstream,
+                    size_t wstream_bytes, const float *bias, int relu_last, float *out_pm, int out_stride, int cout);
+size_t pdm_rows_mlp_x3_stream_bytes(int nlayers, const int *dims);
+int pdm_tune_rows_x3_wg_per_cu(int n);
+
 /* The same SA scale / FP module with the wide part of the FIRST layer hoisted out of the per-pair (per-fine-
  * point) loop — algebraically identical, fp32 rounding order differs (tests: <= 1e-4 of the oracle):
  *   SA:  W1 [f_nb ; x_nb - c] = z[nb] + W1[:, xyz] (x_nb - c),   z = W1[:, features] f  over the n source points;

@@ -87,7 +87,14 @@ class PointHeadBox(PointHeadTemplate):
                 ncls, nbox = self.num_class, self.box_coder.code_size
                 cls = torch.empty((1, rows.shape[1], (ncls + 3) // 4 * 4), dtype=torch.float32, device=rows.device)
                 box = torch.empty((1, rows.shape[1], (nbox + 3) // 4 * 4), dtype=torch.float32, device=rows.device)
-                if list(pc.dims) == list(pb.dims) and getattr(self, 'use_pair', True):
+                if getattr(self, 'use_x3', False) and list(pc.dims) == [128, 256, 256, 16] == list(pb.dims):
+                    # OPT-IN: fp32 emulated on the bf16 matrix pipe (three bf16 pieces per operand, six partial products,
+                    # fp32 accumulation: csrc/rows_chain_x3.hip); agrees with the fp32-MFMA kernels to ~1e-6 of the output scale
+                    xc = fused.cached_layers_x3(self, 'cls_x3', self.cls_layers, lambda: _fc_layers(self.cls_layers), point_features.device)
+                    xb = fused.cached_layers_x3(self, 'box_x3', self.box_layers, lambda: _fc_layers(self.box_layers), point_features.device)
+                    fused.rows_forward_x3(xc, rows, cls, relu_last=False)
+                    fused.rows_forward_x3(xb, rows, box, relu_last=False)
+                elif list(pc.dims) == list(pb.dims) and getattr(self, 'use_pair', True):
                     # one launch for both stacks (the rows are read once); bit-identical to the two calls below
                     fused.rows_forward_pair(pc, pb, rows, cls, box, relu_last=False)
                 else:

@@ -158,6 +158,105 @@ def cached_pack(owner, slot, seq, device, in_perm=None):
     return packed
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# fp32 emulated on the bf16 matrix pipe (csrc/rows_chain_x3.hip): every fp32 value as three bf16 pieces.  Opt-in.
+
+def _bf16_rne(x):
+    """float32 array -> its bfloat16 rounding (round to nearest even) as a float32 array."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split_bf16x3(w):
+    """w (float32) -> (hi, mid, lo) float32 arrays, each exactly representable in bfloat16, hi + mid + lo == w (fp32)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    hi = _bf16_rne(w)
+    r1 = w - hi
+    mid = _bf16_rne(r1)
+    lo = _bf16_rne(r1 - mid)
+    return hi, mid, lo
+
+
+def _x3_fragments(wp):
+    """wp (16 NMB, 32 NK) float32 -> uint16 [piece, mb, kb, lane, j]: lane = kg * 16 + row holds W[16 mb + row][32 kb + 16 (j >> 2) +
+    4 kg + (j & 3)], the A operand of v_mfma_f32_16x16x32_bf16 whose B operand is the lane's own accumulator quads of output
+    blocks 2 kb and 2 kb + 1 of the layer before."""
+    M, K = wp.shape
+    pieces = []
+    for piece in split_bf16x3(wp):
+        bits = (piece.view(np.uint32) >> 16).astype(np.uint16)                       # exact: the low 16 bits are zero
+        f = bits.reshape(M // 16, 16, K // 32, 2, 4, 4).transpose(0, 2, 4, 1, 3, 5)  # [mb, row, kb, h, kg, i] -> [mb, kb, kg, row, h, i]
+        pieces.append(np.ascontiguousarray(f).reshape(M // 16, K // 32, 64, 8))
+    return np.stack(pieces)
+
+
+class PackedMLPx3:
+    """Weight stream of pdm_rows_mlp_x3 for a three-layer stack 128 -> 256 -> 256 -> <= 16 (BatchNorm folded): chunks of 24
+    fragments (4 output blocks x 2 k-blocks x 3 pieces; the last layer's single output block x 8 k-blocks x 3 pieces is one
+    chunk), in the order the kernel consumes them; biases fp32, padded widths, layers back to back."""
+
+    def __init__(self, layers, device):
+        assert len(layers) == 3, "PackedMLPx3: three layers"
+        chunks, biases, dims = [], [], []
+        self.flops_per_position = 0
+        for li, (conv, bn) in enumerate(layers):
+            w, shift = fold_conv_bn(conv, bn)
+            w, shift = w.numpy().astype(np.float32), shift.numpy().astype(np.float32)
+            self.flops_per_position += 2 * w.shape[0] * w.shape[1]
+            kp = (w.shape[1] + 31) // 32 * 32
+            cp = 16 if li == 2 else (w.shape[0] + 63) // 64 * 64
+            wp = np.zeros((cp, kp), dtype=np.float32)
+            wp[:w.shape[0], :w.shape[1]] = w
+            bp = np.zeros(cp, dtype=np.float32)
+            bp[:w.shape[0]] = shift
+            if li == 0:
+                dims.append(kp)
+            else:
+                assert kp == dims[-1], "consecutive layer widths disagree"
+            dims.append(cp)
+            fr = _x3_fragments(wp)                                   # [piece, mb, kb, 64, 8]
+            nmb, nkb = fr.shape[1], fr.shape[2]
+            if li < 2:
+                c = fr.reshape(3, nmb // 4, 4, nkb // 2, 2, 64, 8).transpose(1, 3, 4, 2, 0, 5, 6)   # [mg, kg, kbi, i, piece, lane, j]
+            else:
+                assert nmb == 1 and nkb == 8
+                c = fr[:, 0].transpose(1, 0, 2, 3)                   # [kb, piece, lane, j]
+            chunks.append(np.ascontiguousarray(c).reshape(-1))
+            biases.append(bp)
+        assert dims == [128, 256, 256, 16], f"PackedMLPx3: only 128 -> 256 -> 256 -> <= 16 is instantiated, got {dims}"
+        self.nlayers, self.dims = 3, dims
+        self.cout, self.cin = layers[-1][0].out_channels, layers[0][0].in_channels
+        self.dims_c = (ctypes.c_int * len(dims))(*dims)
+        self.wstream = torch.from_numpy(np.concatenate(chunks).view(np.int16)).to(device)
+        self.bias = torch.from_numpy(np.concatenate(biases)).to(device)
+
+    @property
+    def dims_ptr(self):
+        return ctypes.cast(self.dims_c, ctypes.c_void_p)
+
+
+def rows_forward_x3(pk, in_pm, out_pm, relu_last=False):
+    """Per-row three-layer MLP with fp32 emulated by three bf16 pieces per operand (six partial products, fp32 accumulation)."""
+    cin = in_pm.shape[-1]
+    rows = in_pm.numel() // cin
+    assert pk.cin == cin and in_pm.is_contiguous() and out_pm.is_contiguous() and in_pm.dtype == torch.float32
+    _count(f"pdm_rows_mlp_x3[{pk.nlayers} layers, {cin} in, {rows} rows]", rows, pk)
+    _native.call("pdm_rows_mlp_x3", _stream(in_pm), rows, cin, in_pm.data_ptr(), pk.nlayers, pk.dims_ptr, pk.wstream.data_ptr(),
+                 pk.wstream.numel() * 2, pk.bias.data_ptr(), 1 if relu_last else 0, out_pm.data_ptr(), out_pm.shape[-1], pk.cout)
+
+
+def cached_layers_x3(owner, slot, key_module, layers_fn, device):
+    cache = owner.__dict__.setdefault('_pdm_fused_cache', {})
+    key = (_state_key(key_module), str(device))
+    hit = cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = PackedMLPx3(layers_fn(), device)
+    cache[slot] = (key, packed)
+    return packed
+
+
 def cached_layers(owner, slot, key_module, layers_fn, device):
     """PackedMLP of layers_fn() (a list of (conv, bn|None)), cached on `owner` under `slot` and rebuilt when any
     tensor of `key_module` changed."""
