@@ -20,6 +20,12 @@
 // registers; the four waves of a workgroup share the weight stream through LDS: chunks of 24 fragments (4 output blocks x
 // 2 k-blocks x 3 pieces, 24 KB), double-buffered, one barrier per chunk (48 MFMAs per wave).  The chunks of the three
 // layers lie back to back in memory in the order they are consumed, so the stream is one pointer that wraps per tile.
+//
+// Measured (bs = 32 x 16384 rows, both stacks of the point head): 1.03-1.07 ms against 1.60 ms on the fp32 instruction (1.5x;
+// 196-200 TFLOP/s fp32-equivalent), constant 1.0 ns per row from 65 k to 2 M rows.  The six-product arithmetic alone is 0.51 ms at
+// the nominal bf16 rate; timing builds (X3_DIAG): weight fetch cache-hot -5 %, no barriers 0, no re-splitting -3 %, no fragment
+// reads -6 %, all four together 0.72 ms — i.e. a bare MFMA stream in this structure reaches ~70 % of the nominal rate and the
+// operand delivery around it costs the rest (profiles/r04k_split_bf16_chain_diag.txt).
 #include "common.h"
 
 namespace pdm {
@@ -32,6 +38,13 @@ typedef float x3_f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) x3_u4 *x3_gu4c;
 
 constexpr int X3_THREADS = 256;
+#ifndef X3_DIAG
+#define X3_DIAG 0         // timing builds (results wrong): 1 every fetch reads chunk 0 (cache-hot), 2 no barriers, 4 no re-splitting of activations, 8 no fragment reads
+#endif
+#ifndef X3_AHEAD
+#define X3_AHEAD 0        // 1: request the next tile's input rows under the current tile's second layer — measured: 256 VGPRs with 12
+                          // spilled, 1.07-1.10 ms for the point head's two stacks against 1.03-1.07 without (tools/diag/x3_rate.py)
+#endif
 constexpr int X3_CHUNK_U4 = 24 * 64;        // 24 fragments x 64 lanes x 16 bytes
 
 struct RowsChainX3Args {
@@ -83,7 +96,7 @@ __device__ __forceinline__ void x3_mac(x3_f4 &acc, const x3_u4 (&a)[3], const x3
 // The weight stream: chunk `c` of the `total` chunks of the network sits at wstream + c * 24 KB.  fetch = this thread's six
 // 16-byte pieces of a chunk into registers; stash = into an LDS buffer (same layout as in memory).
 __device__ __forceinline__ void x3_fetch(x3_u4 (&r)[6], const unsigned *__restrict__ wstream, int c, int t) {
-    x3_gu4c src = (x3_gu4c)(wstream) + (size_t)c * X3_CHUNK_U4 + t;
+    x3_gu4c src = (x3_gu4c)(wstream) + (size_t)((X3_DIAG & 1) ? 0 : c) * X3_CHUNK_U4 + t;
 #pragma unroll
     for (int u = 0; u < 6; ++u) r[u] = src[u * X3_THREADS];
 }
@@ -92,12 +105,32 @@ __device__ __forceinline__ void x3_stash(const x3_u4 (&r)[6], x3_u4 *buf, int t)
     for (int u = 0; u < 6; ++u) buf[u * X3_THREADS + t] = r[u];
 }
 
-// One layer with NK k-blocks (32 channels each) in and NMB >= 4 output blocks (16 channels each): NMB / 4 x NK / 2 chunks, k inner.
-// On entry buffer p holds this layer's first chunk (stashed and barriered); on exit buffer p holds the first chunk of what
-// follows in the stream.  `c` = running chunk number (wraps at `total`).
+// One chunk = 8 steps (a step = one output block x one k-block = 3 fragments, 6 MFMAs).  The A fragments of step s + 1 are read
+// while step s's MFMAs run; the chunk's barrier sits in front of its LAST step: the next chunk is stashed into the other
+// buffer, barrier, and step 0 of the next chunk is read from there under the last 6 MFMAs — no LDS latency is exposed at a
+// chunk boundary (rows_chain.hip's protocol).  WAR: the other buffer held chunk c - 1, last read in step 6 of chunk c - 1, in
+// front of that chunk's barrier.  `an` = the fragments of the step about to run (in: this chunk's step 0; out: the next chunk's).
+#define X3_STEP(S, ACC, BFRAG)                                                                                     \
+    {                                                                                                              \
+        x3_u4 a_[3];                                                                                               \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) a_[pl_] = an[pl_];                                    \
+        if ((S) < 7) {                                                                                             \
+            if (!(X3_DIAG & 8)) { _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) an[pl_] = buf[(((S) + 1) * 3 + pl_) * 64]; } \
+        } else {                                                                                                   \
+            x3_stash(r, lds + (p ^ 1) * X3_CHUNK_U4, t);                                                           \
+            if (!(X3_DIAG & 2)) __syncthreads();                                                                   \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) an[pl_] = nbuf[pl_ * 64];                          \
+        }                                                                                                          \
+        x3_mac(ACC, a_, BFRAG);                                                                                    \
+    }
+
+// One layer with NK k-blocks (32 channels each) in and NMB >= 4 output blocks (16 channels each): NMB / 4 x NK / 2 chunks, k inner;
+// chunk layout: step (kbi, i) = kbi * 4 + i.  On entry buffer p holds this layer's first chunk and `an` its step 0; on exit the
+// same for what follows in the stream.  `c` = running chunk number (wraps at `total`).
 template <int NK, int NMB>
 __device__ __forceinline__ void x3_layer(const x3_u4 (&in)[NK][3], x3_f4 (&acc)[NMB], const float *__restrict__ bias,
-                                         const unsigned *__restrict__ wstream, int &c, int total, x3_u4 *lds, int &p, int t, int lane) {
+                                         const unsigned *__restrict__ wstream, int &c, int total, x3_u4 *lds, int &p, int t, int lane,
+                                         x3_u4 (&an)[3]) {
     static_assert(NK % 2 == 0 && NMB % 4 == 0, "x3_layer: whole chunks");
     const int g = lane >> 4;
 #pragma unroll
@@ -109,44 +142,31 @@ __device__ __forceinline__ void x3_layer(const x3_u4 (&in)[NK][3], x3_f4 (&acc)[
             x3_u4 r[6];
             const int nxt = c + 1 == total ? 0 : c + 1;
             x3_fetch(r, wstream, nxt, t);
-            const x3_u4 *buf = lds + p * X3_CHUNK_U4 + lane;
+            const x3_u4 *buf = lds + p * X3_CHUNK_U4 + lane, *nbuf = lds + (p ^ 1) * X3_CHUNK_U4 + lane;
 #pragma unroll
             for (int kbi = 0; kbi < 2; ++kbi) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    x3_u4 a[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[pl] = buf[((kbi * 4 + i) * 3 + pl) * 64];
-                    x3_mac(acc[4 * mg + i], a, in[2 * kg + kbi]);
-                }
+                for (int i = 0; i < 4; ++i) X3_STEP(kbi * 4 + i, acc[4 * mg + i], in[2 * kg + kbi])
             }
-            x3_stash(r, lds + (p ^ 1) * X3_CHUNK_U4, t);
-            __syncthreads();
             p ^= 1;
             c = nxt;
         }
     }
 }
-// The heads' last layer: ONE output block over 8 k-blocks = one chunk, fragment (kb, piece) at slot kb * 3 + piece.
+// The heads' last layer: ONE output block over 8 k-blocks = one chunk, step = k-block.
 template <int NK>
 __device__ __forceinline__ void x3_last_layer(const x3_u4 (&in)[NK][3], x3_f4 &acc, const float *__restrict__ bias,
-                                              const unsigned *__restrict__ wstream, int &c, int total, x3_u4 *lds, int &p, int t, int lane) {
+                                              const unsigned *__restrict__ wstream, int &c, int total, x3_u4 *lds, int &p, int t, int lane,
+                                              x3_u4 (&an)[3]) {
     static_assert(NK == 8, "x3_last_layer: 8 k-blocks x 3 pieces = one chunk");
     const int g = lane >> 4;
     acc = *reinterpret_cast<const x3_f4 *>(bias + 4 * g);
     x3_u4 r[6];
     const int nxt = c + 1 == total ? 0 : c + 1;
     x3_fetch(r, wstream, nxt, t);
-    const x3_u4 *buf = lds + p * X3_CHUNK_U4 + lane;
+    const x3_u4 *buf = lds + p * X3_CHUNK_U4 + lane, *nbuf = lds + (p ^ 1) * X3_CHUNK_U4 + lane;
 #pragma unroll
-    for (int kb = 0; kb < NK; ++kb) {
-        x3_u4 a[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[pl] = buf[(kb * 3 + pl) * 64];
-        x3_mac(acc, a, in[kb]);
-    }
-    x3_stash(r, lds + (p ^ 1) * X3_CHUNK_U4, t);
-    __syncthreads();
+    for (int kb = 0; kb < NK; ++kb) X3_STEP(kb, acc, in[kb])
     p ^= 1;
     c = nxt;
 }
@@ -158,6 +178,10 @@ __device__ __forceinline__ void x3_relu_split(const x3_f4 (&acc)[NMB], x3_u4 (&o
         x3_f4 u = acc[2 * q], v = acc[2 * q + 1];
         u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (X3_DIAG & 4) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) out[q][pl] = x3_u4{__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(v.x), __float_as_uint(v.y)};
+        } else
         x3_split8(u, v, out[q]);
     }
 }
@@ -179,13 +203,20 @@ __global__ __launch_bounds__(X3_THREADS, 2) void rows_chain_x3_kernel(RowsChainX
         x3_stash(r, lds, t);
     }
     __syncthreads();
+    x3_u4 an[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) an[pl] = lds[pl * 64 + lane];
+    x3_f4 xn[2 * NK0];       // the next tile's input rows (raw fp32), requested under this tile's second layer
     for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         asm volatile("" : "+s"(wstream));     // keeps the chunk addresses from being hoisted out of the loop as ~50 invariants
         long long row = tl * 64 + 16 * wave + pos;
         const bool live = row < a.rows;
         if (!live) row = a.rows - 1;
         x3_u4 x0[NK0][3];
-        {
+        if (X3_AHEAD && tl != (long long)blockIdx.x) {
+#pragma unroll
+            for (int kb = 0; kb < NK0; ++kb) x3_split8(xn[2 * kb], xn[2 * kb + 1], x0[kb]);
+        } else {
             const float *__restrict__ src = a.in + (size_t)row * a.in_stride + 4 * g;
 #pragma unroll
             for (int kb = 0; kb < NK0; ++kb) {
@@ -196,17 +227,27 @@ __global__ __launch_bounds__(X3_THREADS, 2) void rows_chain_x3_kernel(RowsChainX
         x3_u4 x1[NM1 / 2][3];
         {
             x3_f4 acc[NM1];
-            x3_layer<NK0, NM1>(x0, acc, a.bias + a.boff[0], wstream, c, TOTAL, lds, p, t, lane);
+            x3_layer<NK0, NM1>(x0, acc, a.bias + a.boff[0], wstream, c, TOTAL, lds, p, t, lane, an);
             x3_relu_split<NM1>(acc, x1);
+        }
+        if (X3_AHEAD) {
+            long long nrow = (tl + gridDim.x) * 64 + 16 * wave + pos;
+            if (nrow >= a.rows) nrow = a.rows - 1;
+            const float *__restrict__ nsrc = a.in + (size_t)nrow * a.in_stride + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < NK0; ++kb) {
+                xn[2 * kb] = *reinterpret_cast<const x3_f4 *>(nsrc + 32 * kb);
+                xn[2 * kb + 1] = *reinterpret_cast<const x3_f4 *>(nsrc + 32 * kb + 16);
+            }
         }
         x3_u4 x2[NM2 / 2][3];
         {
             x3_f4 acc[NM2];
-            x3_layer<NM1 / 2, NM2>(x1, acc, a.bias + a.boff[1], wstream, c, TOTAL, lds, p, t, lane);
+            x3_layer<NM1 / 2, NM2>(x1, acc, a.bias + a.boff[1], wstream, c, TOTAL, lds, p, t, lane, an);
             x3_relu_split<NM2>(acc, x2);
         }
         x3_f4 y;
-        x3_last_layer<NM2 / 2>(x2, y, a.bias + a.boff[2], wstream, c, TOTAL, lds, p, t, lane);
+        x3_last_layer<NM2 / 2>(x2, y, a.bias + a.boff[2], wstream, c, TOTAL, lds, p, t, lane, an);
         if (a.relu_last) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
         if (live) {
             float *__restrict__ orow = a.out + (size_t)row * a.out_stride;

@@ -6,6 +6,9 @@ import torch
 from pdm_ssd_amd import _native, fused
 from pdm_ssd_amd.dense_heads.point_head_box import _fc_layers
 from pdm_ssd_amd.dense_heads.point_head_template import PointHeadTemplate
+if "--lib" in sys.argv:
+    _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+    print("library:", _native.LIB_PATH, flush=True)
 dev = torch.device("cuda:0"); l = _native.lib()
 torch.manual_seed(0)
 rows = 32 * 16384
