@@ -1208,6 +1208,16 @@ def main():
                                  "launch": b8.mode, "verified": verify_or_message(b8)}
                 del b8
                 torch.cuda.empty_cache()
+        if (B, N) == (32, 16384) and world == 1:
+            # OPT-IN, never the headline: the point head's two stacks with fp32 EMULATED on the bf16 matrix pipe (three bf16
+            # pieces per operand, six partial products, fp32 accumulation: csrc/rows_chain_x3.hip) — the fp32 MFMA instruction
+            # that bounds the step runs at 1/16 of the bf16 rate on this chip.  Kernel time and error table, then the same
+            # pipelined step with head.use_x3 = True (verified against the serial detector running the same kernels).
+            try:
+                with torch.no_grad():
+                    extras["split_bf16_chain"] = split_bf16_section(model, B, N, args, device)
+            except Exception as e:
+                extras["split_bf16_chain"] = {"error": f"{type(e).__name__}: {e}"}
     # rebuilt if deleted above: only its attributes are needed for the line
     line = {
         "metric": f"frames/sec ({N}-pt clouds, bs={B})", "value": round(frames_per_s, 2), "unit": "frames/s",
@@ -1256,6 +1266,72 @@ def main():
 
 
 LAUNCH_MODE = [None, None]
+
+
+def split_bf16_section(model, B, N, args, device):
+    from pdm_ssd_amd import fused
+    from pdm_ssd_amd.dense_heads.point_head_box import _fc_layers
+    head = model.point_head
+    rows = B * N
+    x = torch.randn(rows, 128, device=device)
+    stacks = [(head.num_class, head.cls_layers), (head.box_coder.code_size, head.box_layers)]
+    p32 = [fused.PackedMLP(_fc_layers(seq), device) for _, seq in stacks]
+    px3 = [fused.PackedMLPx3(_fc_layers(seq), device) for _, seq in stacks]
+    o32 = [torch.empty(rows, (c + 3) // 4 * 4, device=device) for c, _ in stacks]
+    ox3 = [torch.empty(rows, (c + 3) // 4 * 4, device=device) for c, _ in stacks]
+
+    def f32():
+        fused.rows_forward_pair(p32[0], p32[1], x, o32[0], o32[1], relu_last=False)
+
+    def x3():
+        for p, o in zip(px3, ox3):
+            fused.rows_forward_x3(p, x, o, relu_last=False)
+
+    def timed(f, n=20):
+        for _ in range(40):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    ms32, msx3 = timed(f32), timed(x3)
+    flop = rows * sum(p.flops_per_position for p in p32)
+    sub = 32768
+    errs = {}
+    for (c, seq), a, b in zip(stacks, o32, ox3):
+        import copy
+        want = copy.deepcopy(seq).cpu().double().eval()(x[:sub].cpu().double())
+        scale = float(want.abs().max())
+        a64, b64 = a[:sub, :c].cpu().double(), b[:sub, :c].cpu().double()
+        errs[f"{c}_outputs"] = {"max_rel_x3_vs_fp32_mfma": float((a64 - b64).abs().max()) / scale,
+                                "max_rel_fp32_mfma_vs_float64": float((a64 - want).abs().max()) / scale,
+                                "max_rel_x3_vs_float64": float((b64 - want).abs().max()) / scale,
+                                "rms_rel_fp32_mfma_vs_float64": float((a64 - want).pow(2).mean().sqrt()) / scale,
+                                "rms_rel_x3_vs_float64": float((b64 - want).pow(2).mean().sqrt()) / scale}
+    out = {"dtype": "f32 emulated (3 x bf16 split, 6 products on v_mfma_f32_16x16x32_bf16, f32 accumulation)",
+           "status": "opt-in (PointHeadBox.use_x3); NOT used by the headline step",
+           "workload": f"the point head's two stacks 128 -> 256 -> 256 -> {{{stacks[0][0]}, {stacks[1][0]}}} over {rows} rows",
+           "ms_fp32_mfma_one_launch": round(ms32, 4), "ms_split_bf16_two_launches": round(msx3, 4), "speedup": round(ms32 / msx3, 3),
+           "TFLOPs_fp32_mfma": round(flop / ms32 / 1e9, 1), "TFLOPs_fp32_equivalent_split_bf16": round(flop / msx3 / 1e9, 1),
+           "errors_relative_to_output_scale": errs, "error_sample_rows": sub}
+    del x, o32, ox3
+    torch.cuda.empty_cache()
+    head.use_x3 = True
+    try:
+        bx = Bench(model, B, N, args.clouds, args.pipeline_depth, device, seed0=1234, graph=not args.no_graph, autotune=not args.no_autotune)
+        n = max(10, args.steps)
+        t = bx.timed(n, 3)
+        out["full_step_with_split_bf16_point_head"] = {"ms_per_step": round(t / n * 1e3, 4), "frames_per_s": round(B * n / t, 1),
+                                                        "verified": verify_or_message(bx)}
+        del bx
+    finally:
+        head.use_x3 = False
+        torch.cuda.empty_cache()
+    return out
 
 
 def verify_or_message(b, steps=2):
