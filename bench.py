@@ -397,8 +397,20 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
     # torch's fused multi-tensor AdamW (one launch chain for all parameters; PDM_BENCH_ADAMW=foreach for the per-operation form:
     # same update, 21.8 instead of 21.7 ms per step and 1 ms more host time)
     opt = torch.optim.AdamW(params, lr=1e-3, capturable=want_graph, fused=os.environ.get("PDM_BENCH_ADAMW", "fused") == "fused" or None)
-    gt_boxes = synthetic_gt_boxes(B, 12, 99 + rank, device)
+    # The reference's step fetches a NEW batch every iteration (tools/train_utils/train_utils.py:33) and clips the gradient norm
+    # (:58-62, GRAD_NORM_CLIP = 10 in OpenPCDet's configs): NB distinct clouds + box sets rotate through static buffers (one
+    # pdm_copy_many launch per step, as Bench._advance does for the inference step), so the cloud whose sampling chain runs on the
+    # side stream really is the next batch, and every step ends with clip_grad_norm_ (foreach form: the norm stays on the device).
+    NB = 4
+    batches = [points] + [make_batch(B, N, args.clouds, 1234 + rank * B + 1000 * i, device)[1] for i in range(1, NB)]
+    gts = [synthetic_gt_boxes(B, 12, 99 + rank + 17 * i, device) for i in range(NB)]
+    cur_pts, next_pts, gt_boxes = batches[0].clone(), batches[1].clone(), gts[0].clone()
     backbone = model.backbone_3d
+    grad_clip = float(os.environ.get("PDM_BENCH_GRAD_CLIP", "10"))
+
+    def advance(i):
+        """Static buffers <- batch i (consumed by this step) and batch i + 1 (sampled for the next step)."""
+        _native.copy_many([cur_pts, gt_boxes, next_pts], [batches[i % NB], gts[i % NB], batches[(i + 1) % NB]])
 
     class Step(torch.nn.Module):
         def __init__(self, m):
@@ -418,30 +430,34 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
                                                             gradient_as_bucket_view=True)
 
     # The sampling chain (FPS + gather, one workgroup per cloud) needs no gradient: the chain of the NEXT batch
-    # runs on a side stream under this batch's forward/backward (same synthetic cloud every step).
+    # runs on a side stream under this batch's forward/backward.
     side = overlapping_stream(device)     # pdm_ssd_amd/pipeline.py: a stream on a hardware queue of its own
-    state = {"sampled": None}
+    state = {"sampled": None, "it": 0}
 
     def sample_next():
         with torch.no_grad():
-            return backbone.sample_chain(points[:, 1:4].contiguous().view(B, -1, 3))
+            return backbone.sample_chain(next_pts[:, 1:4].contiguous().view(B, -1, 3))
 
     if not args.serial:
+        next_pts.copy_(batches[0])       # the first step consumes batch 0: its chain is the "next" one now
         state["sampled"] = sample_next()
+        torch.cuda.synchronize()
 
-    def step():
+    def step_body():
         opt.zero_grad(set_to_none=True)
         if args.serial:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = stepper(points)
+                loss = stepper(cur_pts)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 nxt = sample_next()
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = stepper(points, state["sampled"])
+                loss = stepper(cur_pts, state["sampled"])
         loss.backward()
+        if grad_clip > 0:
+            torch.nn.utils.clip_grad_norm_(params, grad_clip, foreach=True)
         opt.step()
         if not args.serial:
             main.wait_stream(side)
@@ -453,6 +469,11 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
                     t.record_stream(main)
                 state["sampled"] = nxt
         return loss
+
+    def step():
+        advance(state["it"])
+        state["it"] += 1
+        return step_body()
 
     for _ in range(max(1, warmup)):
         step()
@@ -528,7 +549,7 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
                 graph = torch.cuda.CUDAGraph()
                 opt.zero_grad(set_to_none=True)
                 with torch.cuda.graph(graph, stream=cap):
-                    static_loss = step()
+                    static_loss = step_body()     # the input rotation (advance) stays outside the captured region
             torch.cuda.current_stream().wait_stream(cap)
             torch.cuda.synchronize()
             graph.replay(); graph.replay()
@@ -543,6 +564,8 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
             torch.cuda.synchronize()
     if graph is not None:
         def step():   # noqa: F811 - the timed loop below replays
+            advance(state["it"])
+            state["it"] += 1
             graph.replay()
             return static_loss
     import gc
@@ -565,7 +588,8 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
         "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "bf16 (MLPs) / f32 (coordinates, operators)", "data": "synthetic",
         "config": {"workload": f"configs[3]: PDM-SSD train step (PointNet2MSG + PDM neck + hybrid head losses), bs={B}/GPU x {N} "
-                               "pts, 12 synthetic boxes per cloud, AdamW (torch fused multi-tensor), DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
+                               f"pts, 12 synthetic boxes per cloud, {NB} distinct batches + box sets in rotation, clip_grad_norm_({grad_clip:g}), "
+                               "AdamW (torch fused multi-tensor), DDP gradient all-reduce over RCCL", "parallelism": f"dp{world}",
                    "global_batch": world * B, "launch": launch,
                    "overlap": "none" if args.serial else "FPS chain of the next batch on a side stream"},
         "final_loss": float(loss.detach())}

@@ -162,18 +162,27 @@ def test_training_step_issues_without_host_synchronisation(dev):
     gt = scene_boxes(B, 6, 3)
     batch = {'batch_size': B, 'points': torch.from_numpy(synthetic.to_batch_points(cl)).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
              'points_per_sample_checked': True}
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3, fused=True)
     for _ in range(2):     # first calls build caches (packed weights, grids)
+        opt.zero_grad(set_to_none=True)
         ret, tb, disp = model(dict(batch))
         ret['loss'].backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0, foreach=True)
+        opt.step()
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")
     try:
+        opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             ret, tb, disp = model(dict(batch))
         ret['loss'].backward()
+        # the reference clips every step (tools/train_utils/train_utils.py:58-62): the foreach form keeps the norm on the device
+        total = torch.nn.utils.clip_grad_norm_(params, 10.0, foreach=True)
+        opt.step()
     finally:
         torch.cuda.set_sync_debug_mode("default")
-    assert torch.isfinite(ret['loss'])
+    assert torch.isfinite(ret['loss']) and torch.isfinite(total)
 
 
 @pytest.mark.gpu
