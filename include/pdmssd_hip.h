@@ -232,6 +232,21 @@ int pdm_rows_mlp_fused_pair(void *stream, int rows, int cin, const float *in_pm,
                             int cout_b);
 int pdm_tune_fused_pair(int on);   /* 0: always two launches (A/B and tests); returns the previous setting */
 
+/* Point head in training: target assignment + sigmoid focal loss + weighted smooth-L1 loss + d L / d predictions, per point
+ * (/root/reference/pcdet/models/dense_heads/point_head_template.py:51-206 with set_ignore_flag, PointResidualCoder with mean
+ * sizes box_coder_utils.py:156-179, loss_utils.py:10-141).  n_total = B * n_per_sample points in sample order; box_idx / ext_idx =
+ * pdm_points_in_boxes on the boxes / the enlarged boxes; gt_boxes (B, boxes_per_sample, 8); pred_bf16 = dtype of cls_preds
+ * (n_total, num_class) and box_preds (n_total, 8) (row strides in elements) AND of the gradients dcls / dbox (contiguous);
+ * code_weights: 8 floats on the HOST.  labels (n_total) int64; out (3): [L_cls, L_box, #positives], L_box = NaN when a positive's
+ * class exceeds the mean-size table (the reference asserts).  Three launches, no atomics on floats: bit-reproducible. */
+int pdm_point_head_loss(void *stream, long long n_total, int n_per_sample, int boxes_per_sample, int num_class, int n_mean,
+                        int pred_bf16, const void *cls_preds, long long cls_stride, const void *box_preds, long long box_stride,
+                        const float *xyz, long long xyz_stride, const int *box_idx, const int *ext_idx, const float *gt_boxes,
+                        const float *mean_size, const float *code_weights, float beta, float alpha, float gamma, float cls_weight,
+                        float box_weight, long long *labels, void *dcls, void *dbox, float *out, void *workspace,
+                        size_t workspace_bytes);
+size_t pdm_point_head_loss_workspace_bytes(long long n_total);
+
 /* OPT-IN: the same three-layer per-row MLP with fp32 EMULATED on the bf16 matrix pipe — every fp32 operand split into three
  * bf16 pieces (8 + 8 + 8 significand bits), a product formed from the six leading partial products on
  * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (3/8 of the fp32-MFMA pipe time; dropped terms <= 2^-24 |a b|).

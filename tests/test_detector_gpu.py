@@ -66,6 +66,58 @@ def test_point_head_targets_on_gpu_match_reference_fixture(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
+def test_point_head_fused_loss_equals_torch_formulation(dev, bf16):
+    """pdm_point_head_loss (targets + focal + smooth-L1 + gradients in three launches) against the torch formulation of
+    point_head_template.py (the one pinned by the reference-run fixtures): labels identical, both losses and the positive
+    count to 1e-5, the gradients of every parameter to 1e-4 of their scale — fp32, and bf16 predictions under autocast (the
+    gradient of a bf16 prediction is rounded once on both paths).  Zero-padded box rows, points inside only the enlarged box
+    and a sample without a positive are in the case."""
+    torch.manual_seed(4)
+    B, n = 3, 2048
+    gt = scene_boxes(B, 5, 11)
+    gt[2] = 0.0                                            # a sample with no box at all
+    rng = np.random.default_rng(5)
+    xyz = np.stack([rng.uniform(0, 70, (B, n)), rng.uniform(-40, 40, (B, n)), rng.uniform(-3, 1, (B, n))], -1).astype(np.float32)
+    for b in range(2):
+        for k in range(3):     # points in and just around the first boxes (inside / ring of the enlarged box / outside)
+            xyz[b, 300 * k:300 * (k + 1)] = gt[b, k, :3] + rng.normal(0, 1.0, (300, 3)).astype(np.float32) * gt[b, k, 3:6] * 0.4
+    coords = np.concatenate([np.repeat(np.arange(B, dtype=np.float32), n)[:, None], xyz.reshape(-1, 3)], 1)
+    head = PointHeadBox(num_class=3, input_channels=16, model_cfg=HEAD_CFG).to(dev).train()
+    feats = torch.randn(B * n, 16, device=dev)
+    bd = {'batch_size': B, 'point_features': feats, 'point_coords': torch.from_numpy(coords).to(dev),
+          'gt_boxes': torch.from_numpy(gt).to(dev), 'points_per_sample_checked': True}
+    res = {}
+    for fused_on in (True, False):
+        head.use_fused_loss = fused_on
+        head.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            head(dict(bd))
+            assert ('fused_loss_inputs' in head.forward_ret_dict) == fused_on
+            loss, tb = head.get_loss()
+        loss.backward()
+        res[fused_on] = (float(loss), {k: float(v) for k, v in tb.items()}, head.forward_ret_dict['point_cls_labels'].clone(),
+                         {k: p.grad.clone() for k, p in head.named_parameters()})
+    (la, ta, laba, ga), (lb, tb_, labb, gb) = res[True], res[False]
+    assert torch.equal(laba, labb)
+    assert int((laba > 0).sum()) > 50 and int((laba == -1).sum()) > 5 and ta['point_pos_num'] == tb_['point_pos_num'] == float((laba > 0).sum())
+    tol = 2e-3 if bf16 else 1e-5
+    assert abs(la - lb) <= tol * abs(lb)
+    for k in ('point_loss_cls', 'point_loss_box'):
+        assert abs(ta[k] - tb_[k]) <= tol * abs(tb_[k]) + 1e-7, k
+    for k in ga:
+        scale = float(gb[k].abs().max())
+        assert float((ga[k] - gb[k]).abs().max()) <= (2e-2 if bf16 else 1e-4) * scale + 1e-9, k
+    # a positive whose class is outside the mean-size table: NaN box loss (the reference asserts)
+    head.use_fused_loss = True
+    bad = dict(bd, gt_boxes=bd['gt_boxes'].clone())
+    bad['gt_boxes'][0, 0, 7] = 9
+    head(bad)
+    loss, tb = head.get_loss()
+    assert not torch.isfinite(loss) and not torch.isfinite(tb['point_loss_box']) and torch.isfinite(tb['point_loss_cls'])
+
+
+@pytest.mark.gpu
 def test_point_head_fused_inference_equals_torch_layers(dev):
     torch.manual_seed(0)
     head = build_pdm_ssd().point_head.to(dev).eval()
