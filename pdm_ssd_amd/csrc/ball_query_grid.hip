@@ -739,7 +739,7 @@ __global__ __launch_bounds__(BQG_QWAVES * 64) void bq_grid_query_auto_kernel(
 
 // Query form.  1 (default): four centres per wave (round 2's kernel).  2: one centre per lane (round 4).  3: per cloud by the density
 // the build measures (lane for sparse, quad for dense clouds).  0: one wave per centre (round 1).  All return the same indices.
-// Measured on the API-exact block of the bench (8 ball_query + 16 group_points, bs = 32, same process, profiles/r04h_ball_query_forms.txt):
+// Measured on the API-exact block of the bench (8 ball_query + 16 group_points, bs = 32, same process, profiles/r04i_ball_query_forms.txt):
 // uniform KITTI-range clouds quad 462-473 us, lane 456-462, by density 461-477; lidar-like clouds quad 623-634, lane 716-960 (a
 // wave answers its heavy centres one after the other), by density 683-704 (FPS-sampled levels of a dense scene count as sparse by
 // points per cell and still hold dozens of candidates per ball).  2-3 % on the sparse case against 10-50 % on the dense one: the
