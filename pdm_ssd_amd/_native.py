@@ -115,6 +115,8 @@ _SIGNATURES = {
     "pdm_tune_bq_quad": None,
     "pdm_tune_bq_heavy": None,
     "pdm_tune_bq_cpw": None,
+    "pdm_tune_copy_variant": None,
+    "pdm_tune_copy_max_wg": None,
     "pdm_tune_bq_small_waves": None,
     "pdm_tune_bq_dense_ppc": None,
     "pdm_tune_grid_split": None,

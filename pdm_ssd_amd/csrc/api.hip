@@ -52,6 +52,9 @@ struct CopyTable {
     unsigned unit[COPY_MAX];
 };
 
+// VARIANT (pdm_tune_copy_variant): bit 0 = non-temporal stores, bit 1 = eight 16-byte loads in flight per lane (32 KB tiles),
+// bit 2 = non-temporal loads.
+template <int VARIANT>
 __global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
     const int k = blockIdx.y;
     unsigned long long n = t.bytes[k];
@@ -65,18 +68,27 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
         const unsigned long long n16 = n >> 4;
-        const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(s);
-        uint4 *__restrict__ d4 = reinterpret_cast<uint4 *>(d);
+        typedef unsigned cp_u4 __attribute__((ext_vector_type(4)));     // (the non-temporal builtins take clang vectors)
+        const cp_u4 *__restrict__ s4 = reinterpret_cast<const cp_u4 *>(s);
+        cp_u4 *__restrict__ d4 = reinterpret_cast<cp_u4 *>(d);
         // a workgroup walks 16 KB tiles (4 x 256 lanes x 16 bytes, contiguous): four 16-byte loads in flight per lane before the
         // first store (one load per iteration left the memory system a quarter of the requests it needs: 4.7 TB/s on a 1 GiB
         // copy in round 2; pieces a whole grid-stride apart, tried first, were slower still: 4.4 TB/s)
-        const unsigned long long ntiles = n16 >> 10;
+        constexpr int U = (VARIANT & 2) ? 8 : 4;
+        constexpr int SH = (VARIANT & 2) ? 11 : 10;
+        const unsigned long long ntiles = n16 >> SH;
         for (unsigned long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            const unsigned long long i = (tile << 10) + threadIdx.x;
-            const uint4 a = s4[i], b = s4[i + 256], c = s4[i + 512], e = s4[i + 768];
-            d4[i] = a; d4[i + 256] = b; d4[i + 512] = c; d4[i + 768] = e;
+            const unsigned long long i = (tile << SH) + threadIdx.x;
+            cp_u4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = (VARIANT & 4) ? __builtin_nontemporal_load(s4 + i + 256 * u) : s4[i + 256 * u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (VARIANT & 1) __builtin_nontemporal_store(v[u], d4 + i + 256 * u);
+                else d4[i + 256 * u] = v[u];
+            }
         }
-        for (unsigned long long i = (ntiles << 10) + tid; i < n16; i += stride) d4[i] = s4[i];
+        for (unsigned long long i = (ntiles << SH) + tid; i < n16; i += stride) d4[i] = s4[i];
         for (unsigned long long j = (n16 << 4) + tid; j < n; j += stride) d[j] = s[j];
     } else {
         for (unsigned long long i = tid; i < n; i += stride) d[i] = s[i];
@@ -87,6 +99,13 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
 
 static int copy_many_impl(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes,
                           const int *const *dyn_count, const unsigned *dyn_unit);
+// -1 (default): non-temporal loads and stores (variant 5) for launches whose largest buffer is >= 32 MB — streamed once, nothing
+// of it is worth a cache line: 5.4-5.5 -> 6.0 TB/s on a 1 GiB copy (tools/diag/copy_rate.py; the guide's float4 copy: 6.29; torch's
+// copy_: 5.05) — and plain accesses below (the pipeline's hand-over: data the next kernels read again); 0..7 force a variant.
+static int g_copy_variant = -1;
+static int g_copy_max_wg = 8192;
+extern "C" int pdm_tune_copy_variant(int v) { const int old = g_copy_variant; g_copy_variant = v < 0 ? -1 : (v & 7); return old; }
+extern "C" int pdm_tune_copy_max_wg(int n) { const int old = g_copy_max_wg; if (n > 0) g_copy_max_wg = n; return old; }
 
 extern "C" int pdm_copy_many(void *stream, int count, void *const *dst, const void *const *src, const size_t *bytes) {
     return copy_many_impl(stream, count, dst, src, bytes, nullptr, nullptr);
@@ -122,8 +141,12 @@ static int copy_many_impl(void *stream, int count, void *const *dst, const void 
         if (n == 0) continue;
         // a lane moves four 16-byte pieces per pass; up to 8 workgroups per CU
         const unsigned long long want = (largest / 64 + 255) / 256;
-        const unsigned gx = (unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want);
-        hipLaunchKernelGGL(copy_many_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), t);
+        const unsigned gx = (unsigned)(want < 1 ? 1 : want > (unsigned long long)g_copy_max_wg ? (unsigned long long)g_copy_max_wg : want);
+        switch (g_copy_variant < 0 ? (largest >= (32ull << 20) ? 5 : 0) : (g_copy_variant & 7)) {
+#define PDM_COPY_CASE(V) case V: hipLaunchKernelGGL(copy_many_kernel<V>, dim3(gx, n), dim3(256), 0, as_stream(stream), t); break;
+            PDM_COPY_CASE(0) PDM_COPY_CASE(1) PDM_COPY_CASE(2) PDM_COPY_CASE(3) PDM_COPY_CASE(4) PDM_COPY_CASE(5) PDM_COPY_CASE(6) PDM_COPY_CASE(7)
+#undef PDM_COPY_CASE
+        }
         const int rc = check_launch("copy_many");
         if (rc) return rc;
     }
