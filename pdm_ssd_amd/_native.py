@@ -116,6 +116,7 @@ _SIGNATURES = {
     "pdm_tune_bq_heavy": None,
     "pdm_tune_bq_cpw": None,
     "pdm_tune_copy_variant": None,
+    "pdm_tune_group_nt": None,
     "pdm_tune_copy_max_wg": None,
     "pdm_tune_bq_small_waves": None,
     "pdm_tune_bq_dense_ppc": None,

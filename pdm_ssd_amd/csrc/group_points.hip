@@ -16,9 +16,17 @@ constexpr int GP_THREADS = 256;
 constexpr int GP_CG = 8;  // channels per workgroup (index registers reused across them)
 
 // vectorised: L % 4 == 0, idx/out 16-byte aligned
+// outputs are written once and read by another kernel much later: non-temporal stores keep them from displacing the index and
+// source lines the gathers hit in L2 (pdm_tune_group_nt; measured with tools/diag/api_block_ab.py)
+typedef float gp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gp_store4(float *p, const float4 &v, int nt) {
+    if (nt) __builtin_nontemporal_store(gp_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<gp_f4 *>(p));
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+
 __global__ __launch_bounds__(GP_THREADS) void group_points_v4_kernel(
     int c, int n, long long L, const float *__restrict__ points, const int *__restrict__ idx,
-    float *__restrict__ out) {
+    float *__restrict__ out, int nt = 0) {
     const int b = blockIdx.z;
     const long long q = (long long)blockIdx.x * GP_THREADS + threadIdx.x;  // quad index
     if (q * 4 >= L) return;
@@ -29,7 +37,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_v4_kernel(
         const float *__restrict__ row = points + ((size_t)b * c + ci) * n;
         float4 v;
         v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
-        *reinterpret_cast<float4 *>(out + ((size_t)b * c + ci) * L + q * 4) = v;
+        gp_store4(out + ((size_t)b * c + ci) * L + q * 4, v, nt);
     }
 }
 
@@ -128,7 +136,7 @@ constexpr int GPL_THREADS = 256;
 
 __global__ __launch_bounds__(GPL_THREADS) void group_points_lds_kernel(
     int c, int n, long long L, int rows_per_wg, const float *__restrict__ points, const int *__restrict__ idx,
-    float *__restrict__ out) {
+    float *__restrict__ out, int nt = 0) {
     extern __shared__ float rows[];  // rows_per_wg x n
     const int b = blockIdx.y;
     const int c0 = blockIdx.x * rows_per_wg;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(GPL_THREADS) void group_points_lds_kernel(
                 const float *row = rows + (size_t)r * n;
                 float4 v;
                 v.x = row[id.x]; v.y = row[id.y]; v.z = row[id.z]; v.w = row[id.w];
-                *reinterpret_cast<float4 *>(ob + (size_t)r * L + q * 4) = v;
+                gp_store4(ob + (size_t)r * L + q * 4, v, nt);
             }
         }
     } else {
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(GPL_THREADS) void group_points_grad_lds_kernel(
 template <int T, int GPR_UQ, bool XCD>
 __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long long L, int rpw, int nrg, int lsplit, int B,
                                                               const float *__restrict__ points, const int *__restrict__ idx,
-                                                              float *__restrict__ out) {
+                                                              float *__restrict__ out, int nt = 0) {
     extern __shared__ float rows[];  // rpw x n
     const int per_b = nrg * lsplit;
     int b, rem;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long
                 if (q < q_end) {
                     float4 v;
                     v.x = row[id[u].x]; v.y = row[id[u].y]; v.z = row[id[u].z]; v.w = row[id[u].w];
-                    ob[(size_t)r * nq + q] = v;
+                    gp_store4(reinterpret_cast<float *>(ob + (size_t)r * nq + q), v, nt);
                 }
             }
         }
@@ -259,6 +267,8 @@ __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long
 // tuning knob (tools/diag/group_sweep.py): 0 = heuristics; else variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel without
 // the XCD unit order) | rpw << 4 | lsplit << 8 | (threads / 256) << 16 | quads per lane and pass << 20
 static int g_gp_tune = 0;
+static int g_gp_nt = 0;      // 1: non-temporal stores of the grouped outputs
+extern "C" int pdm_tune_group_nt(int on) { const int old = g_gp_nt; g_gp_nt = on != 0; return old; }
 
 // rows of n floats per workgroup: up to `budget` bytes of LDS (several workgroups per CU overlap one's staging
 // with another's streaming), at most 8 (index registers reused across them); 0 = a row does not fit 64 KB
@@ -317,7 +327,7 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
         const long long wgs = (long long)b * nrg * lsplit;
         PDM_REQUIRE(wgs <= 0x7fffffffll, PDM_E_TOOLARGE, "group_points: %lld workgroups", wgs);
         const size_t lds = (size_t)rpw * row_bytes;
-#define GPR_LAUNCH(T, U, X) hipLaunchKernelGGL((group_points_rows_kernel<T, U, X>), dim3((unsigned)wgs), dim3(T), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out)
+#define GPR_LAUNCH(T, U, X) hipLaunchKernelGGL((group_points_rows_kernel<T, U, X>), dim3((unsigned)wgs), dim3(T), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out, g_gp_nt)
         if (variant == 3) {            // diagnostic: plain unit order (no XCD grouping)
             if (threads == 256) GPR_LAUNCH(256, 4, false); else if (threads == 512) GPR_LAUNCH(512, 4, false); else GPR_LAUNCH(1024, 4, false);
         } else if (uq == 1) {
@@ -334,13 +344,13 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
     if (rpw > 0 && L >= 4 * n && (long long)b * divup(c, rpw) >= 512) {
         dim3 grid(divup(c, rpw), b);
         hipLaunchKernelGGL(group_points_lds_kernel, grid, dim3(GPL_THREADS), (size_t)rpw * n * sizeof(float),
-                           as_stream(stream), c, n, L, rpw, points, idx, out);
+                           as_stream(stream), c, n, L, rpw, points, idx, out, g_gp_nt);
         return check_launch("group_points");
     }
     if (L % 4 == 0 && aligned16(idx) && aligned16(out)) {
         dim3 grid(divup(L / 4, GP_THREADS), divup(c, GP_CG), b);
         hipLaunchKernelGGL(group_points_v4_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream), c, n,
-                           L, points, idx, out);
+                           L, points, idx, out, g_gp_nt);
     } else {
         dim3 grid(divup(L, GP_THREADS), divup(c, GP_CG), b);
         hipLaunchKernelGGL(group_points_scalar_kernel, grid, dim3(GP_THREADS), 0, as_stream(stream),

@@ -56,7 +56,10 @@ with torch.no_grad():
             forms = (("quad", 1, 16, 96, 16), ("auto", 3, 16, 96, 16)) if "--lib" in sys.argv else \
                 (("quad", 1, 16, 96, 16), ("quad, 4-wave small scans", 1, 16, 96, 4), ("lane cpw16", 2, 16, 96, 16), ("lane cpw16 heavy32", 2, 16, 32, 16),
                  ("lane cpw64", 2, 64, 96, 16), ("by density", 3, 16, 96, 16))
+            if "--group-nt" in sys.argv:
+                forms = (("quad", 1, 16, 96, 16), ("quad, non-temporal group stores", 1, 16, 96, 16 + 256))
             for name, form, cpw, heavy, sw in forms:
+                l.pdm_tune_group_nt(1 if sw >= 256 else 0); sw &= 255
                 l.pdm_tune_bq_quad(form); l.pdm_tune_bq_cpw(cpw); l.pdm_tune_bq_heavy(heavy); l.pdm_tune_bq_small_waves(sw)
                 us = graph_us(fn)
-                print(f"{kind:8s} {name:26s}: {us:7.1f} us = {1676.79e3 / us / 8000:.3f} of 8 TB/s", flush=True)
+                print(f"{kind:8s} {name:34s}: {us:7.1f} us = {1676.79e3 / us / 8000:.3f} of 8 TB/s", flush=True)

@@ -6,9 +6,7 @@ import torch
 from pdm_ssd_amd import _native
 dev = torch.device("cuda:0"); l = _native.lib()
 n = 1024 * 1024 * 1024 // 4
-src = torch.empty(n, dtype=torch.float32, device=dev).normal_(); dsl.pdm_tune_copy_variant(-1); l.pdm_tune_copy_max_wg(8192)
-print(f"default (variant by size, cap 8192): {rate():.1f} GB/s")
-t = torch.empty_like(src)
+src = torch.empty(n, dtype=torch.float32, device=dev).normal_(); dst = torch.empty_like(src)
 def rate(iters=10):
     _native.copy_many([dst], [src]); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,6 +18,7 @@ for _ in range(3): rate()
 for wg in (1024, 2048, 4096, 8192):
     l.pdm_tune_copy_max_wg(wg)
     print(f"grid cap {wg:5d}: " + "  ".join(f"v{v}={(l.pdm_tune_copy_variant(v), rate())[1]:7.1f}" for v in range(8)) + "  GB/s", flush=True)
+l.pdm_tune_copy_variant(-1); l.pdm_tune_copy_max_wg(8192)
 l.pdm_tune_copy_variant(-1); l.pdm_tune_copy_max_wg(8192)
 print(f"default (variant by size, cap 8192): {rate():.1f} GB/s")
 t = torch.empty_like(src)
