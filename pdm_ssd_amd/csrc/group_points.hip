@@ -267,7 +267,7 @@ __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long
 // tuning knob (tools/diag/group_sweep.py): 0 = heuristics; else variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel without
 // the XCD unit order) | rpw << 4 | lsplit << 8 | (threads / 256) << 16 | quads per lane and pass << 20
 static int g_gp_tune = 0;
-static int g_gp_nt = 0;      // 1: non-temporal stores of the grouped outputs
+static int g_gp_nt = 1;      // 1 (default): non-temporal stores of the grouped outputs (455 against 458-463 us on the target block)
 extern "C" int pdm_tune_group_nt(int on) { const int old = g_gp_nt; g_gp_nt = on != 0; return old; }
 
 // rows of n floats per workgroup: up to `budget` bytes of LDS (several workgroups per CU overlap one's staging
