@@ -542,6 +542,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_pair_kernel(RowsChai
 #define FPC_LATE 1   // with a skip GEMM, request the z rows behind it (0: under it — 23 spilled registers at FP2's widths, 246 us against 237)
 #endif
 struct FpChainArgs {
+    int nt_out;                 // 1: the output rows leave through non-temporal stores (they are read much later, by another
+                                // kernel; kept out of the L2 they no longer displace the z rows the gathers come back for)
     int rows, n, m, c_skip, z_stride;
     const float *z, *skip, *weight;
     const int *idx;
@@ -695,8 +697,10 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
             float *__restrict__ orow = a.out + (size_t)lr[h] * a.out_stride + 16 * mb0;
             const f4 v = stage[(grow + 8 * h) * SQ + gq + 8 * j];
             const int c0 = 16 * mb0 + 4 * (gq + 8 * j);
-            if (c0 + 4 <= a.cout) *reinterpret_cast<f4 *>(orow + 4 * (gq + 8 * j)) = v;
-            else {
+            if (c0 + 4 <= a.cout) {
+                if (a.nt_out) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(orow + 4 * (gq + 8 * j)));
+                else *reinterpret_cast<f4 *>(orow + 4 * (gq + 8 * j)) = v;
+            } else {
                 if (c0 < a.cout) orow[4 * (gq + 8 * j)] = v.x;
                 if (c0 + 1 < a.cout) orow[4 * (gq + 8 * j) + 1] = v.y;
                 if (c0 + 2 < a.cout) orow[4 * (gq + 8 * j) + 2] = v.z;
@@ -732,6 +736,8 @@ static int g_rc_dw_xcd = 1;       // heat-map kernel: patches dealt to the XCDs 
 extern "C" int pdm_tune_rows_chain_xcd(int on) { const int old = g_rc_dw_xcd; g_rc_dw_xcd = on != 0; return old; }
 static int g_rc_wg_per_cu = 12;   // grid cap of the chain kernels = 256 CUs x this many workgroups (2 are resident at a time)
 extern "C" int pdm_tune_rows_chain_wg_per_cu(int n) { const int old = g_rc_wg_per_cu; if (n > 0) g_rc_wg_per_cu = n; return old; }
+static int g_fpc_nt = 0;        // FP chain kernel: non-temporal output stores
+extern "C" int pdm_tune_fp_chain_nt(int on) { const int old = g_fpc_nt; g_fpc_nt = on != 0; return old; }
 static int g_fpc_pad_lds = 0;   // diagnostic: extra dynamic LDS per workgroup (forces one workgroup per CU at 90 KB)
 extern "C" int pdm_tune_fp_chain_pad_lds(int bytes) { const int old = g_fpc_pad_lds; g_fpc_pad_lds = bytes; return old; }
 
@@ -743,6 +749,7 @@ int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *
     const long long rows = (long long)b * n;
     if (rows < 32768 || rows >= (1ll << 31) || (long long)b * m * z_stride >= (1ll << 31)) return 0;
     FpChainArgs a{};
+    a.nt_out = g_fpc_nt;
     a.rows = (int)rows; a.n = n; a.m = m; a.c_skip = c_skip; a.z_stride = z_stride;
     a.z = z_pm; a.skip = skip_pm; a.weight = weight; a.idx = idx; a.wpack = wpack; a.bias = bias;
     a.woff[0] = 0; a.boff[0] = 0; a.woff[1] = dims[0] * dims[1]; a.boff[1] = dims[1];

@@ -60,3 +60,30 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libpdmssd_oracle" not in src, f
+
+
+def test_new_entry_points_validate_their_arguments_before_any_launch():
+    """Round-4 entry points return an error code + message for arguments they cannot serve (no GPU is touched: the checks
+    come first), as the rest of the ABI does instead of the reference's exit(-1)."""
+    import ctypes as C
+
+    from pdm_ssd_amd import _native
+    lib = _native.lib()
+    dims_ok = (C.c_int * 4)(128, 256, 256, 16)
+    dims_bad = (C.c_int * 4)(128, 128, 128, 16)
+    assert lib.pdm_rows_mlp_x3_stream_bytes(3, C.cast(dims_ok, C.c_void_p)) == 25 * 24 * 1024
+    assert lib.pdm_rows_mlp_x3_stream_bytes(3, C.cast(dims_bad, C.c_void_p)) == 0
+    buf = (C.c_float * 64)()
+    ptr = C.cast(buf, C.c_void_p)
+    with pytest.raises(_native.NativeLibraryError, match="only 128 -> 256 -> 256"):
+        _native.call("pdm_rows_mlp_x3", 0, 64, 128, ptr, 3, C.cast(dims_bad, C.c_void_p), ptr, 1 << 20, ptr, 0, ptr, 16, 8)
+    with pytest.raises(_native.NativeLibraryError, match="weight stream"):
+        _native.call("pdm_rows_mlp_x3", 0, 64, 128, ptr, 3, C.cast(dims_ok, C.c_void_p), ptr, 1024, ptr, 0, ptr, 16, 8)
+    assert lib.pdm_point_head_loss_workspace_bytes(1000) == 16 + 4 * 2 * 4
+    with pytest.raises(_native.NativeLibraryError, match="multiple of n_per_sample"):
+        _native.call("pdm_point_head_loss", 0, 1000, 300, 4, 3, 3, 0, ptr, 3, ptr, 8, ptr, 4, ptr, ptr, ptr, ptr, ptr, 0.1, 0.25, 2.0, 1.0, 1.0,
+                     ptr, ptr, ptr, ptr, ptr, 1 << 20)
+    with pytest.raises(_native.NativeLibraryError, match="workspace too small"):
+        _native.call("pdm_point_head_loss", 0, 1000, 500, 4, 3, 3, 0, ptr, 3, ptr, 8, ptr, 4, ptr, ptr, ptr, ptr, ptr, 0.1, 0.25, 2.0, 1.0, 1.0,
+                     ptr, ptr, ptr, ptr, ptr, 8)
+
