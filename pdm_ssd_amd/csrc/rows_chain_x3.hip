@@ -38,6 +38,13 @@ typedef float x3_f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) x3_u4 *x3_gu4c;
 
 constexpr int X3_THREADS = 256;
+#ifndef X3_PAIR
+#define X3_PAIR 0         // 1: two output blocks per step, their MFMAs interleaved.  Measured: NOT faster — the bare MFMA stream
+                          // (X3_DIAG 15) 0.755 against 0.707 ms, the product 1.14 ms with 18 spilled registers against 1.03-1.07:
+                          // six dependent v_mfma_f32_16x16x32_bf16 in a row issue at the rate of independent ones
+#endif
+#define X3_AN (X3_PAIR ? 6 : 3)
+#define an2 an
 #ifndef X3_DIAG
 #define X3_DIAG 0         // timing builds (results wrong): 1 every fetch reads chunk 0 (cache-hot), 2 no barriers, 4 no re-splitting of activations, 8 no fragment reads
 #endif
@@ -124,13 +131,37 @@ __device__ __forceinline__ void x3_stash(const x3_u4 (&r)[6], x3_u4 *buf, int t)
         x3_mac(ACC, a_, BFRAG);                                                                                    \
     }
 
+// Two steps at once (X3_PAIR): the 12 MFMAs of two output blocks alternate between the two accumulators, so no MFMA waits for the
+// one issued just before it; `an` holds the six fragments of the pair about to run.
+__device__ __forceinline__ void x3_mac2(x3_f4 &c0, x3_f4 &c1, const x3_u4 (&a)[6], const x3_u4 (&b0)[3], const x3_u4 (&b1)[3]) {
+    c0 = x3_mfma(a[2], b0[0], c0); c1 = x3_mfma(a[5], b1[0], c1);
+    c0 = x3_mfma(a[0], b0[2], c0); c1 = x3_mfma(a[3], b1[2], c1);
+    c0 = x3_mfma(a[1], b0[1], c0); c1 = x3_mfma(a[4], b1[1], c1);
+    c0 = x3_mfma(a[1], b0[0], c0); c1 = x3_mfma(a[4], b1[0], c1);
+    c0 = x3_mfma(a[0], b0[1], c0); c1 = x3_mfma(a[3], b1[1], c1);
+    c0 = x3_mfma(a[0], b0[0], c0); c1 = x3_mfma(a[3], b1[0], c1);
+}
+#define X3_STEP2(S, ACC0, ACC1, B0, B1)                                                                            \
+    {                                                                                                              \
+        x3_u4 a_[6];                                                                                               \
+        _Pragma("unroll") for (int f_ = 0; f_ < 6; ++f_) a_[f_] = an2[f_];                                        \
+        if ((S) < 6) {                                                                                             \
+            if (!(X3_DIAG & 8)) { _Pragma("unroll") for (int f_ = 0; f_ < 6; ++f_) an2[f_] = buf[(((S) + 2) * 3 + f_) * 64]; } \
+        } else {                                                                                                   \
+            x3_stash(r, lds + (p ^ 1) * X3_CHUNK_U4, t);                                                           \
+            if (!(X3_DIAG & 2)) __syncthreads();                                                                   \
+            _Pragma("unroll") for (int f_ = 0; f_ < 6; ++f_) an2[f_] = nbuf[f_ * 64];                              \
+        }                                                                                                          \
+        x3_mac2(ACC0, ACC1, a_, B0, B1);                                                                           \
+    }
+
 // One layer with NK k-blocks (32 channels each) in and NMB >= 4 output blocks (16 channels each): NMB / 4 x NK / 2 chunks, k inner;
 // chunk layout: step (kbi, i) = kbi * 4 + i.  On entry buffer p holds this layer's first chunk and `an` its step 0; on exit the
 // same for what follows in the stream.  `c` = running chunk number (wraps at `total`).
 template <int NK, int NMB>
 __device__ __forceinline__ void x3_layer(const x3_u4 (&in)[NK][3], x3_f4 (&acc)[NMB], const float *__restrict__ bias,
                                          const unsigned *__restrict__ wstream, int &c, int total, x3_u4 *lds, int &p, int t, int lane,
-                                         x3_u4 (&an)[3]) {
+                                         x3_u4 (&an)[X3_AN]) {
     static_assert(NK % 2 == 0 && NMB % 4 == 0, "x3_layer: whole chunks");
     const int g = lane >> 4;
 #pragma unroll
@@ -143,11 +174,20 @@ __device__ __forceinline__ void x3_layer(const x3_u4 (&in)[NK][3], x3_f4 (&acc)[
             const int nxt = c + 1 == total ? 0 : c + 1;
             x3_fetch(r, wstream, nxt, t);
             const x3_u4 *buf = lds + p * X3_CHUNK_U4 + lane, *nbuf = lds + (p ^ 1) * X3_CHUNK_U4 + lane;
+#if X3_PAIR
+#pragma unroll
+            for (int kbi = 0; kbi < 2; ++kbi) {
+#pragma unroll
+                for (int i = 0; i < 4; i += 2)
+                    X3_STEP2(kbi * 4 + i, acc[4 * mg + i], acc[4 * mg + i + 1], in[2 * kg + kbi], in[2 * kg + kbi])
+            }
+#else
 #pragma unroll
             for (int kbi = 0; kbi < 2; ++kbi) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) X3_STEP(kbi * 4 + i, acc[4 * mg + i], in[2 * kg + kbi])
             }
+#endif
             p ^= 1;
             c = nxt;
         }
@@ -157,7 +197,7 @@ __device__ __forceinline__ void x3_layer(const x3_u4 (&in)[NK][3], x3_f4 (&acc)[
 template <int NK>
 __device__ __forceinline__ void x3_last_layer(const x3_u4 (&in)[NK][3], x3_f4 &acc, const float *__restrict__ bias,
                                               const unsigned *__restrict__ wstream, int &c, int total, x3_u4 *lds, int &p, int t, int lane,
-                                              x3_u4 (&an)[3]) {
+                                              x3_u4 (&an)[X3_AN]) {
     static_assert(NK == 8, "x3_last_layer: 8 k-blocks x 3 pieces = one chunk");
     const int g = lane >> 4;
     acc = *reinterpret_cast<const x3_f4 *>(bias + 4 * g);
@@ -165,8 +205,15 @@ __device__ __forceinline__ void x3_last_layer(const x3_u4 (&in)[NK][3], x3_f4 &a
     const int nxt = c + 1 == total ? 0 : c + 1;
     x3_fetch(r, wstream, nxt, t);
     const x3_u4 *buf = lds + p * X3_CHUNK_U4 + lane, *nbuf = lds + (p ^ 1) * X3_CHUNK_U4 + lane;
+#if X3_PAIR
+    x3_f4 acc1 = x3_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NK; kb += 2) X3_STEP2(kb, acc, acc1, in[kb], in[kb + 1])
+    acc += acc1;
+#else
 #pragma unroll
     for (int kb = 0; kb < NK; ++kb) X3_STEP(kb, acc, in[kb])
+#endif
     p ^= 1;
     c = nxt;
 }
@@ -203,9 +250,9 @@ __global__ __launch_bounds__(X3_THREADS, 2) void rows_chain_x3_kernel(RowsChainX
         x3_stash(r, lds, t);
     }
     __syncthreads();
-    x3_u4 an[3];
+    x3_u4 an[X3_AN];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) an[pl] = lds[pl * 64 + lane];
+    for (int pl = 0; pl < X3_AN; ++pl) an[pl] = lds[pl * 64 + lane];
     x3_f4 xn[2 * NK0];       // the next tile's input rows (raw fp32), requested under this tile's second layer
     for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         asm volatile("" : "+s"(wstream));     // keeps the chunk addresses from being hoisted out of the loop as ~50 invariants
