@@ -640,7 +640,14 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
     __syncthreads();
     f4 an[4];
     rc_first_fragments(an, lds, 0, lane);
-    for (long long u = first; u < last; u += step) {
+    // A workgroup takes CONSECUTIVE tiles (u = first * per_wg + k).  With u = first + k * step the workgroups resident on an XCD at one
+    // time (64 of its 384) moved on to tiles `step` further along after their first one — a different cloud — so one L2 held the z
+    // rows of up to three clouds (6 MB against its 4 MB) and every tile's 192 scattered row gathers missed: FETCH 292 MB per FP1
+    // launch for 80 MB of distinct rows (PMC).
+    const long long per_wg = (last + step - 1) / step;
+    for (long long k = 0; k < per_wg; ++k) {
+        const long long u = first * per_wg + k;
+        if (u >= last) break;
         const long long tl = tile_of(u);
         asm volatile("" : "+s"(w1), "+s"(w2));
         const long long wrow0 = tl * 64 + 16 * wave;
@@ -736,7 +743,7 @@ static int g_rc_dw_xcd = 1;       // heat-map kernel: patches dealt to the XCDs 
 extern "C" int pdm_tune_rows_chain_xcd(int on) { const int old = g_rc_dw_xcd; g_rc_dw_xcd = on != 0; return old; }
 static int g_rc_wg_per_cu = 12;   // grid cap of the chain kernels = 256 CUs x this many workgroups (2 are resident at a time)
 extern "C" int pdm_tune_rows_chain_wg_per_cu(int n) { const int old = g_rc_wg_per_cu; if (n > 0) g_rc_wg_per_cu = n; return old; }
-static int g_fpc_nt = 0;        // FP chain kernel: non-temporal output stores
+static int g_fpc_nt = 0;        // FP chain kernel: non-temporal output stores (off: no change in time or in PMC traffic; the rows are the point head's input next)
 extern "C" int pdm_tune_fp_chain_nt(int on) { const int old = g_fpc_nt; g_fpc_nt = on != 0; return old; }
 static int g_fpc_pad_lds = 0;   // diagnostic: extra dynamic LDS per workgroup (forces one workgroup per CU at 90 KB)
 extern "C" int pdm_tune_fp_chain_pad_lds(int bytes) { const int old = g_fpc_pad_lds; g_fpc_pad_lds = bytes; return old; }
