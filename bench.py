@@ -903,6 +903,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _native.lib()  # fail loudly now if the HIP library is missing
+    if os.environ.get("PDM_FP_CHAIN_MASK"):      # A/B knob: which FP shapes take the register-resident chain kernel
+        _native.lib().pdm_tune_fp_chain_mask(int(os.environ["PDM_FP_CHAIN_MASK"]))
 
     B, N = args.batch, args.points
     scaling = "weak"

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "pdm_tune_rows_x3_wg_per_cu": None,
     "pdm_tune_fp_chain_pad_lds": None,
     "pdm_tune_fp_chain_nt": None,
+    "pdm_tune_fp_chain_mask": None,
     "pdm_tune_rows_chain_wg_per_cu": None,
     "pdm_tune_rows_chain_xcd": None,
     "pdm_tune_fused_swz": None,

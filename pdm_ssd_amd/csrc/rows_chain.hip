@@ -745,6 +745,12 @@ static int g_rc_wg_per_cu = 12;   // grid cap of the chain kernels = 256 CUs x t
 extern "C" int pdm_tune_rows_chain_wg_per_cu(int n) { const int old = g_rc_wg_per_cu; if (n > 0) g_rc_wg_per_cu = n; return old; }
 static int g_fpc_nt = 0;        // FP chain kernel: non-temporal output stores (off: no change in time or in PMC traffic; the rows are the point head's input next)
 extern "C" int pdm_tune_fp_chain_nt(int on) { const int old = g_fpc_nt; g_fpc_nt = on != 0; return old; }
+// which FP shapes take the chain kernel: bit 0 the FP1 shape, bit 1 the FP2 shape (else the LDS-tiled forms).  Default 2: with the
+// backbone's REAL three-NN indices (spatially local gathers) the LDS-tiled kernel runs FP1 in 243 us against 252-268 us for the
+// chain (tools/diag/fp_chain_rate.py --real; round 2 chose the chain on random indices: 258 against 275) and moves ~410 MB per
+// launch against 449-570; FP2 stays on the chain (209 against 276 us).  The pipelined step is the same either way (4.45-4.50 ms).
+static int g_fpc_mask = 2;
+extern "C" int pdm_tune_fp_chain_mask(int m) { const int old = g_fpc_mask; if (m >= 0) g_fpc_mask = m & 3; return old; }
 static int g_fpc_pad_lds = 0;   // diagnostic: extra dynamic LDS per workgroup (forces one workgroup per CU at 90 KB)
 extern "C" int pdm_tune_fp_chain_pad_lds(int bytes) { const int old = g_fpc_pad_lds; g_fpc_pad_lds = bytes; return old; }
 
@@ -771,8 +777,8 @@ int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *
         *launched = 1;                                                                                               \
         return check_launch("fp_mlp_fused_pre(chain)");                                                              \
     }
-    FC_TRY(0, 8, 8, c_skip <= 4 && dims[0] == 16)                               // FP1: raw input channels -> 128 -> 128
-    FC_TRY(6, 16, 16, c_skip % 4 == 0 && c_skip > 4 && dims[0] == 96)           // FP2: 96 skip channels -> 256 -> 256
+    FC_TRY(0, 8, 8, (g_fpc_mask & 1) && c_skip <= 4 && dims[0] == 16)                               // FP1: raw input channels -> 128 -> 128
+    FC_TRY(6, 16, 16, (g_fpc_mask & 2) && c_skip % 4 == 0 && c_skip > 4 && dims[0] == 96)           // FP2: 96 skip channels -> 256 -> 256
 #undef FC_TRY
     return 0;
 }
