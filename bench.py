@@ -1045,6 +1045,7 @@ def main():
     KERNELS_OF = {"pdm_sa_mlp_fused": ("pdm::sa_mlp_fused_kernel", "pdm::sa_reg_mlp_kernel"),
                   "pdm_sa_mlp_fused_pre": ("pdm::sa_mlp_fused_kernel",),
                   "pdm_sa_mlp_packed": ("pdm::sa_packed_fused_kernel", "pdm::sa_reg_packed_kernel"),
+                  "pdm_sa_mlp_packed_pair": ("pdm::sa_packed_pair_kernel", "pdm::sa_reg_packed_kernel"),   # both scales of a level
                   "pdm_fp_mlp_fused": ("pdm::fp_mlp_fused_kernel",),
                   "pdm_fp_mlp_fused_pre": ("pdm::fp_chain_kernel", "pdm::fp_mlp_fused_kernel"),   # FP1-2 chain, FP3-4 tiled
                   "pdm_bev_head_fused": ("pdm::rows_chain_kernel<8, 4, 4, 1, true>",),

@@ -291,6 +291,18 @@ int pdm_sa_mlp_packed(void *stream, int b, int n, int m, int cin, int nsample, c
                       const int *pack, const int *meta, int nlayers, const int *dims, const float *wpack,
                       const float *bias, float *out_pm, int out_stride, int out_coff, int cout);
 
+/* The two scales of an MSG level (pointnet2_modules.py:58-99: the same centres, two radii / MLPs) in ONE launch: per-scale
+ * arguments as HOST arrays of two (nsample, z_coff, pack, meta, nlayers, dims, wpack, bias, out_coff, cout), the level's xyz /
+ * new_xyz / feat_pm / z_pm / out_pm shared.  One launch where both scales map to the same kernel instantiation (the deep levels
+ * of PointNet2MSG: a few hundred row tiles per scale, which two launches run one after the other on a mostly idle chip),
+ * otherwise two pdm_sa_mlp_packed launches; bit-identical either way. */
+int pdm_sa_mlp_packed_pair(void *stream, int b, int n, int m, int cin, const int *nsample, const float *xyz,
+                           const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride, const int *z_coff,
+                           const int *const *pack, const int *const *meta, const int *nlayers, const int *const *dims,
+                           const float *const *wpack, const float *const *bias, float *out_pm, int out_stride,
+                           const int *out_coff, const int *cout);
+int pdm_tune_sa_pair(int on);          /* 0: always two launches */
+
 /* ---- pointnet2_stack: ragged ("stacked") batches -----------------------
  * One entry per function of the reference's pointnet2_stack_cuda extension that the PointNet++ modules use
  * (pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp): points of all samples concatenated, per-sample

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused_pre": [_i] * 4 + [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_sa_pack": [_i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    "pdm_sa_mlp_packed_pair": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "pdm_sa_mlp_packed": [_i] * 5 + [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_interp_concat_rows": [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "pdm_interp_concat_rows_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
@@ -125,6 +126,7 @@ _SIGNATURES = {
     "pdm_tune_fused_gemm": None,
     "pdm_tune_fused_chain": None,
     "pdm_tune_fused_pair": None,
+    "pdm_tune_sa_pair": None,
     "pdm_tune_rows_x3_wg_per_cu": None,
     "pdm_tune_fp_chain_pad_lds": None,
     "pdm_tune_fp_chain_nt": None,

@@ -715,11 +715,9 @@ __device__ __forceinline__ int pack_tile_L(int row, int m1, int m2, int m3, int 
 // NT = 1 in two sub-steps.  The number of pairs is read from meta[6] (device memory): the grid is sized for the worst
 // case and surplus workgroups leave at once.
 template <int W, int NT, int MAXNB, int PSW, bool PRE>
-__global__ __launch_bounds__(64 * W * PSW) void sa_packed_fused_kernel(MlpDesc d, SaArgs a,
-                                                                       const int2 *__restrict__ pack,
-                                                                       const int *__restrict__ meta,
-                                                                       const float *__restrict__ wpack,
-                                                                       const float *__restrict__ bias) {
+__device__ __forceinline__ void sa_packed_body(const MlpDesc &d, const SaArgs &a, const int2 *__restrict__ pack,
+                                               const int *__restrict__ meta, const float *__restrict__ wpack,
+                                               const float *__restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = wave_all % W, grp = wave_all / W;
@@ -765,6 +763,30 @@ __global__ __launch_bounds__(64 * W * PSW) void sa_packed_fused_kernel(MlpDesc d
             run_mlp<W, NT, MAXNB, PSW, PRE>(d, wpack, bias, P, Q, lane, wave, TilesIn<SaIn<PRE>, NT>{&in}, TilesOut<SegPoolOut, NT>{&out});
         }
     }
+}
+template <int W, int NT, int MAXNB, int PSW, bool PRE>
+__global__ __launch_bounds__(64 * W * PSW) void sa_packed_fused_kernel(MlpDesc d, SaArgs a,
+                                                                       const int2 *__restrict__ pack,
+                                                                       const int *__restrict__ meta,
+                                                                       const float *__restrict__ wpack,
+                                                                       const float *__restrict__ bias) {
+    sa_packed_body<W, NT, MAXNB, PSW, PRE>(d, a, pack, meta, wpack, bias);
+}
+// The two scales of an SA level in ONE launch (blockIdx.y = scale): with compacted lists a deep level holds a few hundred row
+// tiles per scale (SA4 on BASELINE's uniform clouds: 64 tile pairs = 64 busy workgroups on 256 CUs, each a ~65 us chain of
+// weight fragments), so two launches one after the other leave most of the chip idle twice; side by side they take the time of
+// one.  Both scales must map to the same instantiation (same waves / tiles / groups / hoisting); results are bit-identical.
+struct SaScale {
+    MlpDesc d;
+    SaArgs a;
+    const int2 *pack;
+    const int *meta;
+    const float *wpack, *bias;
+};
+template <int W, int NT, int MAXNB, int PSW, bool PRE>
+__global__ __launch_bounds__(64 * W * PSW) void sa_packed_pair_kernel(SaScale s0, SaScale s1) {
+    if (blockIdx.y == 0) sa_packed_body<W, NT, MAXNB, PSW, PRE>(s0.d, s0.a, s0.pack, s0.meta, s0.wpack, s0.bias);
+    else sa_packed_body<W, NT, MAXNB, PSW, PRE>(s1.d, s1.a, s1.pack, s1.meta, s1.wpack, s1.bias);
 }
 
 template <int W, int NT, int MAXNB, int PSW, bool PRE>
@@ -1265,13 +1287,23 @@ extern "C" int pdm_tune_fused_tiles(int t) { const int old = g_fused_tiles; g_fu
         else FUSED_LAUNCH1(KERNEL, 8, 1, blocks, lds_bytes, __VA_ARGS__);                                      \
     } while (0)
 
-static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
-                           const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride,
-                           int z_coff, const int *idx, int nlayers, const int *dims, const float *wpack,
-                           const float *bias, float *out_pm, int out_stride, int out_coff, int cout,
-                           const int *pack = nullptr, const int *meta = nullptr) {
+// Everything sa_fused_launch decides before launching: argument checks, layer descriptor, kernel arguments, workgroup shape.
+struct SaPlan {
+    MlpDesc d;
+    SaArgs a;
+    int W, NT, G, blocks;
+    size_t lds_bytes;
+    bool pre_form, packed, reg;     // reg: the register-resident kernels (small scales) apply
+    int b1, b2, b3;
+    long long cap_pairs;
+    const int2 *pack2;
+};
+static int sa_plan(int b, int n, int m, int cin, int nsample, const float *xyz, const float *new_xyz, const float *feat_pm,
+                   const float *z_pm, int z_stride, int z_coff, const int *idx, int nlayers, const int *dims, const float *wpack,
+                   const float *bias, float *out_pm, int out_stride, int out_coff, int cout, const int *pack, const int *meta, SaPlan &pl) {
     PDM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && cin >= 0 && nsample > 0, PDM_E_BADARG, "sa_mlp_fused: bad size");
     PDM_REQUIRE(nsample % 16 == 0, PDM_E_BADARG, "sa_mlp_fused: nsample=%d must be a multiple of 16", nsample);
+    pl.blocks = 0;
     if (b == 0 || m == 0) return 0;
     PDM_REQUIRE(xyz && new_xyz && (idx || (pack && meta)) && wpack && bias && out_pm && (cin == 0 || feat_pm), PDM_E_BADARG,
                 "sa_mlp_fused: null pointer");
@@ -1281,9 +1313,10 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
         PDM_REQUIRE((long long)b * m * nsample + 256 < (1ll << 31) && (reinterpret_cast<uintptr_t>(pack) & 7) == 0,
                     PDM_E_BADARG, "sa_mlp_packed: row list too long or misaligned");
     }
-    const int2 *pack2 = reinterpret_cast<const int2 *>(pack);
-    const long long cap_pairs = (long long)pdm_sa_pack_rows(b, m, nsample) / 32;
-    MlpDesc d;
+    pl.packed = packed;
+    pl.pack2 = reinterpret_cast<const int2 *>(pack);
+    pl.cap_pairs = (long long)pdm_sa_pack_rows(b, m, nsample) / 32;
+    MlpDesc &d = pl.d;
     int W = 1, NT = 1, G = 1;
     const long long sa_tiles = (long long)b * m * (nsample / 16);
     int rc = fill_desc("sa_mlp_fused", d, nlayers, dims, cin + 3,
@@ -1301,14 +1334,42 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
                     (reinterpret_cast<uintptr_t>(wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
                     (cin % 4 != 0 || (reinterpret_cast<uintptr_t>(feat_pm) & 15) == 0),
                 PDM_E_BADARG, "sa_mlp_fused: out/wpack/bias/feat must be 16-byte aligned, out_stride and out_coff multiples of 4");
-    SaArgs a{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout, z_pm, z_stride, z_coff};
-    const bool pre_form = z_pm != nullptr;
-    const size_t lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
-    PDM_REQUIRE(lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", lds_bytes);
-    if (g_fused_reg && !pre_form && nlayers == 3 && d.K[0] == 16 && (long long)b * m * nsample < (1ll << 31) &&
-        (long long)b * n * (cin > 3 ? cin : 3) < (1ll << 31)) {
+    pl.a = SaArgs{b, n, m, cin, nsample, xyz, new_xyz, feat_pm, idx, out_pm, out_stride, out_coff, cout, z_pm, z_stride, z_coff};
+    pl.pre_form = z_pm != nullptr;
+    pl.lds_bytes = (size_t)G * (NT * 16 * (d.lds_p + d.lds_q) + d.K[nlayers]) * sizeof(float);
+    PDM_REQUIRE(pl.lds_bytes <= 160 * 1024, PDM_E_TOOLARGE, "sa_mlp_fused: needs %zu bytes of LDS", pl.lds_bytes);
+    pl.W = W; pl.NT = NT; pl.G = G;
+    pl.b1 = d.K[1] >> 4; pl.b2 = d.K[2] >> 4; pl.b3 = d.K[3] >> 4;
+    pl.reg = g_fused_reg && !pl.pre_form && nlayers == 3 && d.K[0] == 16 && (long long)b * m * nsample < (1ll << 31) &&
+             (long long)b * n * (cin > 3 ? cin : 3) < (1ll << 31) &&
+             ((pl.b1 == 1 && pl.b2 == 1 && pl.b3 == 2) || (pl.b1 == 2 && pl.b2 == 2 && pl.b3 == 4));
+    const int tpc_ = nsample / 16;
+    const long long units_ = packed ? pl.cap_pairs : tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
+    const long long niter = (units_ + G - 1) / G;
+    const long long cap = (long long)256 * g_fused_wg_per_cu;
+    pl.blocks = (int)(niter < cap ? niter : cap);
+    return 0;
+}
+
+static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
+                           const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride,
+                           int z_coff, const int *idx, int nlayers, const int *dims, const float *wpack,
+                           const float *bias, float *out_pm, int out_stride, int out_coff, int cout,
+                           const int *pack = nullptr, const int *meta = nullptr) {
+    SaPlan pl;
+    if (int rc = sa_plan(b, n, m, cin, nsample, xyz, new_xyz, feat_pm, z_pm, z_stride, z_coff, idx, nlayers, dims, wpack, bias, out_pm,
+                         out_stride, out_coff, cout, pack, meta, pl)) return rc;
+    if (b == 0 || m == 0) return 0;
+    const MlpDesc &d = pl.d;
+    const SaArgs &a = pl.a;
+    const int W = pl.W, NT = pl.NT, G = pl.G, blocks = pl.blocks;
+    const bool pre_form = pl.pre_form, packed = pl.packed;
+    const size_t lds_bytes = pl.lds_bytes;
+    const int2 *pack2 = pl.pack2;
+    const long long cap_pairs = pl.cap_pairs;
+    if (pl.reg) {
         // small scales: the whole MLP stays in registers (weights, activations), one wave per tile pair
-        const int b1 = d.K[1] >> 4, b2 = d.K[2] >> 4, b3 = d.K[3] >> 4;
+        const int b1 = pl.b1, b2 = pl.b2, b3 = pl.b3;
         const long long centres = (long long)b * m;
         const long long units = nsample >= 32 ? centres : (centres + 1) / 2;
         const long long want = (units + 3) / 4, capr = 256 * 8;
@@ -1329,11 +1390,6 @@ static int sa_fused_launch(void *stream, int b, int n, int m, int cin, int nsamp
         PDM_REG_LAUNCH(2, 2, 4)
 #undef PDM_REG_LAUNCH
     }
-    const int tpc_ = nsample / 16;
-    const long long units_ = packed ? cap_pairs : tpc_ >= NT ? (long long)b * m : ((long long)b * m + NT / tpc_ - 1) / (NT / tpc_);
-    const long long niter = (units_ + G - 1) / G;
-    const long long cap = (long long)256 * g_fused_wg_per_cu;
-    const int blocks = (int)(niter < cap ? niter : cap);
     if (packed) {
         FUSED_DISPATCH(sa_packed_fused_kernel, W, G, blocks, lds_bytes, d, a, pack2, meta, wpack, bias);
         return check_launch("sa_mlp_packed");
@@ -1374,6 +1430,41 @@ extern "C" int pdm_sa_mlp_packed(void *stream, int b, int n, int m, int cin, int
     return sa_fused_launch(stream, b, n, m, z_pm ? 0 : cin, nsample, xyz, new_xyz, z_pm ? nullptr : feat_pm, z_pm,
                            z_stride, z_coff, nullptr, nlayers, dims, wpack, bias, out_pm, out_stride, out_coff, cout,
                            pack, meta);
+}
+
+// Both scales of an SA level over their compacted lists in ONE launch where they map to the same kernel instantiation (the deep
+// levels of PointNet2MSG do; see sa_packed_pair_kernel), otherwise two pdm_sa_mlp_packed launches.  Per-scale arguments come as
+// arrays of two; xyz / new_xyz / feat_pm / z_pm / out_pm are the level's.  Bit-identical to the two calls.
+static int g_sa_pair = 1;
+extern "C" int pdm_tune_sa_pair(int on) { const int old = g_sa_pair; g_sa_pair = on != 0; return old; }
+extern "C" int pdm_sa_mlp_packed_pair(void *stream, int b, int n, int m, int cin, const int *nsample, const float *xyz,
+                                      const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride, const int *z_coff,
+                                      const int *const *pack, const int *const *meta, const int *nlayers, const int *const *dims,
+                                      const float *const *wpack, const float *const *bias, float *out_pm, int out_stride,
+                                      const int *out_coff, const int *cout) {
+    PDM_REQUIRE(nsample && z_coff && pack && meta && nlayers && dims && wpack && bias && out_coff && cout, PDM_E_BADARG,
+                "sa_mlp_packed_pair: null table");
+    PDM_REQUIRE((pack[0] && meta[0] && pack[1] && meta[1]) || b == 0 || m == 0, PDM_E_BADARG, "sa_mlp_packed_pair: null row list");
+    SaPlan pl[2];
+    for (int k = 0; k < 2; ++k)
+        if (int rc = sa_plan(b, n, m, z_pm ? 0 : cin, nsample[k], xyz, new_xyz, z_pm ? nullptr : feat_pm, z_pm, z_stride, z_coff[k], nullptr,
+                             nlayers[k], dims[k], wpack[k], bias[k], out_pm, out_stride, out_coff[k], cout[k], pack[k], meta[k], pl[k])) return rc;
+    if (b == 0 || m == 0) return 0;
+    const bool same = g_sa_pair && !pl[0].reg && !pl[1].reg && pl[0].W == pl[1].W && pl[0].NT == pl[1].NT && pl[0].G == pl[1].G &&
+                      pl[0].pre_form == pl[1].pre_form && pl[0].packed && pl[1].packed;
+    if (!same) {
+        for (int k = 0; k < 2; ++k)
+            if (int rc = pdm_sa_mlp_packed(stream, b, n, m, cin, nsample[k], xyz, new_xyz, feat_pm, z_pm, z_stride, z_coff[k], pack[k], meta[k],
+                                           nlayers[k], dims[k], wpack[k], bias[k], out_pm, out_stride, out_coff[k], cout[k])) return rc;
+        return 0;
+    }
+    const int W = pl[0].W, NT = pl[0].NT, G = pl[0].G;
+    const bool pre_form = pl[0].pre_form;
+    const size_t lds_bytes = pl[0].lds_bytes > pl[1].lds_bytes ? pl[0].lds_bytes : pl[1].lds_bytes;
+    const dim3 blocks((unsigned)(pl[0].blocks > pl[1].blocks ? pl[0].blocks : pl[1].blocks), 2);
+    const SaScale s0{pl[0].d, pl[0].a, pl[0].pack2, meta[0], wpack[0], bias[0]}, s1{pl[1].d, pl[1].a, pl[1].pack2, meta[1], wpack[1], bias[1]};
+    FUSED_DISPATCH(sa_packed_pair_kernel, W, G, blocks, lds_bytes, s0, s1);
+    return check_launch("sa_mlp_packed_pair");
 }
 
 // mode 0: FP module (known rows interpolated in the kernel); 1: FP module with pre-projected known rows z;

@@ -387,6 +387,26 @@ def sa_scale_forward_packed(pk, xyz, new_xyz, feat_pm, z, z_coff, packed, ns, ou
                  pk.wpack.data_ptr(), pk.bias.data_ptr(), out_pm.data_ptr(), out_pm.shape[2], out_coff, pk.cout)
 
 
+def sa_level_forward_packed(pks, xyz, new_xyz, feat_pm, z, z_coffs, packeds, nss, out_pm, out_coffs):
+    """Both scales of an MSG level over their compacted neighbour lists in one launch (pdm_sa_mlp_packed_pair; two launches
+    inside the library when the scales do not map to the same kernel): arguments per scale as lists of two."""
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    cin = 0 if (feat_pm is None or z is not None) else feat_pm.shape[2]
+    assert len(pks) == 2 and all(pk.cin == cin + 3 for pk in pks)
+    if FLOP_COUNTER is not None:
+        for pk, (pack, meta) in zip(pks, packeds):
+            _count("pdm_sa_mlp_packed_pair", int(meta[6].item()), pk)   # rows actually run (a sync: accounting passes only)
+    I2, P2 = ctypes.c_int * 2, ctypes.c_void_p * 2
+    keep = [I2(*nss), I2(*z_coffs), P2(*[p.data_ptr() for p, _ in packeds]), P2(*[m.data_ptr() for _, m in packeds]),
+            I2(*[pk.nlayers for pk in pks]), P2(*[pk.dims_ptr.value for pk in pks]), P2(*[pk.wpack.data_ptr() for pk in pks]),
+            P2(*[pk.bias.data_ptr() for pk in pks]), I2(*out_coffs), I2(*[pk.cout for pk in pks])]
+    c = [ctypes.cast(k, ctypes.c_void_p) for k in keep]
+    _native.call("pdm_sa_mlp_packed_pair", _stream(xyz), B, N, M, cin, c[0], xyz.data_ptr(), new_xyz.data_ptr(),
+                 0 if cin == 0 else feat_pm.data_ptr(), 0 if z is None else z.data_ptr(), 0 if z is None else z.shape[2], c[1], c[2], c[3],
+                 c[4], c[5], c[6], c[7], out_pm.data_ptr(), out_pm.shape[2], c[8], c[9])
+
+
 def fp_forward_pre(pk, z, skip_pm, idx, weight, out_pm):
     """FP module whose first layer's known-feature part was applied to the known points: z (B,m,width)."""
     B, m, _ = z.shape

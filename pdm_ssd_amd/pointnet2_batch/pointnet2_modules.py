@@ -109,9 +109,18 @@ class _PointnetSAModuleBase(nn.Module):
             prepack, packs = pre
             z = torch.empty((B, xyz.shape[1], prepack.width), dtype=torch.float32, device=xyz.device)
             fused.rows_forward(prepack, feat_pm, z, relu_last=False)
+        idxs = [idx_list[i] if idx_list is not None else
+                self._maybe_pack(pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1]) for i, g in enumerate(self.groupers)]
+        if len(packs) == 2 and all(isinstance(q, tuple) for q in idxs) and getattr(self, 'use_pair', True):
+            # both scales over their compacted lists in ONE launch: a deep level holds a few hundred row tiles per scale,
+            # which two launches run one after the other on a mostly idle chip (bit-identical: csrc/fused_mlp.hip)
+            coffs = [0, packs[0].cout]
+            fused.sa_level_forward_packed(list(packs), xyz, new_xyz, feat_pm, None if pre is None else z,
+                                          [0, 0] if pre is None else [prepack.offsets[0], prepack.offsets[1]], idxs,
+                                          [g.nsample for g in self.groupers], out_pm, coffs)
+            return new_xyz, out_pm.transpose(1, 2)
         for i, (grouper, pk) in enumerate(zip(self.groupers, packs)):
-            idx = idx_list[i] if idx_list is not None else \
-                self._maybe_pack(pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz), xyz.shape[1])
+            idx = idxs[i]
             if isinstance(idx, tuple):   # compacted list: padding copies of the first hit are not computed
                 fused.sa_scale_forward_packed(pk, xyz, new_xyz, feat_pm, None if pre is None else z,
                                               0 if pre is None else prepack.offsets[i], idx, grouper.nsample, out_pm, coff)

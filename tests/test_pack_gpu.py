@@ -94,6 +94,46 @@ def test_packed_sa_is_bit_identical_to_dense(dev, cin, mlps, nsamples, radii, np
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("cin,mlps,npoint,hoist", [
+    (96, [[96, 64, 64, 128], [96, 64, 96, 128]], 300, True),          # SA2 of PointNet2MSG
+    (256, [[256, 128, 196, 256], [256, 128, 196, 256]], 150, True),   # SA3
+    (512, [[512, 256, 256, 512], [512, 256, 384, 512]], 64, True),    # SA4: 64 centres per cloud, a few tile pairs per scale
+    (512, [[512, 256, 256, 512], [512, 256, 384, 512]], 64, False),   # ... unhoisted
+    (1, [[1, 16, 16, 32], [1, 32, 32, 64]], 400, False),              # SA1: register kernels, two launches inside the entry point
+])
+def test_both_scales_in_one_launch_equal_two_launches(dev, cin, mlps, npoint, hoist):
+    """pdm_sa_mlp_packed_pair (both scales of an MSG level, blockIdx.y = scale) against one pdm_sa_mlp_packed launch per scale,
+    and against the entry point's own two-launch route: bit-identical pooled features."""
+    from pdm_ssd_amd import _native
+    torch.manual_seed(cin + npoint)
+    sa = pm.PointnetSAModuleMSG(npoint=npoint, radii=[1.0, 3.0], nsamples=[16, 32], mlps=copy.deepcopy(mlps)).eval().to(dev)
+    sa.use_pre = hoist
+    cl = synthetic.lidar_like_clouds(3, 1800, 9)
+    xyz = torch.from_numpy(np.ascontiguousarray(cl[:, :, :3])).to(dev)
+    feat = torch.randn(3, cin, 1800, device=dev)
+    calls = []
+    orig = _native.call
+    _native.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        with torch.no_grad():
+            new_xyz = sa.sample(xyz)
+            packs = sa.query(xyz, new_xyz)
+            _, one = sa(xyz, feat, new_xyz=new_xyz, idx_list=packs)
+            one = one.clone()
+            assert calls.count("pdm_sa_mlp_packed_pair") == 1 and calls.count("pdm_sa_mlp_packed") == 0
+            sa.use_pair = False
+            _, two = sa(xyz, feat, new_xyz=new_xyz, idx_list=packs)
+            two = two.clone()
+            assert calls.count("pdm_sa_mlp_packed") == 2
+            sa.use_pair = True
+            old = _native.lib().pdm_tune_sa_pair(0)
+            _, three = sa(xyz, feat, new_xyz=new_xyz, idx_list=packs)
+            _native.lib().pdm_tune_sa_pair(old)
+    finally:
+        _native.call = orig
+    assert torch.isfinite(one).all() and torch.equal(one, two) and torch.equal(one, three)
+
+
 def test_packed_sa_empty_and_tiny(dev):
     sa = pm.PointnetSAModuleMSG(npoint=3, radii=[0.5], nsamples=[32], mlps=[[4, 16, 32]]).eval().to(dev)
     xyz = torch.rand(1, 50, 3, device=dev)
