@@ -286,6 +286,10 @@ size_t pdm_sa_pack_workspace_bytes(int b, int m);
 size_t pdm_sa_pack_rows(int b, int m, int nsample);
 int pdm_sa_pack(void *stream, int b, int n, int m, int nsample, const int *idx, void *workspace,
                 size_t workspace_bytes, int *pack, int *meta);
+/* both scales of an MSG level in one count -> scan -> fill sequence (per-scale nsample / idx / workspace / pack / meta as HOST arrays
+ * of two; each workspace of workspace_bytes >= pdm_sa_pack_workspace_bytes(b, m)) */
+int pdm_sa_pack_pair(void *stream, int b, int n, int m, const int *nsample, const int *const *idx, void *const *workspace,
+                     size_t workspace_bytes, int *const *pack, int *const *meta);
 int pdm_sa_mlp_packed(void *stream, int b, int n, int m, int cin, int nsample, const float *xyz,
                       const float *new_xyz, const float *feat_pm, const float *z_pm, int z_stride, int z_coff,
                       const int *pack, const int *meta, int nlayers, const int *dims, const float *wpack,

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused_pre": [_i] * 4 + [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_sa_pack": [_i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    "pdm_sa_pack_pair": [_i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp, _vp],
     "pdm_sa_mlp_packed_pair": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "pdm_sa_mlp_packed": [_i] * 5 + [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_interp_concat_rows": [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],

@@ -36,10 +36,24 @@ __device__ __forceinline__ int pack_count_row(const int *__restrict__ row, int n
 }
 __device__ __forceinline__ int pack_class(int cnt) { return cnt <= 1 ? 0 : 32 - __clz(cnt - 1); }
 
+// One launch serves up to two lists (the two scales of an MSG level): blockIdx.y picks the job.
+struct PackJob {
+    int ncentres, m, n, ns, nblocks;
+    const int *idx;
+    unsigned char *cnt;
+    int *bh, *meta;
+    int2 *pack;
+};
+struct PackJobs { PackJob j[2]; };
+
 // per-workgroup class histogram of the centres [256 blk, +256)
-__global__ __launch_bounds__(PK_T) void sa_pack_count_kernel(int ncentres, int ns, const int *__restrict__ idx,
-                                                             unsigned char *__restrict__ cnt_out,
-                                                             int *__restrict__ bh) {
+__global__ __launch_bounds__(PK_T) void sa_pack_count_kernel(PackJobs jobs) {
+    const PackJob &J = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= J.nblocks) return;
+    const int ncentres = J.ncentres, ns = J.ns;
+    const int *__restrict__ idx = J.idx;
+    unsigned char *__restrict__ cnt_out = J.cnt;
+    int *__restrict__ bh = J.bh;
     __shared__ int h[PK_NCLS];
     if (threadIdx.x < PK_NCLS) h[threadIdx.x] = 0;
     __syncthreads();
@@ -56,9 +70,12 @@ __global__ __launch_bounds__(PK_T) void sa_pack_count_kernel(int ncentres, int n
 // One workgroup of PK_NCLS waves: wave k turns bh[:, k] into exclusive prefixes (in place), then thread 0 lays the
 // classes out and the workgroup marks the alignment padding rows dead.  meta[0..5] = first row of class k,
 // meta[6] = total rows (a multiple of 32), meta[7] = rows of live segments.
-__global__ __launch_bounds__(64 * PK_NCLS) void sa_pack_scan_kernel(int nblocks, int *__restrict__ bh,
-                                                                    int *__restrict__ meta,
-                                                                    int2 *__restrict__ pack) {
+__global__ __launch_bounds__(64 * PK_NCLS) void sa_pack_scan_kernel(PackJobs jobs) {
+    const PackJob &J = jobs.j[blockIdx.y];
+    const int nblocks = J.nblocks;
+    int *__restrict__ bh = J.bh;
+    int *__restrict__ meta = J.meta;
+    int2 *__restrict__ pack = J.pack;
     __shared__ int total[PK_NCLS];
     __shared__ int base[PK_NCLS + 1];
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -100,12 +117,15 @@ __global__ __launch_bounds__(64 * PK_NCLS) void sa_pack_scan_kernel(int nblocks,
     }
 }
 
-__global__ __launch_bounds__(PK_T) void sa_pack_fill_kernel(int ncentres, int m, int n, int ns,
-                                                            const int *__restrict__ idx,
-                                                            const unsigned char *__restrict__ cnt_in,
-                                                            const int *__restrict__ bh,
-                                                            const int *__restrict__ meta,
-                                                            int2 *__restrict__ pack) {
+__global__ __launch_bounds__(PK_T) void sa_pack_fill_kernel(PackJobs jobs) {
+    const PackJob &J = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= J.nblocks) return;
+    const int ncentres = J.ncentres, m = J.m, n = J.n, ns = J.ns;
+    const int *__restrict__ idx = J.idx;
+    const unsigned char *__restrict__ cnt_in = J.cnt;
+    const int *__restrict__ bh = J.bh;
+    const int *__restrict__ meta = J.meta;
+    int2 *__restrict__ pack = J.pack;
     __shared__ int wc[PK_T / 64][PK_NCLS];
     const int c = blockIdx.x * PK_T + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -145,28 +165,48 @@ extern "C" size_t pdm_sa_pack_rows(int b, int m, int nsample) {
     return (size_t)((long long)(b > 0 ? b : 0) * (m > 0 ? m : 0) * nsample + 32 * (PK_NCLS + 1));
 }
 
-extern "C" int pdm_sa_pack(void *stream, int b, int n, int m, int nsample, const int *idx, void *workspace,
-                           size_t workspace_bytes, int *pack, int *meta) {
-    PDM_REQUIRE(b >= 0 && n >= 1 && m >= 0, PDM_E_BADARG, "sa_pack: bad size b=%d n=%d m=%d", b, n, m);
-    PDM_REQUIRE(nsample == 16 || nsample == 32, PDM_E_BADARG, "sa_pack: nsample=%d (16 or 32)", nsample);
-    PDM_REQUIRE(meta && pack, PDM_E_BADARG, "sa_pack: null output");
+static int sa_pack_job(const char *who, int b, int n, int m, int nsample, const int *idx, void *workspace, size_t workspace_bytes, int *pack,
+                       int *meta, PackJob &J) {
+    PDM_REQUIRE(b >= 0 && n >= 1 && m >= 0, PDM_E_BADARG, "%s: bad size b=%d n=%d m=%d", who, b, n, m);
+    PDM_REQUIRE(nsample == 16 || nsample == 32, PDM_E_BADARG, "%s: nsample=%d (16 or 32)", who, nsample);
+    PDM_REQUIRE(meta && pack, PDM_E_BADARG, "%s: null output", who);
     const long long nc = (long long)b * m;
     PDM_REQUIRE(nc * nsample + 32 * (PK_NCLS + 1) < (1ll << 31) && (long long)b * n < (1ll << 31), PDM_E_TOOLARGE,
-                "sa_pack: row numbers overflow 32 bits");
-    PDM_REQUIRE(nc == 0 || (idx && workspace), PDM_E_BADARG, "sa_pack: null pointer");
-    PDM_REQUIRE(workspace_bytes >= pdm_sa_pack_workspace_bytes(b, m), PDM_E_BADARG, "sa_pack: workspace %zu < %zu bytes",
+                "%s: row numbers overflow 32 bits", who);
+    PDM_REQUIRE(nc == 0 || (idx && workspace), PDM_E_BADARG, "%s: null pointer", who);
+    PDM_REQUIRE(workspace_bytes >= pdm_sa_pack_workspace_bytes(b, m), PDM_E_BADARG, "%s: workspace %zu < %zu bytes", who,
                 workspace_bytes, pdm_sa_pack_workspace_bytes(b, m));
     PDM_REQUIRE((reinterpret_cast<uintptr_t>(idx) & 15) == 0 && (reinterpret_cast<uintptr_t>(pack) & 7) == 0, PDM_E_BADARG,
-                "sa_pack: idx must be 16-byte, pack 8-byte aligned");
-    const int nblocks = (int)((nc + PK_T - 1) / PK_T);
+                "%s: idx must be 16-byte, pack 8-byte aligned", who);
     unsigned char *cnt = static_cast<unsigned char *>(workspace);
-    int *bh = reinterpret_cast<int *>(cnt + (nc + 15) / 16 * 16);
-    if (nblocks > 0)
-        hipLaunchKernelGGL(sa_pack_count_kernel, dim3(nblocks), dim3(PK_T), 0, as_stream(stream), (int)nc, nsample, idx, cnt, bh);
-    hipLaunchKernelGGL(sa_pack_scan_kernel, dim3(1), dim3(64 * PK_NCLS), 0, as_stream(stream), nblocks, bh, meta,
-                       reinterpret_cast<int2 *>(pack));
-    if (nblocks > 0)
-        hipLaunchKernelGGL(sa_pack_fill_kernel, dim3(nblocks), dim3(PK_T), 0, as_stream(stream), (int)nc, m, n, nsample, idx,
-                           cnt, bh, meta, reinterpret_cast<int2 *>(pack));
+    J.ncentres = (int)nc; J.m = m; J.n = n; J.ns = nsample; J.nblocks = (int)((nc + PK_T - 1) / PK_T);
+    J.idx = idx; J.cnt = cnt; J.bh = reinterpret_cast<int *>(cnt + (nc + 15) / 16 * 16); J.meta = meta;
+    J.pack = reinterpret_cast<int2 *>(pack);
+    return 0;
+}
+static int sa_pack_launch(void *stream, const PackJobs &jobs, int njobs) {
+    int nb = 0;
+    for (int k = 0; k < njobs; ++k) nb = jobs.j[k].nblocks > nb ? jobs.j[k].nblocks : nb;
+    if (nb > 0) hipLaunchKernelGGL(sa_pack_count_kernel, dim3(nb, njobs), dim3(PK_T), 0, as_stream(stream), jobs);
+    hipLaunchKernelGGL(sa_pack_scan_kernel, dim3(1, njobs), dim3(64 * PK_NCLS), 0, as_stream(stream), jobs);
+    if (nb > 0) hipLaunchKernelGGL(sa_pack_fill_kernel, dim3(nb, njobs), dim3(PK_T), 0, as_stream(stream), jobs);
     return check_launch("sa_pack");
+}
+
+extern "C" int pdm_sa_pack(void *stream, int b, int n, int m, int nsample, const int *idx, void *workspace,
+                           size_t workspace_bytes, int *pack, int *meta) {
+    PackJobs jobs{};
+    if (int rc = sa_pack_job("sa_pack", b, n, m, nsample, idx, workspace, workspace_bytes, pack, meta, jobs.j[0])) return rc;
+    return sa_pack_launch(stream, jobs, 1);
+}
+
+// The neighbour lists of BOTH scales of an MSG level (same b, n, m; nsample / idx / workspace / pack / meta per scale as HOST
+// arrays of two) compacted by ONE count -> scan -> fill sequence: three launches for the level instead of six.
+extern "C" int pdm_sa_pack_pair(void *stream, int b, int n, int m, const int *nsample, const int *const *idx, void *const *workspace,
+                                size_t workspace_bytes, int *const *pack, int *const *meta) {
+    PDM_REQUIRE(nsample && idx && workspace && pack && meta, PDM_E_BADARG, "sa_pack_pair: null table");
+    PackJobs jobs{};
+    for (int k = 0; k < 2; ++k)
+        if (int rc = sa_pack_job("sa_pack_pair", b, n, m, nsample[k], idx[k], workspace[k], workspace_bytes, pack[k], meta[k], jobs.j[k])) return rc;
+    return sa_pack_launch(stream, jobs, 2);
 }

@@ -371,6 +371,25 @@ def sa_pack(idx, n):
     return pack, meta
 
 
+def sa_pack_pair(idx0, idx1, n):
+    """sa_pack of the two scales of an MSG level in one count -> scan -> fill sequence: [(pack, meta), (pack, meta)]."""
+    assert idx0.shape[:2] == idx1.shape[:2] and all(i.dtype == torch.int32 and i.is_contiguous() and i.shape[2] in (16, 32) for i in (idx0, idx1))
+    B, M = idx0.shape[:2]
+    l = _native.lib()
+    ws_bytes = l.pdm_sa_pack_workspace_bytes(B, M)
+    outs, keep = [], []
+    for idx in (idx0, idx1):
+        rows = l.pdm_sa_pack_rows(B, M, idx.shape[2])
+        outs.append((torch.empty((rows, 2), dtype=torch.int32, device=idx.device), torch.empty((8,), dtype=torch.int32, device=idx.device),
+                     torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=idx.device)))
+    I2, P2 = ctypes.c_int * 2, ctypes.c_void_p * 2
+    keep = [I2(idx0.shape[2], idx1.shape[2]), P2(idx0.data_ptr(), idx1.data_ptr()), P2(outs[0][2].data_ptr(), outs[1][2].data_ptr()),
+            P2(outs[0][0].data_ptr(), outs[1][0].data_ptr()), P2(outs[0][1].data_ptr(), outs[1][1].data_ptr())]
+    c = [ctypes.cast(k, ctypes.c_void_p) for k in keep]
+    _native.call("pdm_sa_pack_pair", _stream(idx0), B, n, M, c[0], c[1], c[2], ws_bytes, c[3], c[4])
+    return [(outs[0][0], outs[0][1]), (outs[1][0], outs[1][1])]
+
+
 def sa_scale_forward_packed(pk, xyz, new_xyz, feat_pm, z, z_coff, packed, ns, out_pm, out_coff):
     """One SA scale over a compacted neighbour list `packed` = sa_pack(idx, N); z None = unhoisted form (feat_pm rows),
     else the hoisted form of sa_scale_forward_pre."""

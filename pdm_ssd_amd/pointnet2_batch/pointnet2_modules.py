@@ -80,8 +80,15 @@ class _PointnetSAModuleBase(nn.Module):
         ahead of time (pdm_ssd_amd/pipeline.py) and pass them to forward(..., idx_list=)."""
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
         with pointnet2_utils.shared_search_grids():   # one grid of `xyz` for every radius
-            return [self._maybe_pack(pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
-                    for g in self.groupers]
+            idxs = [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+        return self._maybe_pack_all(idxs, xyz.shape[1])
+
+    def _maybe_pack_all(self, idxs, n):
+        """_maybe_pack of every scale; the two scales of an MSG level share one count -> scan -> fill sequence."""
+        if (len(idxs) == 2 and getattr(self, 'use_pack', True) and all(i.shape[2] in (16, 32) for i in idxs) and not self.training
+                and not torch.is_grad_enabled() and getattr(self, 'use_fused', True) and getattr(self, 'use_pair', True)):
+            return fused.sa_pack_pair(idxs[0], idxs[1], n)
+        return [self._maybe_pack(i, n) for i in idxs]
 
     def _maybe_pack(self, idx, n):
         """Compact the neighbour list for the fused kernels (fused.sa_pack) when the module takes its fused inference
@@ -109,8 +116,8 @@ class _PointnetSAModuleBase(nn.Module):
             prepack, packs = pre
             z = torch.empty((B, xyz.shape[1], prepack.width), dtype=torch.float32, device=xyz.device)
             fused.rows_forward(prepack, feat_pm, z, relu_last=False)
-        idxs = [idx_list[i] if idx_list is not None else
-                self._maybe_pack(pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1]) for i, g in enumerate(self.groupers)]
+        idxs = list(idx_list) if idx_list is not None else \
+            self._maybe_pack_all([pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers], xyz.shape[1])
         if len(packs) == 2 and all(isinstance(q, tuple) for q in idxs) and getattr(self, 'use_pair', True):
             # both scales over their compacted lists in ONE launch: a deep level holds a few hundred row tiles per scale,
             # which two launches run one after the other on a mostly idle chip (bit-identical: csrc/fused_mlp.hip)

@@ -134,6 +134,22 @@ def test_both_scales_in_one_launch_equal_two_launches(dev, cin, mlps, npoint, ho
     assert torch.isfinite(one).all() and torch.equal(one, two) and torch.equal(one, three)
 
 
+def test_pack_pair_equals_two_single_packs(dev):
+    """pdm_sa_pack_pair (both scales of a level in one count -> scan -> fill sequence) == pdm_sa_pack per scale: meta and every
+    live row identical, for different nsample per scale and a centre count that is not a multiple of the workgroup size."""
+    cl = synthetic.lidar_like_clouds(3, 2500, 4)
+    xyz = torch.from_numpy(np.ascontiguousarray(cl[:, :, :3])).to(dev)
+    new_xyz = xyz[:, :333].contiguous()
+    i0 = pu.ball_query(0.6, 16, xyz, new_xyz)
+    i1 = pu.ball_query(2.5, 32, xyz, new_xyz)
+    (p0, m0), (p1, m1) = fused.sa_pack_pair(i0, i1, xyz.shape[1])
+    for idx, p, mt in ((i0, p0, m0), (i1, p1, m1)):
+        ps, ms = fused.sa_pack(idx, xyz.shape[1])
+        assert torch.equal(ms, mt)
+        rows = int(mt[6])
+        assert rows > 0 and torch.equal(ps[:rows], p[:rows])
+
+
 def test_packed_sa_empty_and_tiny(dev):
     sa = pm.PointnetSAModuleMSG(npoint=3, radii=[0.5], nsamples=[32], mlps=[[4, 16, 32]]).eval().to(dev)
     xyz = torch.rand(1, 50, 3, device=dev)
