@@ -906,6 +906,9 @@ def main():
     if os.environ.get("PDM_FP_CHAIN_MASK"):      # A/B knob: which FP shapes take the register-resident chain kernel
         _native.lib().pdm_tune_fp_chain_mask(int(os.environ["PDM_FP_CHAIN_MASK"]))
 
+    if os.environ.get("PDM_DW_WG_PER_CU"):       # A/B knob: grid cap of the heat-map head's one-kernel form
+        _native.lib().pdm_tune_rows_chain_dw_wg_per_cu(int(os.environ["PDM_DW_WG_PER_CU"]))
+
     B, N = args.batch, args.points
     scaling = "weak"
     if args.global_batch:

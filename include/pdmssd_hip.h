@@ -553,8 +553,10 @@ int pdm_tune_grid_split(int min_n);     /* search-grid build: clouds of >= min_n
 int pdm_tune_bq_small_waves(int w);     /* exhaustive ball query with <= 32768 centres in the call: waves per workgroup, 4 or 16 (default) */
 int pdm_tune_bq_cpw(int centres);       /* lane form: centres per wave, 16 (default) / 32 / 64 */
 int pdm_tune_bq_heavy(int candidates);  /* lane form: centres with more candidates than this take the whole-wave path (default 96) */
+int pdm_tune_group_lds_floor(int bytes); /* LDS-staged group_points: request at least this much LDS per workgroup (caps the workgroups per CU so that kernels of other streams find wave slots beside a streaming gather); 0 = what the rows need */
 int pdm_tune_group_rows(int packed);    /* group_points LDS form: 0 heuristics; variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel in plain unit order) | rows per workgroup << 4 | parts of L << 8 | threads / 256 << 16 | index quads per lane and pass << 20 */
 int pdm_tune_rows_chain_wg_per_cu(int n); /* grid cap of the many-row chain kernels = 256 CUs x n workgroups (default 12; 2 resident) */
+int pdm_tune_rows_chain_dw_wg_per_cu(int n); /* the same for pdm_bev_head_fused (default 2: every workgroup resident from the start) */
 int pdm_tune_rows_chain_xcd(int on);   /* heat-map chain kernel: contiguous patch range per XCD (default) / launch order */
 int pdm_tune_fp_chain_pad_lds(int bytes); /* diagnostic: extra LDS per workgroup of the FP chain kernel (occupancy experiments) */
 

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "pdm_tune_bq_cpw": None,
     "pdm_tune_copy_variant": None,
     "pdm_tune_group_nt": None,
+    "pdm_tune_group_lds_floor": None,
     "pdm_tune_copy_max_wg": None,
     "pdm_tune_bq_small_waves": None,
     "pdm_tune_bq_dense_ppc": None,
@@ -133,6 +134,7 @@ _SIGNATURES = {
     "pdm_tune_fp_chain_nt": None,
     "pdm_tune_fp_chain_mask": None,
     "pdm_tune_rows_chain_wg_per_cu": None,
+    "pdm_tune_rows_chain_dw_wg_per_cu": None,
     "pdm_tune_rows_chain_xcd": None,
     "pdm_tune_fused_swz": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],

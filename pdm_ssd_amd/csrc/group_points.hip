@@ -269,6 +269,11 @@ __global__ __launch_bounds__(T) void group_points_rows_kernel(int c, int n, long
 static int g_gp_tune = 0;
 static int g_gp_nt = 1;      // 1 (default): non-temporal stores of the grouped outputs (455 against 458-463 us on the target block)
 extern "C" int pdm_tune_group_nt(int on) { const int old = g_gp_nt; g_gp_nt = on != 0; return old; }
+// LDS-staged gathers request at least this many bytes of LDS per workgroup (0 = what the rows need).  A streaming gather fills
+// every wave slot of the chip and is bound by HBM long before that: beside it a latency-bound kernel of another stream (a ball
+// query, a grid build) waits for whole rounds of its workgroups.  64 KB = two workgroups per CU and 32 KB of LDS left over.
+static int g_gp_lds_floor = 0;
+extern "C" int pdm_tune_group_lds_floor(int bytes) { const int old = g_gp_lds_floor; if (bytes >= 0 && bytes <= 64 * 1024) g_gp_lds_floor = bytes; return old; }
 
 // rows of n floats per workgroup: up to `budget` bytes of LDS (several workgroups per CU overlap one's staging
 // with another's streaming), at most 8 (index registers reused across them); 0 = a row does not fit 64 KB
@@ -326,7 +331,7 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
         if ((long long)lsplit > nq) lsplit = (int)nq;
         const long long wgs = (long long)b * nrg * lsplit;
         PDM_REQUIRE(wgs <= 0x7fffffffll, PDM_E_TOOLARGE, "group_points: %lld workgroups", wgs);
-        const size_t lds = (size_t)rpw * row_bytes;
+        const size_t lds = std::max((size_t)rpw * row_bytes, (size_t)g_gp_lds_floor);
 #define GPR_LAUNCH(T, U, X) hipLaunchKernelGGL((group_points_rows_kernel<T, U, X>), dim3((unsigned)wgs), dim3(T), lds, as_stream(stream), c, n, L, rpw, nrg, lsplit, b, points, idx, out, g_gp_nt)
         if (variant == 3) {            // diagnostic: plain unit order (no XCD grouping)
             if (threads == 256) GPR_LAUNCH(256, 4, false); else if (threads == 512) GPR_LAUNCH(512, 4, false); else GPR_LAUNCH(1024, 4, false);
@@ -343,7 +348,7 @@ extern "C" int pdm_group_points(void *stream, int b, int c, int n, int npoints, 
     rpw = lds_rows_per_wg(n, c, 32 * 1024);   // round 2's kernel and its decomposition
     if (rpw > 0 && L >= 4 * n && (long long)b * divup(c, rpw) >= 512) {
         dim3 grid(divup(c, rpw), b);
-        hipLaunchKernelGGL(group_points_lds_kernel, grid, dim3(GPL_THREADS), (size_t)rpw * n * sizeof(float),
+        hipLaunchKernelGGL(group_points_lds_kernel, grid, dim3(GPL_THREADS), std::max((size_t)rpw * n * sizeof(float), (size_t)g_gp_lds_floor),
                            as_stream(stream), c, n, L, rpw, points, idx, out, g_gp_nt);
         return check_launch("group_points");
     }

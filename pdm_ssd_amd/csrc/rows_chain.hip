@@ -22,6 +22,10 @@
 namespace pdm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+#ifndef DW_SL
+#define DW_SL 4     // depthwise prologue: 16-channel slices per LDS stage (1, 2, 4 or 8 of the 8)
+#endif
+typedef const __attribute__((address_space(4))) f4 *cf4c;   // constant address space: uniform addresses load through the scalar cache
 typedef const __attribute__((address_space(1))) f4 *gf4c;   // a pointer the compiler must treat as global (no flat loads)
 
 struct RowsChainArgs {
@@ -245,11 +249,6 @@ __device__ __forceinline__ void rc_first_fragments(f4 (&an)[4], const f4 *lds, i
 template <int NK0, int NK1, int NK2, int NK3, bool DW = false>
 __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs a) {
     __shared__ __attribute__((aligned(16))) f4 lds[2 * RC_CHUNK_F4];
-    __shared__ __attribute__((aligned(16))) f4 dww[DW ? 10 * NK0 * 4 : 1];   // 9 taps + shift, C / 4 quads each
-    if constexpr (DW) {
-        for (int i = threadIdx.x; i < 9 * NK0 * 4; i += RC_THREADS) dww[i] = reinterpret_cast<const f4 *>(a.dw_w)[i];
-        for (int i = threadIdx.x; i < NK0 * 4; i += RC_THREADS) dww[9 * NK0 * 4 + i] = reinterpret_cast<const f4 *>(a.dw_shift)[i];
-    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int pos = lane & 15, g = lane >> 4;
     const f4 *w1 = reinterpret_cast<const f4 *>(a.wpack + a.woff[0]);
@@ -258,8 +257,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     constexpr int NL = NK3 ? 3 : NK2 ? 2 : 1;
     const float neg_inf = -__builtin_inff();
     f4 r[4];
-    __shared__ __attribute__((aligned(16))) f4 halo[DW ? 6 * 18 * 4 : 1];   // DW: (4 + 2) x (16 + 2) cells x 16 channels
-    __shared__ __attribute__((aligned(16))) f4 xs[DW ? 64 * (NK0 * 4 + 1) : 1];   // DW: the patch's convolved rows (+1 quad pad)
+    __shared__ __attribute__((aligned(16))) f4 halo[DW ? DW_SL * 6 * 18 * 4 : 1];   // DW: DW_SL slices of (4 + 2) x (16 + 2) cells x 16 channels
+    __shared__ __attribute__((aligned(16))) f4 xs[DW ? DW_SL * 64 * 5 : 1];         // DW: a stage's convolved quads, (slice, cell) rows of 4 quads + 1 pad
     const int ntx = DW ? (a.dw_W + 15) / 16 : 1, nty = DW ? (a.dw_H + 3) / 4 : 1;
     const long long ntiles = DW ? (long long)(a.rows / (a.dw_H * a.dw_W)) * nty * ntx : ((long long)a.rows + 63) / 64;
     // first chunk of layer 1 for the first tile; every later tile finds it prefetched behind the last chunk of the
@@ -282,12 +281,16 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
     // previous tile's chain (with the next slice requested under the current slice's taps, ~500 cycles of work against an
     // HBM round trip, every slice waited for memory)
     f4 hva[DW ? NK0 : 1][2];
+    // (patch coordinates: two 32-bit divisions per tile, computed once — when the patch's halo is requested — and carried to
+    //  the iteration that consumes it; the first form redid four 64-bit divisions and remainders three times per tile)
     auto dw_tile = [&](long long step, int &b, int &y0, int &x0) -> bool {   // patch of step `step` of this workgroup's walk
         if (step >= nsteps) return false;
         const long long tl = by_xcd ? (step & 7) * per_xcd + (step >> 3) : step;
         if (tl >= ntiles) return false;
-        b = (int)(tl / ((long long)ntx * nty));
-        y0 = (int)((tl / ntx) % nty) * 4; x0 = (int)(tl % ntx) * 16;
+        const unsigned tu = (unsigned)tl, pp = (unsigned)(ntx * nty);
+        const unsigned bb = tu / pp, rem = tu - bb * pp, ty = rem / (unsigned)ntx;
+        b = (int)bb;
+        y0 = (int)ty * 4; x0 = (int)(rem - ty * (unsigned)ntx) * 16;
         return true;
     };
     auto dw_fetch = [&](int b, int y0, int x0) {   // thread t: f4 (cell, quad) = t, t + 256 of the (4 + 2) x (16 + 2) halo, per slice
@@ -304,9 +307,9 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
             for (int kb = 0; kb < (DW ? NK0 : 1); ++kb) hva[kb][u] = in ? src[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    int cb = 0, cy0 = 0, cx0 = 0;   // DW: the patch whose halo is in hva
     if constexpr (DW) {
-        int b0, y0, x0;
-        if (dw_tile(blockIdx.x, b0, y0, x0)) dw_fetch(b0, y0, x0);
+        if (dw_tile(blockIdx.x, cb, cy0, cx0)) dw_fetch(cb, cy0, cx0);
     }
     for (long long step = blockIdx.x; step < nsteps; step += gridDim.x) {
         const long long tl = by_xcd ? (step & 7) * per_xcd + (step >> 3) : step;
@@ -321,9 +324,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
         bool live = row < a.rows;
         int dw_b = 0, dw_y0 = 0, dw_x0 = 0;
         if constexpr (DW) {
-            const int tx = (int)(tl % ntx), ty = (int)((tl / ntx) % nty);
-            dw_b = (int)(tl / ((long long)ntx * nty));
-            dw_y0 = ty * 4; dw_x0 = tx * 16;
+            dw_b = cb; dw_y0 = cy0; dw_x0 = cx0;
             live = dw_y0 + wave < a.dw_H && dw_x0 + pos < a.dw_W;
             row = ((long long)dw_b * a.dw_H + dw_y0 + wave) * a.dw_W + dw_x0 + pos;
         }
@@ -340,36 +341,74 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
                 for (int kb = 0; kb < NK0; ++kb) x0[kb] = *reinterpret_cast<const f4 *>(src + 16 * kb);
             }
         } else {
-            // depthwise 3x3 + shift + ReLU: the patch's halo is staged through LDS 16 channels at a time (each cell of
-            // the map is fetched once per workgroup instead of up to nine times), from the registers filled a tile ahead
+            // depthwise 3x3 + shift + ReLU: the patch's halo is staged through LDS (each cell of the map is fetched once per
+            // workgroup instead of up to nine times), from the registers filled a tile ahead, DW_SL slices of 16 channels per
+            // stage.  Inside a stage the work is dealt differently from the chain: WAVE w takes channel quad w of a slice for
+            // all 64 cells of the patch (lane = cell), so the nine tap weights and the shift of (slice, quad) are wave-uniform
+            // and come through the scalar cache — no LDS reads and no registers for them (the first form read them from LDS per
+            // lane, 9 of its 19 reads per slice, and the prologue was bound by the LDS pipe: 152 KB per wave and tile,
+            // 11.3k of a tile's 27.2k cycles, tools/diag/bev_head_phase.py).  The results cross to the chain's fragment
+            // layout (lane (pos, g) of wave r holds quad g of cell (r, pos)) through a padded LDS tile.
+            // Same fma order per channel as before (shift, then taps row by row, left to right): identical results.
             constexpr int C4 = NK0 * 4;
-            // a lane parks its slice results in its own LDS row and reads them back as x0[] afterwards
-            f4 *mine = xs + (wave * 16 + pos) * (C4 + 1) + g;
+            static_assert(NK0 % DW_SL == 0, "rows_chain DW: slices per stage");
+            const int wu = __builtin_amdgcn_readfirstlane(wave);
+            const int cr = lane >> 4;                                   // this lane's cell of the patch: row cr, column pos
+#if RC_DIAG & 4
+            long long dws[10];
+            int dwi = 0;
+#define DW_STAMP() do { __builtin_amdgcn_s_waitcnt(0xc07f); if (dwi < 9) dws[dwi++] = __builtin_amdgcn_s_memtime(); } while (0)
+            { __builtin_amdgcn_s_waitcnt(0x0070 | 0xc00f); }   // (lgkm and vm counters left to the stamps below)
+            dws[dwi++] = __builtin_amdgcn_s_memtime();
+#else
+#define DW_STAMP()
+#endif
 #pragma unroll
-            for (int kb = 0; kb < NK0; ++kb) {
-                if (t < 6 * 18 * 4) halo[t] = hva[kb][0];
-                if (t + RC_THREADS < 6 * 18 * 4) halo[t + RC_THREADS] = hva[kb][1];
-                __syncthreads();
-                f4 acc = dww[9 * C4 + kb * 4 + g];
+            for (int s0 = 0; s0 < NK0; s0 += DW_SL) {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+                for (int q = 0; q < DW_SL; ++q) {
+                    // quad-major inside a slice ((quad, cell) instead of (cell, quad)): a wave reads ONE quad of 64 cells per
+                    // tap, consecutive lanes 16 bytes apart (cell-major, those reads used a quarter of the banks: 497 us against 448)
+                    if (t < 6 * 18 * 4) halo[q * (6 * 18 * 4) + (t & 3) * (6 * 18) + (t >> 2)] = hva[s0 + q][0];
+                    if (t + RC_THREADS < 6 * 18 * 4) halo[q * (6 * 18 * 4) + (t & 3) * (6 * 18) + ((t + RC_THREADS) >> 2)] = hva[s0 + q][1];
+                }
+                DW_STAMP();
+                __syncthreads();   // halo of this stage written; everyone has read the stage before's crossing tile
+                DW_STAMP();
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const f4 v = halo[((wave + dy) * 18 + pos + dx) * 4 + g];
-                        const f4 k = dww[(dy * 3 + dx) * C4 + kb * 4 + g];
-                        acc.x = fmaf(k.x, v.x, acc.x); acc.y = fmaf(k.y, v.y, acc.y);
-                        acc.z = fmaf(k.z, v.z, acc.z); acc.w = fmaf(k.w, v.w, acc.w);
-                    }
-                mine[kb * 4] = f4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);   // (unpinned, the compiler gathers all 80 tap reads up front and spills them)
+                for (int q = 0; q < DW_SL; ++q) {
+                    const int kb = s0 + q;
+                    // (constant address space + a wave-uniform address = s_load_dwordx4; through a plain pointer the compiler
+                    //  issues per-lane global loads, since the kernel's own stores might alias)
+                    const cf4c wq = (cf4c)(uintptr_t)(a.dw_w + kb * 16 + 4 * wu);
+                    f4 acc = *(cf4c)(uintptr_t)(a.dw_shift + kb * 16 + 4 * wu);
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const f4 v = halo[q * (6 * 18 * 4) + wu * (6 * 18) + (cr + dy) * 18 + pos + dx];
+                            const f4 k = wq[(dy * 3 + dx) * C4];
+                            acc = __builtin_elementwise_fma(k, v, acc);   // two v_pk_fma_f32: the same IEEE fma per channel
+                        }
+                    acc = f4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+                    xs[(q * 64 + lane) * 5 + wu] = acc;
+                    asm volatile("" ::: "memory");   // the slice's taps are consumed here, before the next slice's reads are issued
+                    __builtin_amdgcn_sched_barrier(0);   // (unpinned, the compiler gathers every tap read up front and spills them)
+                }
+                DW_STAMP();
+                __syncthreads();   // crossing tile written; every tap of this stage read (the next stage may overwrite the halo)
+                DW_STAMP();
+#pragma unroll
+                for (int q = 0; q < DW_SL; ++q) x0[s0 + q] = xs[(q * 64 + wave * 16 + pos) * 5 + g];
             }
-            {   // the next tile's halo
-                int nb, ny0, nx0;
-                if (dw_tile(step + gridDim.x, nb, ny0, nx0)) dw_fetch(nb, ny0, nx0);
+#if RC_DIAG & 4
+            {
+                const long long k = (step - blockIdx.x) / gridDim.x;
+                if (t == 0 && k == 1)
+                    for (int i = 0; i < 9; ++i) reinterpret_cast<long long *>(a.out)[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 9 + i] = dws[i];
             }
-#pragma unroll
-            for (int kb = 0; kb < NK0; ++kb) x0[kb] = mine[kb * 4];
+#endif
+            if (dw_tile(step + gridDim.x, cb, cy0, cx0)) dw_fetch(cb, cy0, cx0);   // the next tile's halo
         }
         float *__restrict__ orow = live ? a.out + (size_t)out_row * a.out_stride : nullptr;
         auto store = [&](auto &y, int nmb) {
@@ -427,7 +466,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
 #if RC_DIAG & 4
                 asm volatile("" :: "v"(x3[0].x));
                 ts[3] = __builtin_amdgcn_s_memtime();
-                const long long k = (tl - blockIdx.x) / gridDim.x;
+                const long long k = (step - blockIdx.x) / gridDim.x;   // (== (tl - blockIdx.x) / gridDim.x in launch order)
                 if (t == 0 && k < 2)
                     for (int i = 0; i < 4; ++i) reinterpret_cast<long long *>(a.out)[((size_t)blockIdx.x * 2 + k) * 4 + i] = ts[i];
 #else
@@ -743,6 +782,10 @@ static int g_rc_dw_xcd = 1;       // heat-map kernel: patches dealt to the XCDs 
 extern "C" int pdm_tune_rows_chain_xcd(int on) { const int old = g_rc_dw_xcd; g_rc_dw_xcd = on != 0; return old; }
 static int g_rc_wg_per_cu = 12;   // grid cap of the chain kernels = 256 CUs x this many workgroups (2 are resident at a time)
 extern "C" int pdm_tune_rows_chain_wg_per_cu(int n) { const int old = g_rc_wg_per_cu; if (n > 0) g_rc_wg_per_cu = n; return old; }
+// the same for the heat-map head's one-kernel form: its workgroups pay more at their start (first halo and first weight chunk
+// not prefetched), so fewer, longer ones: alone 436 / 442 / 452 us at 2 / 4 / 12 (tools/diag/bev_head_rate.py), in the step 4.37 / 4.40 / 4.41 ms
+static int g_rc_dw_wg_per_cu = 2;
+extern "C" int pdm_tune_rows_chain_dw_wg_per_cu(int n) { const int old = g_rc_dw_wg_per_cu; if (n > 0) g_rc_dw_wg_per_cu = n; return old; }
 static int g_fpc_nt = 0;        // FP chain kernel: non-temporal output stores (off: no change in time or in PMC traffic; the rows are the point head's input next)
 extern "C" int pdm_tune_fp_chain_nt(int on) { const int old = g_fpc_nt; g_fpc_nt = on != 0; return old; }
 // which FP shapes take the chain kernel: bit 0 the FP1 shape, bit 1 the FP2 shape (else the LDS-tiled forms).  Default 2: with the
@@ -868,7 +911,7 @@ int rows_chain_dw_launch(void *stream, int B, int H, int W, int C, const float *
     a.out = out_pm; a.out_stride = out_stride; a.cout = cout; a.relu_last = relu_last;
     a.dw_H = H; a.dw_W = W; a.dw_by_xcd = g_rc_dw_xcd; a.dw_w = dw_w; a.dw_shift = dw_shift;
     const long long tiles = (long long)B * ((H + 3) / 4) * ((W + 15) / 16);
-    const int grid = (int)(tiles < 256 * g_rc_wg_per_cu ? tiles : 256 * g_rc_wg_per_cu);
+    const int grid = (int)(tiles < 256 * g_rc_dw_wg_per_cu ? tiles : 256 * g_rc_dw_wg_per_cu);
     if (rc_shape_is(nlayers, dims, 8, 4, 4, 1)) {
         hipLaunchKernelGGL((rows_chain_kernel<8, 4, 4, 1, true>), dim3(grid), dim3(RC_THREADS), 0, as_stream(stream), a);
         *launched = 1;

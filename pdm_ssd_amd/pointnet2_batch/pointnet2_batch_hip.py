@@ -70,14 +70,20 @@ class _GridCache:
     def __init__(self):
         self.entries = []   # (weakref, version, data_ptr, b, n, stream, workspace, nbytes)
         self.depth = 0
+        self.cross = 0
 
     @contextlib.contextmanager
-    def scope(self):
+    def scope(self, cross_stream=False):
+        """cross_stream: a grid built on one stream also serves searches issued on OTHER streams inside this scope.  The caller
+        orders those streams behind the stream that built it (the first search of the point set) and keeps the scope open until
+        every such stream has been joined, so the workspace outlives its readers."""
         self.depth += 1
+        self.cross += bool(cross_stream)
         try:
             yield self
         finally:
             self.depth -= 1
+            self.cross -= bool(cross_stream)
             if self.depth == 0:
                 self.entries.clear()
 
@@ -86,7 +92,7 @@ class _GridCache:
         if self.depth > 0:
             for e in self.entries:
                 if (e[0]() is pts and e[1] == pts._version and e[2] == pts.data_ptr() and e[3] == b and e[4] == n
-                        and e[5] == stream):
+                        and (e[5] == stream or self.cross > 0)):
                     return e[6], e[7]
         nbytes = _native.lib().pdm_ball_query_grid_workspace_bytes(b, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)

@@ -19,11 +19,12 @@ from torch.autograd import Function
 from . import pointnet2_batch_hip as pointnet2
 
 
-def shared_search_grids():
+def shared_search_grids(cross_stream=False):
     """`with shared_search_grids():` — the ball queries / three_nn calls inside the block that search the same point
     set share one search grid (pointnet2_batch_hip.GRID_CACHE).  The caller promises not to rewrite those point sets
-    inside the block; every grid is dropped when the outermost block ends."""
-    return pointnet2.GRID_CACHE.scope()
+    inside the block; every grid is dropped when the outermost block ends.  cross_stream: also across streams the caller
+    has ordered behind the building one (see _GridCache.scope)."""
+    return pointnet2.GRID_CACHE.scope(cross_stream)
 
 _FP32_FWD = dict(device_type="cuda", cast_inputs=torch.float32)
 

@@ -15,6 +15,21 @@ if "--quad" in sys.argv:     # grid ball query form: 2 lane (default), 1 quad, 0
     i = sys.argv.index("--quad")
     _native.lib().pdm_tune_bq_quad(int(sys.argv[i + 1]))
     del sys.argv[i:i + 2]
+CHAINS = 0
+if "--chains" in sys.argv:   # 4 = one chain per SA level, 8 = one per (level, scale) behind the level's grid build; streams, fork / join only
+    i = sys.argv.index("--chains")
+    CHAINS = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
+GP_TUNE = None
+if "--gp-tune" in sys.argv:  # pdm_tune_group_rows word (tools/diag/group_sweep.py)
+    i = sys.argv.index("--gp-tune")
+    GP_TUNE = int(sys.argv[i + 1], 0)
+    del sys.argv[i:i + 2]
+GP_FLOOR = None
+if "--gp-lds-floor" in sys.argv:
+    i = sys.argv.index("--gp-lds-floor")
+    GP_FLOOR = int(sys.argv[i + 1], 0)
+    del sys.argv[i:i + 2]
 if "--cpw" in sys.argv:
     i = sys.argv.index("--cpw")
     _native.lib().pdm_tune_bq_cpw(int(sys.argv[i + 1]))
@@ -47,11 +62,57 @@ with torch.no_grad():
             for C in (3, f.shape[1]):
                 totb += B * (4 * M * g.nsample + 4 * C * N + 4 * C * M * g.nsample)
         xyz = new_xyz
+    if GP_FLOOR is not None:
+        _native.lib().pdm_tune_group_lds_floor(GP_FLOOR)
+    if GP_TUNE is not None:
+        _native.lib().pdm_tune_group_rows(GP_TUNE)
+    streams = [torch.cuda.Stream() for _ in range(8)]
     def whole():
-        with pu.shared_search_grids():
-            for radius, ns, x, nx, f, xt in plan:
-                idx = pu.ball_query(radius, ns, x, nx)
-                pu.grouping_operation(xt, idx)
+        if not CHAINS:
+            with pu.shared_search_grids():
+                for radius, ns, x, nx, f, xt in plan:
+                    idx = pu.ball_query(radius, ns, x, nx)
+                    pu.grouping_operation(xt, idx)
+                    pu.grouping_operation(f, idx)
+            return
+        cur = torch.cuda.current_stream()
+        def scale(entry, big=True):
+            radius, ns, x, nx, f, xt = entry
+            idx = pu.ball_query(radius, ns, x, nx)
+            pu.grouping_operation(xt, idx)
+            if big or f.shape[1] == 1:
+                pu.grouping_operation(f, idx)
+                return None
+            return (f, idx)
+        for st in streams:
+            st.wait_stream(cur)
+        later = []
+        with pu.shared_search_grids(cross_stream=True):
+            for li in range(4):
+                a, b2 = streams[2 * li], streams[2 * li + 1]
+                if CHAINS == 4:
+                    with torch.cuda.stream(a):
+                        scale(plan[2 * li]); scale(plan[2 * li + 1])
+                    continue
+                # 8 chains: the level's grid build + first search on a, the second scale behind the build only.
+                # 9 = the same, and the six feature gathers of levels 2-4 (the streaming part: 1.2 of 1.68 GB) AFTER every chain
+                # has been joined, one after the other: searches and small copies no longer wait for slots beside them.
+                radius, ns, x, nx, f, xt = plan[2 * li]
+                with torch.cuda.stream(a):
+                    idx = pu.ball_query(radius, ns, x, nx)
+                b2.wait_stream(a)
+                with torch.cuda.stream(a):
+                    pu.grouping_operation(xt, idx)
+                    if CHAINS == 8 or f.shape[1] == 1:
+                        pu.grouping_operation(f, idx)
+                    else:
+                        later.append((f, idx))
+                with torch.cuda.stream(b2):
+                    r = scale(plan[2 * li + 1], big=CHAINS == 8)
+                    if r: later.append(r)
+            for st in streams:          # join only after every chain has been forked
+                cur.wait_stream(st)
+            for f, idx in later:
                 pu.grouping_operation(f, idx)
     whole(); torch.cuda.synchronize()
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())

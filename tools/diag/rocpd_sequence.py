@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 rows = list(cur.execute("select name, start, end from kernels order by start"))
-per = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+per = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0
 def short(n):
     n = re.sub(r"\(.*\)$", "", n)
     n = n.replace("pdm::", "")
@@ -19,6 +19,13 @@ if not per:   # the repeating unit: distance between the last two occurrences of
             per = cand
             break
 print(f"{len(rows)} kernel dispatches, {per} per replay")
+if "--timeline" in sys.argv:     # the LAST replay as it ran: start and end offsets (kernels of concurrent branches overlap)
+    blk = rows[len(rows) - per:]
+    t0 = blk[0][1]
+    for n, s, e in blk:
+        print(f"{(s - t0) / 1e3:9.2f} -> {(e - t0) / 1e3:9.2f}  ({(e - s) / 1e3:7.2f} us)  {short(n)}")
+    print(f"span {(max(e for _, _, e in blk) - t0) / 1e3:.1f} us")
+    sys.exit(0)
 import collections
 R = 20   # average over the last R replays
 acc = collections.OrderedDict()
