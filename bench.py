@@ -692,6 +692,8 @@ class Bench:
 
     def step_serial(self, points=None):
         bd = {'batch_size': self.B, 'points': self.inputs[0] if points is None else points, 'points_per_sample_checked': True}
+        if self.model.point_head.wants_deferred_fp():    # as the detector's forward and the pipeline do: last FP module inside the head's launch
+            bd['defer_last_fp'] = True
         bd = self.model.point_head(self.model.dense_head(self.neck(self.backbone(bd))))
         return bd['spatial_features'], bd['point_features'], bd['batch_box_preds'], bd['bev_heatmap']
 
@@ -916,6 +918,8 @@ def main():
             sys.exit(f"[bench] --global-batch {args.global_batch} does not divide over {world} ranks (whole clouds per rank)")
         B, scaling = args.global_batch // world, "strong"
     model = build_detector(device)
+    if os.environ.get("PDM_FP_HEAD_FUSION"):     # A/B knob: 0 = the last FP module and the point head as separate launches
+        model.point_head.use_fp_fusion = os.environ["PDM_FP_HEAD_FUSION"] != "0"
     if args.train:
         _, points = make_batch(B, N, args.clouds, 1234 + rank * B, device)
         line = train_bench(args, model, points, B, N, rank, world, local_rank, device, scaling=scaling)

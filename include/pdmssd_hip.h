@@ -230,6 +230,19 @@ int pdm_rows_mlp_fused_pair(void *stream, int rows, int cin, const float *in_pm,
                             const float *wpack_a, const float *bias_a, const float *wpack_b, const float *bias_b,
                             int relu_last, float *out_a, int out_stride_a, int cout_a, float *out_b, int out_stride_b,
                             int cout_b);
+
+/* The backbone's LAST feature-propagation module and the point head's two stacks in one launch
+ * (/root/reference/pcdet/models/backbones_3d/pointnet2_backbone.py:96-111 writes point_features, which
+ * /root/reference/pcdet/models/dense_heads/point_head_box.py:71-76 reads straight back).  FP arguments as
+ * pdm_fp_mlp_fused_pre (z = the first layer's known-feature part applied to the m known points), head arguments as
+ * pdm_rows_mlp_fused_pair; out_pm receives the module's rows, out_a / out_b the stacks' outputs on them.  Bit-identical to the
+ * two calls (FP through the register-resident chain kernel).  Shapes: <= 4 skip channels, dims {16, 128, 128}, hdims
+ * {128, 256, 256, 16}, >= 32768 rows; PDM_E_BADARG otherwise (issue the two calls instead). */
+int pdm_fp_head_fused(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride, const float *skip_pm,
+                      const int *idx, const float *weight, const int *dims, const float *wpack, const float *bias,
+                      float *out_pm, int out_stride, int cout, const int *hdims, const float *hw_a, const float *hb_a,
+                      const float *hw_b, const float *hb_b, int relu_last, float *out_a, int out_stride_a, int cout_a,
+                      float *out_b, int out_stride_b, int cout_b);
 int pdm_tune_fused_pair(int on);   /* 0: always two launches (A/B and tests); returns the previous setting */
 
 /* Point head in training: target assignment + sigmoid focal loss + weighted smooth-L1 loss + d L / d predictions, per point
@@ -556,6 +569,7 @@ int pdm_tune_bq_heavy(int candidates);  /* lane form: centres with more candidat
 int pdm_tune_group_lds_floor(int bytes); /* LDS-staged group_points: request at least this much LDS per workgroup (caps the workgroups per CU so that kernels of other streams find wave slots beside a streaming gather); 0 = what the rows need */
 int pdm_tune_group_rows(int packed);    /* group_points LDS form: 0 heuristics; variant (1 rows kernel, 2 round-2 kernel, 3 rows kernel in plain unit order) | rows per workgroup << 4 | parts of L << 8 | threads / 256 << 16 | index quads per lane and pass << 20 */
 int pdm_tune_rows_chain_wg_per_cu(int n); /* grid cap of the many-row chain kernels = 256 CUs x n workgroups (default 12; 2 resident) */
+int pdm_tune_fp_head_tiles(int n);           /* pdm_fp_head_fused: consecutive 64-row tiles per workgroup (default 2) */
 int pdm_tune_rows_chain_dw_wg_per_cu(int n); /* the same for pdm_bev_head_fused (default 2: every workgroup resident from the start) */
 int pdm_tune_rows_chain_xcd(int on);   /* heat-map chain kernel: contiguous patch range per XCD (default) / launch order */
 int pdm_tune_fp_chain_pad_lds(int bytes); /* diagnostic: extra LDS per workgroup of the FP chain kernel (occupancy experiments) */

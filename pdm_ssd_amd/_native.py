@@ -90,6 +90,8 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
     "pdm_rows_mlp_x3": [_i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp, _i, _vp, _i, _i],
     "pdm_rows_mlp_fused_pair": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i],
+    "pdm_fp_head_fused": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
+                          _vp, _i, _i],
     "pdm_sa_mlp_fused_pre": [_i] * 4 + [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
     "pdm_fp_mlp_fused_pre": [_i] * 4 + [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_sa_pack": [_i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp, _vp],
@@ -135,6 +137,7 @@ _SIGNATURES = {
     "pdm_tune_fp_chain_mask": None,
     "pdm_tune_rows_chain_wg_per_cu": None,
     "pdm_tune_rows_chain_dw_wg_per_cu": None,
+    "pdm_tune_fp_head_tiles": None,
     "pdm_tune_rows_chain_xcd": None,
     "pdm_tune_fused_swz": None,
     "pdm_scatter_bev": [_i, _i, _i, _i, _vp, _vp, _vp, _vp] + [_f] * 9 + [_i] * 7 + [_vp, _vp],

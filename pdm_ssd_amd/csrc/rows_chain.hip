@@ -22,6 +22,9 @@
 namespace pdm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+#ifndef DW_PIN
+#define DW_PIN 1    // depthwise prologue: slices whose tap reads may be in flight together
+#endif
 #ifndef DW_SL
 #define DW_SL 4     // depthwise prologue: 16-channel slices per LDS stage (1, 2, 4 or 8 of the 8)
 #endif
@@ -392,8 +395,10 @@ __global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs
                         }
                     acc = f4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
                     xs[(q * 64 + lane) * 5 + wu] = acc;
-                    asm volatile("" ::: "memory");   // the slice's taps are consumed here, before the next slice's reads are issued
-                    __builtin_amdgcn_sched_barrier(0);   // (unpinned, the compiler gathers every tap read up front and spills them)
+                    if ((q % DW_PIN) == DW_PIN - 1) {
+                        asm volatile("" ::: "memory");   // the slice's taps are consumed here, before the next slice's reads are issued
+                        __builtin_amdgcn_sched_barrier(0);   // (unpinned, the compiler gathers every tap read up front and spills them)
+                    }
                 }
                 DW_STAMP();
                 __syncthreads();   // crossing tile written; every tap of this stage read (the next stage may overwrite the halo)
@@ -590,11 +595,27 @@ struct FpChainArgs {
     int woff[2], boff[2];
     float *out;
     int out_stride, cout;
+    // HEAD instantiations: the point head's two stacks (RowsChainPairArgs' fields) run on the tile's output rows while they
+    // are still in registers
+    const float *hw[2], *hb[2];
+    int hwoff[3], hboff[3];
+    float *hout[2];
+    int hout_stride[2], hcout[2], hrelu_last;
 };
 
-template <int NK0, int NK1, int NK2>
+// HEAD: the last FP module and the point head in ONE launch.  /root/reference/pcdet/models/backbones_3d/pointnet2_backbone.py:
+// 96-111 ends with FP module 1 writing point_features, which dense_heads/point_head_box.py:71-76 reads straight back as the
+// input of its two stacks.  The module's output fragments (lane (pos, g): channels 16 mb + 4 g .. of row pos) ARE the
+// stacks' input fragments, so after its rows have left for memory (point_features is an output of the detector) the wave
+// runs class stack, then box stack on them as rows_chain_pair_kernel does.  The FP module's gathers and its 268 MB of
+// output stores sit in a weight stream of seven layers instead of one (alone they add up with its MFMAs: DESIGN 7h), the
+// head does not read the rows back, one launch boundary and one slow first tile per workgroup less.  Every layer is
+// rc_layer: the FP output equals fp_chain_kernel<0, 8, 8>'s and the logits equal rows_chain_pair_kernel's on it, bit for bit.
+template <int NK0, int NK1, int NK2, bool HEAD = false>
 __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) {
     static_assert(NK1 % 8 == 0 && NK2 % 8 == 0, "fp_chain: widths are multiples of 128 channels (one staging pass)");
+    static_assert(!HEAD || (NK0 == 0 && NK2 == 8), "fp_chain HEAD: FP module 1 (raw skip channels, 128 out) + the 128 -> 256 -> 256 -> <= 16 stacks");
+    constexpr int H1 = 16, H2 = 16, H3 = 1;   // HEAD: blocks of the stacks' layers
     __shared__ __attribute__((aligned(16))) f4 lds[2 * RC_CHUNK_F4];
     // per-wave transposition buffer: 16 rows x 128 channels (+1 quad per row: D-layout reads of a 16-lane group then
     // touch 16 different bank quads).  Gathers and stores move whole 128-byte lines per row (8 lanes x 16 B); the
@@ -607,6 +628,10 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
     f4 *stage = stage_all + wave * 16 * SQ;
     const f4 *w1 = reinterpret_cast<const f4 *>(a.wpack + a.woff[0]);
     const f4 *w2 = reinterpret_cast<const f4 *>(a.wpack + a.woff[1]);
+    const f4 *wa1 = HEAD ? reinterpret_cast<const f4 *>(a.hw[0] + a.hwoff[0]) : nullptr, *wa2 = HEAD ? reinterpret_cast<const f4 *>(a.hw[0] + a.hwoff[1]) : nullptr,
+             *wa3 = HEAD ? reinterpret_cast<const f4 *>(a.hw[0] + a.hwoff[2]) : nullptr;
+    const f4 *wb1 = HEAD ? reinterpret_cast<const f4 *>(a.hw[1] + a.hwoff[0]) : nullptr, *wb2 = HEAD ? reinterpret_cast<const f4 *>(a.hw[1] + a.hwoff[1]) : nullptr,
+             *wb3 = HEAD ? reinterpret_cast<const f4 *>(a.hw[1] + a.hwoff[2]) : nullptr;
     const float neg_inf = -__builtin_inff();
     f4 r[4];
     const long long ntiles = ((long long)a.rows + 63) / 64;
@@ -689,6 +714,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
         if (u >= last) break;
         const long long tl = tile_of(u);
         asm volatile("" : "+s"(w1), "+s"(w2));
+        if constexpr (HEAD) asm volatile("" : "+s"(wa1), "+s"(wa2), "+s"(wa3), "+s"(wb1), "+s"(wb2), "+s"(wb3));
         const long long wrow0 = tl * 64 + 16 * wave;
         long long row = wrow0 + pos;          // accumulator-layout row of this lane
         if (row >= a.rows) row = a.rows - 1;
@@ -757,7 +783,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
         for (int mb = 0; mb < NK2; ++mb) x2[mb] = x1[mb % NK1];
         __syncthreads();
 #else
-        rc_layer<NK1, NK2>(x1, x2, w2, a.bias + a.boff[1], lds, p, 0.0f, NK0 > 0 ? w1 : w2, NK0 > 0 ? NK0 : NK1, NK0 > 0 ? NK1 : NK2, t, lane, r, an);
+        if constexpr (HEAD) rc_layer<NK1, NK2>(x1, x2, w2, a.bias + a.boff[1], lds, p, 0.0f, wa1, NK2, H1, t, lane, r, an);
+        else rc_layer<NK1, NK2>(x1, x2, w2, a.bias + a.boff[1], lds, p, 0.0f, NK0 > 0 ? w1 : w2, NK0 > 0 ? NK0 : NK1, NK0 > 0 ? NK1 : NK2, t, lane, r, an);
 #endif
         // rows leave line-wise through the same buffer.  (Measured and dropped: the next tile's z rows requested ahead
         // of these stores, 272 us against 258 at FP1's shape; the stores deferred by a tile and spread behind the next
@@ -775,6 +802,39 @@ __global__ __launch_bounds__(RC_THREADS, 2) void fp_chain_kernel(FpChainArgs a) 
             __builtin_amdgcn_wave_barrier();
         }
 #endif
+        if constexpr (HEAD) {
+            const bool live = wrow0 + pos < a.rows;
+            const float last_floor = a.hrelu_last ? 0.0f : neg_inf;
+            auto hstore = [&](int br, auto &y) {
+                if (!live) return;
+                float *__restrict__ orow = a.hout[br] + (size_t)row * a.hout_stride[br];
+                const int cout = a.hcout[br];
+#pragma unroll
+                for (int mb = 0; mb < H3; ++mb) {
+                    const int c0 = 16 * mb + 4 * g;
+                    if (c0 + 4 <= cout) *reinterpret_cast<f4 *>(orow + c0) = y[mb];
+                    else {
+                        if (c0 < cout) orow[c0] = y[mb].x;
+                        if (c0 + 1 < cout) orow[c0 + 1] = y[mb].y;
+                        if (c0 + 2 < cout) orow[c0 + 2] = y[mb].z;
+                    }
+                }
+            };
+            {   // class stack (x2 stays live for the box stack)
+                f4 y1[H1], y2[H2], y3[H3];
+                rc_layer<NK2, H1>(x2, y1, wa1, a.hb[0] + a.hboff[0], lds, p, 0.0f, wa2, H1, H2, t, lane, r, an);
+                rc_layer<H1, H2>(y1, y2, wa2, a.hb[0] + a.hboff[1], lds, p, 0.0f, wa3, rc_next_nkb(H2, H3), H3, t, lane, r, an);
+                rc_layer<H2, H3>(y2, y3, wa3, a.hb[0] + a.hboff[2], lds, p, last_floor, wb1, NK2, H1, t, lane, r, an);
+                hstore(0, y3);
+            }
+            {   // box stack; behind its last chunk: the first chunk of the FP module's layer for the next tile
+                f4 y1[H1], y2[H2], y3[H3];
+                rc_layer<NK2, H1>(x2, y1, wb1, a.hb[1] + a.hboff[0], lds, p, 0.0f, wb2, H1, H2, t, lane, r, an);
+                rc_layer<H1, H2>(y1, y2, wb2, a.hb[1] + a.hboff[1], lds, p, 0.0f, wb3, rc_next_nkb(H2, H3), H3, t, lane, r, an);
+                rc_layer<H2, H3>(y2, y3, wb3, a.hb[1] + a.hboff[2], lds, p, last_floor, w2, NK1, NK2, t, lane, r, an);
+                hstore(1, y3);
+            }
+        }
     }
 }
 
@@ -824,6 +884,52 @@ int fp_chain_launch(void *stream, int b, int n, int m, int c_skip, const float *
     FC_TRY(6, 16, 16, (g_fpc_mask & 2) && c_skip % 4 == 0 && c_skip > 4 && dims[0] == 96)           // FP2: 96 skip channels -> 256 -> 256
 #undef FC_TRY
     return 0;
+}
+
+static int g_fph_tiles = 2;   // pdm_fp_head_fused: tiles per workgroup
+}  // namespace pdm
+extern "C" int pdm_tune_fp_head_tiles(int n) { const int old = pdm::g_fph_tiles; if (n > 0) pdm::g_fph_tiles = n; return old; }
+namespace pdm {
+// FP module (hoisted form, raw skip channels, 16 -> 128 -> 128) + the point head's two 128 -> 256 -> 256 -> <= 16 stacks in one
+// launch (fp_chain_kernel<0, 8, 8, true>).  Returns 1 in *launched when the shapes fit.
+int fp_head_launch(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride, const float *skip_pm,
+                   const int *idx, const float *weight, const int *dims, const float *wpack, const float *bias, float *out_pm,
+                   int out_stride, int cout, const int *hdims, const float *hw_a, const float *hb_a, const float *hw_b,
+                   const float *hb_b, int relu_last, float *out_a, int out_stride_a, int cout_a, float *out_b, int out_stride_b,
+                   int cout_b, int *launched) {
+    *launched = 0;
+    const long long rows = (long long)b * n;
+    if (rows < 32768 || rows >= (1ll << 31) || (long long)b * m * z_stride >= (1ll << 31)) return 0;
+    if (!(c_skip <= 4 && dims[0] == 16 && dims[1] == 128 && dims[2] == 128 && hdims[0] == 128 && hdims[1] == 256 && hdims[2] == 256 &&
+          hdims[3] == 16 && cout == 128))
+        return 0;
+    FpChainArgs a{};
+    a.nt_out = g_fpc_nt;
+    a.rows = (int)rows; a.n = n; a.m = m; a.c_skip = c_skip; a.z_stride = z_stride;
+    a.z = z_pm; a.skip = skip_pm; a.weight = weight; a.idx = idx; a.wpack = wpack; a.bias = bias;
+    a.woff[0] = 0; a.boff[0] = 0; a.woff[1] = dims[0] * dims[1]; a.boff[1] = dims[1];
+    a.out = out_pm; a.out_stride = out_stride; a.cout = cout;
+    a.hw[0] = hw_a; a.hb[0] = hb_a; a.hw[1] = hw_b; a.hb[1] = hb_b;
+    int wo = 0, bo = 0;
+    for (int l = 0; l < 3; ++l) {
+        a.hwoff[l] = wo; a.hboff[l] = bo;
+        wo += hdims[l] * hdims[l + 1];
+        bo += hdims[l + 1];
+    }
+    a.hout[0] = out_a; a.hout_stride[0] = out_stride_a; a.hcout[0] = cout_a;
+    a.hout[1] = out_b; a.hout_stride[1] = out_stride_b; a.hcout[1] = cout_b;
+    a.hrelu_last = relu_last;
+    // tiles per workgroup (consecutive ones, see the kernel): a tile of this kernel is seven layers long, so with the chain kernels'
+    // grid cap (3072 workgroups of 3 tiles at the bench shape: 5.3 rounds of 512 resident ones) a sixth of the launch ran with a
+    // third of the chip (2.07 ms); short workgroups even out like the pair kernel's do
+    const long long tiles = (rows + 63) / 64;
+    const long long per8 = (tiles + 7) / 8;
+    long long wgs = 8 * ((per8 + g_fph_tiles - 1) / g_fph_tiles);
+    if (wgs > (1 << 20)) wgs = 1 << 20;
+    const int grid = (int)wgs;
+    hipLaunchKernelGGL((fp_chain_kernel<0, 8, 8, true>), dim3(grid), dim3(RC_THREADS), 0, as_stream(stream), a);
+    *launched = 1;
+    return check_launch("fp_head_fused");
 }
 
 static bool rc_shape_is(int nlayers, const int *dims, int k0, int k1, int k2, int k3) {
@@ -941,5 +1047,35 @@ extern "C" int pdm_bev_head_fused(void *stream, int B, int H, int W, int C, cons
                                         out_stride, cout, &launched);
     if (rc) return rc;
     PDM_REQUIRE(launched, PDM_E_BADARG, "bev_head_fused: no instantiation for these widths");
+    return 0;
+}
+
+// The backbone's last FP module (first layer's known part pre-applied: z, as pdm_fp_mlp_fused_pre) and the point head's two
+// stacks (as pdm_rows_mlp_fused_pair) in ONE launch: out_pm = the module's output rows (point_features), out_a / out_b = the
+// stacks' outputs on them.  Bit-identical to pdm_fp_mlp_fused_pre through the chain kernel followed by pdm_rows_mlp_fused_pair.
+// Only the shapes rows_chain.hip instantiates (<= 4 skip channels, 128 -> 128; stacks 128 -> 256 -> 256 -> <= 16, >= 32768 rows):
+// PDM_E_BADARG otherwise, and the caller issues the two calls.
+extern "C" int pdm_fp_head_fused(void *stream, int b, int n, int m, int c_skip, const float *z_pm, int z_stride, const float *skip_pm,
+                                 const int *idx, const float *weight, const int *dims, const float *wpack, const float *bias,
+                                 float *out_pm, int out_stride, int cout, const int *hdims, const float *hw_a, const float *hb_a,
+                                 const float *hw_b, const float *hb_b, int relu_last, float *out_a, int out_stride_a, int cout_a,
+                                 float *out_b, int out_stride_b, int cout_b) {
+    PDM_REQUIRE(b >= 0 && n >= 0 && m >= 1 && c_skip >= 0, PDM_E_BADARG, "fp_head_fused: bad size");
+    if (b == 0 || n == 0) return 0;
+    PDM_REQUIRE(z_pm && idx && weight && dims && wpack && bias && out_pm && hdims && hw_a && hb_a && hw_b && hb_b && out_a && out_b &&
+                    (c_skip == 0 || skip_pm), PDM_E_BADARG, "fp_head_fused: null pointer");
+    PDM_REQUIRE(out_a != out_b && cout_a > 0 && cout_b > 0 && cout_a <= 16 && cout_b <= 16 && cout_a <= out_stride_a && cout_b <= out_stride_b &&
+                    out_stride_a % 4 == 0 && out_stride_b % 4 == 0 && out_stride % 4 == 0 && cout <= out_stride && z_stride % 4 == 0 && z_stride >= 128,
+                PDM_E_BADARG, "fp_head_fused: strides / widths");
+    PDM_REQUIRE(((reinterpret_cast<uintptr_t>(z_pm) | reinterpret_cast<uintptr_t>(wpack) | reinterpret_cast<uintptr_t>(bias) |
+                  reinterpret_cast<uintptr_t>(out_pm) | reinterpret_cast<uintptr_t>(hw_a) | reinterpret_cast<uintptr_t>(hb_a) |
+                  reinterpret_cast<uintptr_t>(hw_b) | reinterpret_cast<uintptr_t>(hb_b) | reinterpret_cast<uintptr_t>(out_a) |
+                  reinterpret_cast<uintptr_t>(out_b)) & 15) == 0, PDM_E_BADARG, "fp_head_fused: buffers must be 16-byte aligned");
+    int launched = 0;
+    const int rc = pdm::fp_head_launch(stream, b, n, m, c_skip, z_pm, z_stride, skip_pm, idx, weight, dims, wpack, bias, out_pm, out_stride,
+                                       cout, hdims, hw_a, hb_a, hw_b, hb_b, relu_last, out_a, out_stride_a, cout_a, out_b, out_stride_b,
+                                       cout_b, &launched);
+    if (rc) return rc;
+    PDM_REQUIRE(launched, PDM_E_BADARG, "fp_head_fused: no instantiation for these shapes");
     return 0;
 }

@@ -118,9 +118,13 @@ class PointHeadBox(PointHeadTemplate):
         tb_dict.update(tb_dict_2)
         return point_loss_cls + point_loss_box, tb_dict
 
-    def _layers(self, point_features):
+    def _layers(self, point_features, deferred=None):
         """The two MLPs.  Inference: per-row fused kernels (BatchNorm folded) when the features are fp32 rows on the
-        GPU; otherwise the torch layers."""
+        GPU; otherwise the torch layers.  deferred: the backbone's last FP module not yet run (fused.DeferredFP), whose
+        output point_features is: run with the two stacks in one launch when the shapes fit, else filled first."""
+        if deferred is not None and not self._fp_fusable(point_features, deferred):
+            deferred.materialize()
+            deferred = None
         infer = (not self.training and not torch.is_grad_enabled() and point_features.is_cuda
                  and point_features.dtype == torch.float32 and point_features.dim() == 2
                  and getattr(self, 'use_fused', True))
@@ -140,6 +144,9 @@ class PointHeadBox(PointHeadTemplate):
                     xb = fused.cached_layers_x3(self, 'box_x3', self.box_layers, lambda: _fc_layers(self.box_layers), point_features.device)
                     fused.rows_forward_x3(xc, rows, cls, relu_last=False)
                     fused.rows_forward_x3(xb, rows, box, relu_last=False)
+                elif deferred is not None:
+                    # FP module + both stacks in one launch: the rows are written once and not read back
+                    fused.fp_head_forward(deferred, pc, pb, cls, box, relu_last=False)
                 elif list(pc.dims) == list(pb.dims) and getattr(self, 'use_pair', True):
                     # one launch for both stacks (the rows are read once); bit-identical to the two calls below
                     fused.rows_forward_pair(pc, pb, rows, cls, box, relu_last=False)
@@ -148,6 +155,26 @@ class PointHeadBox(PointHeadTemplate):
                     fused.rows_forward(pb, rows, box, relu_last=False)
                 return cls[0, :, :ncls], box[0, :, :nbox]
         return self.cls_layers(point_features), self.box_layers(point_features)
+
+    def _fp_fusable(self, point_features, deferred):
+        """May the deferred FP module run inside the point head's launch (pdm_fp_head_fused)?"""
+        if (self.training or torch.is_grad_enabled() or not point_features.is_cuda or point_features.dtype != torch.float32
+                or point_features.dim() != 2 or not getattr(self, 'use_fused', True) or not getattr(self, 'use_pair', True)
+                or getattr(self, 'use_x3', False) or not getattr(self, 'use_fp_fusion', False)
+                or point_features.data_ptr() != deferred.out_pm.data_ptr()):
+            return False
+        pc = fused.cached_layers(self, 'cls', self.cls_layers, lambda: _fc_layers(self.cls_layers), point_features.device)
+        pb = fused.cached_layers(self, 'box', self.box_layers, lambda: _fc_layers(self.box_layers), point_features.device)
+        return pc is not None and pb is not None and deferred.fits_head(pc, pb)
+
+    def wants_deferred_fp(self):
+        """Should the backbone leave its last FP module to this head (batch_dict['defer_last_fp'])?  OPT-IN (use_fp_fusion):
+        the one-launch form is bit-identical to the separate launches and NOT faster at the bench shape — 2.14 ms against
+        2.10 for the last FP module + both stacks + decode (tools/diag/fp_head_rate.py): inside a workgroup the module's
+        gathers, staging and stores still run ahead of its MFMAs, tile by tile, as they do in its own launch."""
+        return (not self.training and not torch.is_grad_enabled() and getattr(self, 'use_fused', True) and getattr(self, 'use_pair', True)
+                and not getattr(self, 'use_x3', False) and getattr(self, 'use_fp_fusion', False)
+                and not _get(self.model_cfg, 'USE_POINT_FEATURES_BEFORE_FUSION', False))
 
     def _decode_fused(self, batch_dict, cls, box):
         """Eval mode on the GPU: scores and decoded boxes of all points in one HIP pass (pdm_point_head_decode) instead
@@ -183,7 +210,11 @@ class PointHeadBox(PointHeadTemplate):
             point_features = batch_dict['point_features_before_fusion']
         else:
             point_features = batch_dict['point_features']
-        point_cls_preds, point_box_preds = self._layers(point_features)
+        deferred = batch_dict.pop('point_features_deferred', None)
+        if deferred is not None and point_features is not batch_dict.get('point_features'):
+            deferred.materialize()      # this head reads other rows: the module's output is still owed to the detector
+            deferred = None
+        point_cls_preds, point_box_preds = self._layers(point_features, deferred)
         if self._decode_fused(batch_dict, point_cls_preds, point_box_preds):
             self.forward_ret_dict = {'point_cls_preds': point_cls_preds, 'point_box_preds': point_box_preds}
             return batch_dict

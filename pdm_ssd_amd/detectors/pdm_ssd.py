@@ -14,8 +14,15 @@ class PDMSSD(Detector3DTemplate):
         self.module_list = self.build_networks()
 
     def forward(self, batch_dict):
+        # the point head can run the backbone's last FP module inside its own launch (pdm_fp_head_fused)
+        head = getattr(self, 'point_head', None)
+        if head is not None and hasattr(head, 'wants_deferred_fp') and head.wants_deferred_fp():
+            batch_dict['defer_last_fp'] = True
         for cur_module in self.module_list:
             batch_dict = cur_module(batch_dict)
+        owed = batch_dict.pop('point_features_deferred', None)
+        if owed is not None:            # (no module took it)
+            owed.materialize()
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict

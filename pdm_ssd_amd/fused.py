@@ -343,6 +343,47 @@ def rows_forward_pair(pk_a, pk_b, in_pm, out_a, out_b, relu_last=True):
                  out_a.data_ptr(), out_a.shape[-1], pk_a.cout, out_b.data_ptr(), out_b.shape[-1], pk_b.cout)
 
 
+class DeferredFP:
+    """The backbone's last FP module, prepared but not yet run: its output rows `out_pm` (B, n, C) are allocated and handed on
+    as point_features, and are filled either together with the point head's stacks (fp_head_forward: one launch) or by
+    materialize().  Whoever asked the backbone to defer (batch_dict['defer_last_fp']) owns that call."""
+
+    def __init__(self, pk, z, skip_pm, idx, weight, out_pm):
+        self.pk, self.z, self.skip_pm, self.idx, self.weight, self.out_pm = pk, z, skip_pm, idx, weight, out_pm
+        self.done = False
+
+    def materialize(self):
+        if not self.done:
+            fp_forward_pre(self.pk, self.z, self.skip_pm, self.idx, self.weight, self.out_pm)
+            self.done = True
+        return self.out_pm
+
+    def fits_head(self, pk_a, pk_b):
+        B, n, _ = self.out_pm.shape
+        cs = 0 if self.skip_pm is None else self.skip_pm.shape[2]
+        return (not self.done and cs <= 4 and list(self.pk.dims) == [16, 128, 128] and self.pk.cout == 128 and B * n >= 32768
+                and list(pk_a.dims) == [128, 256, 256, 16] == list(pk_b.dims) and self.z.shape[2] % 4 == 0 and self.z.shape[2] >= 128)
+
+
+def fp_head_forward(d, pk_a, pk_b, out_a, out_b, relu_last=False):
+    """pdm_fp_head_fused: the deferred FP module `d` and the two per-row stacks over its output in one launch."""
+    assert d.fits_head(pk_a, pk_b) and out_a.is_contiguous() and out_b.is_contiguous()
+    B, m, _ = d.z.shape
+    n = d.idx.shape[1]
+    cs = 0 if d.skip_pm is None else d.skip_pm.shape[2]
+    rows = B * n
+    _count("pdm_fp_mlp_fused_pre", rows, d.pk)
+    tag = f"pdm_rows_mlp_fused_pair[{pk_a.nlayers} layers, {pk_a.cin} in, {rows} rows]"
+    _count(tag, rows, pk_a)
+    _count(tag, rows, pk_b)
+    _native.call("pdm_fp_head_fused", _stream(d.z), B, n, m, cs, d.z.data_ptr(), d.z.shape[2],
+                 0 if d.skip_pm is None else d.skip_pm.data_ptr(), d.idx.data_ptr(), d.weight.data_ptr(), d.pk.dims_ptr,
+                 d.pk.wpack.data_ptr(), d.pk.bias.data_ptr(), d.out_pm.data_ptr(), d.out_pm.shape[2], d.pk.cout, pk_a.dims_ptr,
+                 pk_a.wpack.data_ptr(), pk_a.bias.data_ptr(), pk_b.wpack.data_ptr(), pk_b.bias.data_ptr(), 1 if relu_last else 0,
+                 out_a.data_ptr(), out_a.shape[-1], pk_a.cout, out_b.data_ptr(), out_b.shape[-1], pk_b.cout)
+    d.done = True
+
+
 def sa_scale_forward_pre(pk, xyz, new_xyz, z, z_coff, idx, out_pm, out_coff):
     """SA scale whose first layer's feature part was applied to the source points: z (B,N,width)."""
     B, N, _ = xyz.shape

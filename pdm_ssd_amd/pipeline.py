@@ -251,9 +251,14 @@ class PipelinedHotPath:
                     if self.dense_head is not None and self.heads_overlap:
                         self.dense_head(d)
             bd['after_sa_hook'] = start_neck
+        if self.point_head is not None and hasattr(self.point_head, 'wants_deferred_fp') and self.point_head.wants_deferred_fp():
+            bd['defer_last_fp'] = True      # the backbone's last FP module runs inside the point head's launch
         bd = self.backbone(bd)
         if self.point_head is not None:
             bd = self.point_head(bd)
+        owed = bd.pop('point_features_deferred', None)
+        if owed is not None:
+            owed.materialize()
         if self.neck is not None:
             torch.cuda.current_stream().wait_stream(self.neck_stream)
             if self.dense_head is not None and not self.heads_overlap:

@@ -235,7 +235,7 @@ class PointnetFPModule(nn.Module):
         return pointnet2_utils.three_nn_weights(unknown, known)
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
-                known_feats: torch.Tensor, interp=None) -> torch.Tensor:
+                known_feats: torch.Tensor, interp=None, defer=None) -> torch.Tensor:
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B, mlp[-1], n).
 
         In eval mode without autograd, interpolation + concat + MLP run as one fused HIP kernel and the
@@ -272,7 +272,12 @@ class PointnetFPModule(nn.Module):
                         z = torch.empty((known_pm.shape[0], known_pm.shape[1], prepack.width), dtype=torch.float32,
                                         device=known_feats.device)
                         fused.rows_forward(prepack, known_pm, z, relu_last=False)
-                        fused.fp_forward_pre(pk1, z, skip_pm, idx, weight.contiguous(), out_pm)
+                        if defer is not None:
+                            # the caller runs this module's last step itself (with the point head: fused.fp_head_forward) or
+                            # calls materialize(); the returned view is of rows not yet written
+                            defer.append(fused.DeferredFP(pk1, z, skip_pm, idx.contiguous(), weight.contiguous(), out_pm))
+                        else:
+                            fused.fp_forward_pre(pk1, z, skip_pm, idx, weight.contiguous(), out_pm)
                     else:
                         fused.fp_forward(pk, known_pm, skip_pm, idx, weight.contiguous(), out_pm)
                     return out_pm.transpose(1, 2)

@@ -184,6 +184,54 @@ def test_point_head_one_launch_equals_two_launches(dev, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N,kind", [(2, 16384, "uniform"), (3, 16384, "lidar")])
+def test_last_fp_module_inside_the_point_head_launch_equals_separate_launches(dev, B, N, kind):
+    """pdm_fp_head_fused (the backbone's last FP module + both stacks of the point head, one launch) against the separate
+    launches: bit-equal to FP-through-the-chain-kernel + pdm_rows_mlp_fused_pair, 1e-4 against the LDS-tiled FP kernel
+    (another summation order), and the module's rows (point_features) are really written."""
+    from pdm_ssd_amd import _native
+    torch.manual_seed(5)
+    model = build_pdm_ssd().to(dev).eval()
+    cl = synthetic.uniform_clouds(B, N, 3) if kind == "uniform" else synthetic.lidar_like_clouds(B, N, 3)
+    pts = torch.from_numpy(synthetic.to_batch_points(cl)).to(dev)
+    calls = []
+    orig = _native.call
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    keys = ('point_features', 'batch_cls_preds', 'batch_box_preds', 'point_cls_scores')
+    def run(fusion, mask):
+        model.point_head.use_fp_fusion = fusion
+        old = _native.lib().pdm_tune_fp_chain_mask(mask)
+        calls.clear()
+        _native.call = spy
+        try:
+            with torch.no_grad():
+                bd = {'batch_size': B, 'points': pts.clone(), 'points_per_sample_checked': True}
+                if model.point_head.wants_deferred_fp():
+                    bd['defer_last_fp'] = True
+                bd = model.point_head(model.backbone_3d(bd))
+                assert 'point_features_deferred' not in bd
+        finally:
+            _native.call = orig
+            _native.lib().pdm_tune_fp_chain_mask(old)
+        return {k: bd[k].clone() for k in keys}, list(calls)
+    fusedv, c1 = run(True, 3)
+    apart, c2 = run(False, 3)          # FP1 through the chain kernel, then the pair launch
+    tiled, c3 = run(False, 2)          # the default of the unfused path: FP1 through the LDS-tiled kernel
+    model.point_head.use_fp_fusion = False      # (the default: an opt-in form)
+    assert c1.count("pdm_fp_head_fused") == 1 and c1.count("pdm_rows_mlp_fused_pair") == 0
+    assert c2.count("pdm_fp_head_fused") == 0 and c2.count("pdm_rows_mlp_fused_pair") == 1
+    assert c1.count("pdm_fp_mlp_fused_pre") == c2.count("pdm_fp_mlp_fused_pre") - 1       # the last FP module went into the head's launch
+    for k in keys:
+        assert torch.isfinite(fusedv[k]).all(), k
+        assert torch.equal(fusedv[k], apart[k]), k
+        scale = float(tiled[k].abs().max()) + 1e-6
+        assert float((fusedv[k] - tiled[k]).abs().max()) <= 1e-4 * max(1.0, scale), k
+    assert float(fusedv['point_features'].abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_detector_training_contract_and_backward(dev):
     torch.manual_seed(1)
     model = build_pdm_ssd(SMALL).to(dev).train()
