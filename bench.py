@@ -242,17 +242,24 @@ def reference_op_section(backbone, points, B, iters=5):
     conc = None
     try:
         cur = torch.cuda.current_stream()
-        per = int(os.environ.get("PDM_BENCH_CHAIN", "2"))       # plan entries per chain: 2 = one chain per level, 1 = per (level, scale)
-        streams = [torch.cuda.Stream() for _ in range(len(plan) // per)]
+        # which SA levels share a chain: "1|2|34" (default) = levels 1 and 2 on their own streams, 3 and 4 one after the other on a
+        # third; "1|2|3|4" = one chain per level.  Measured with tools/diag/api_block.py --chains: 399 / 406 / 434 us for three / four /
+        # two chains (uniform clouds) — a hipGraph runs at most four branches side by side on ROCm 7.2, and the latency-bound
+        # launches of a chain wait for whole rounds of workgroups beside another chain's streaming copies, so more chains is not better.
+        spec = os.environ.get("PDM_BENCH_CHAIN", "1|2|34")
+        chains = [[int(c) - 1 for c in part] for part in spec.split("|")]
+        assert sorted(l for ch in chains for l in ch) == list(range(len(plan) // 2)), spec
+        streams = [torch.cuda.Stream() for _ in chains]
         def by_level():
-            for li, st in enumerate(streams):
+            for levels, st in zip(chains, streams):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     with pu.shared_search_grids():
-                        for radius, ns, x, nx, f, xt in plan[per * li:per * li + per]:
-                            idx = pu.ball_query(radius, ns, x, nx)
-                            pu.grouping_operation(xt, idx)
-                            pu.grouping_operation(f, idx)
+                        for li in levels:
+                            for radius, ns, x, nx, f, xt in plan[2 * li:2 * li + 2]:
+                                idx = pu.ball_query(radius, ns, x, nx)
+                                pu.grouping_operation(xt, idx)
+                                pu.grouping_operation(f, idx)
             for st in streams:
                 cur.wait_stream(st)
         by_level()
@@ -271,7 +278,8 @@ def reference_op_section(backbone, points, B, iters=5):
         torch.cuda.synchronize()
         cms = e0.elapsed_time(e1) / 20
         conc = {"ms_per_step": round(cms, 4), "GBps": round(mb / cms, 1), "frac_of_hbm_peak": round(mb / cms / HBM_PEAK_GBS, 4),
-                "timed_as": "hipGraph replay, the four SA levels as four independent chains on four streams (fork / join only)"}
+                "chains": spec,
+                "timed_as": "hipGraph replay, the SA levels as independent chains on separate streams (fork / join only): " + spec}
     except Exception as e:
         print(f"[bench] API-exact sequence by level: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
     # (Measured and dropped: the same 26 calls with the 8 searches on a second stream, every group_points call behind the event of

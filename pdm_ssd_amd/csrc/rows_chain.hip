@@ -249,8 +249,11 @@ __device__ __forceinline__ void rc_first_fragments(f4 (&an)[4], const f4 *lds, i
 }
 
 // NK0 = k-blocks (16 channels) of the input, NK1 .. NK3 = output blocks of layers 1 .. 3 (0 = layer absent)
+#ifndef DW_WGS
+#define DW_WGS 2    // depthwise form: workgroups per CU the register budget is set for
+#endif
 template <int NK0, int NK1, int NK2, int NK3, bool DW = false>
-__global__ __launch_bounds__(RC_THREADS, 2) void rows_chain_kernel(RowsChainArgs a) {
+__global__ __launch_bounds__(RC_THREADS, DW ? DW_WGS : 2) void rows_chain_kernel(RowsChainArgs a) {
     __shared__ __attribute__((aligned(16))) f4 lds[2 * RC_CHUNK_F4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int pos = lane & 15, g = lane >> 4;

@@ -94,6 +94,13 @@ with torch.no_grad():
                     with torch.cuda.stream(a):
                         scale(plan[2 * li]); scale(plan[2 * li + 1])
                     continue
+                if CHAINS in (2, 3):
+                    # 2: level 1 (grid build, searches, small copies: latency-bound, 0.1 of the 1.68 GB) on one stream, levels 2-4 (the
+                    #    streaming copies) one after the other on a second.  3: levels 1 | 2 | 3 + 4.
+                    st = streams[0] if li == 0 else streams[1] if (CHAINS == 2 or li == 1) else streams[2]
+                    with torch.cuda.stream(st):
+                        scale(plan[2 * li]); scale(plan[2 * li + 1])
+                    continue
                 # 8 chains: the level's grid build + first search on a, the second scale behind the build only.
                 # 9 = the same, and the six feature gathers of levels 2-4 (the streaming part: 1.2 of 1.68 GB) AFTER every chain
                 # has been joined, one after the other: searches and small copies no longer wait for slots beside them.

@@ -21,7 +21,9 @@ raw = logits.permute(0, 2, 3, 1)          # (B, H, W, num_class) view of the (B,
 buf = raw._base if raw._base is not None else raw
 while buf._base is not None:
     buf = buf._base
-nwg = 3072     # 256 CUs x pdm_tune_rows_chain_wg_per_cu (12); two are resident per CU at a time
+cap = _native.lib().pdm_tune_rows_chain_dw_wg_per_cu(1)
+_native.lib().pdm_tune_rows_chain_dw_wg_per_cu(cap)
+nwg = 256 * cap     # the kernel's grid: 256 CUs x pdm_tune_rows_chain_dw_wg_per_cu (two resident per CU at a time)
 ts = buf.contiguous().view(-1).view(torch.int64)[: nwg * 2 * 4].view(nwg, 2, 4).cpu()
 d = (ts[:, :, 1:] - ts[:, :, :-1]).double()
 for k in (0, 1):

@@ -28,11 +28,11 @@ with torch.no_grad():
 l.pdm_tune_rows_chain_xcd(1)
 with torch.no_grad():
     for n in (2, 3, 4, 6, 8, 12, 24):        # grid cap = 256 CUs x n workgroups (two resident per CU)
-        old = l.pdm_tune_rows_chain_wg_per_cu(n)
+        old = l.pdm_tune_rows_chain_dw_wg_per_cu(n)
         m.dense_head({'spatial_features': sf}); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20): m.dense_head({'spatial_features': sf})
         e1.record(); torch.cuda.synchronize()
         print(f"heat-map head, grid = 256 x {n:2d} workgroups: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
-        l.pdm_tune_rows_chain_wg_per_cu(old)
+        l.pdm_tune_rows_chain_dw_wg_per_cu(old)

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for q in 4 8 16; do
-for ch in 4 8 9; do
-  echo -n "graph queues=$q chains=$ch: "
-  DEBUG_HIP_FORCE_GRAPH_QUEUES=$q python3 tools/diag/api_block.py uniform 100 --chains $ch | tail -n 1
+for kind in uniform lidar; do
+for ch in 0 2 3 4; do
+  echo -n "$kind chains=$ch: "
+  python3 tools/diag/api_block.py $kind 100 --chains $ch 2>/dev/null | tail -n 1
 done; done
