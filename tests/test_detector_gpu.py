@@ -308,6 +308,36 @@ def test_detector_eval_returns_nms_filtered_predictions(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cap", [(2, 188, 188, 2), (1, 93, 90, 2), (3, 64, 48, 1), (1, 200, 176, 12), (2, 47, 97, 1)])
+def test_heatmap_head_one_kernel_equals_two_kernels_on_odd_maps(dev, B, H, W, cap):
+    """pdm_bev_head_fused (depthwise prologue + per-cell stack in one kernel) against the depthwise kernel followed by the row MLP:
+    bit-equal logits on maps whose sides are not multiples of the 4 x 16 patch, with one, a few and many tiles per workgroup
+    (grid cap), sparse maps with a border."""
+    from pdm_ssd_amd import _native
+    torch.manual_seed(B * 1000 + H + W)
+    head = build_pdm_ssd().dense_head.to(dev).eval()
+    for m in head.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    x = torch.randn(B, H, W, 128, device=dev) * (torch.rand(B, H, W, 1, device=dev) < 0.4)
+    sf = x.permute(0, 3, 1, 2)
+    l = _native.lib()
+    oldcap = l.pdm_tune_rows_chain_dw_wg_per_cu(cap)
+    try:
+        with torch.no_grad():
+            head({'spatial_features': sf})
+            one = head.forward_ret_dict['hm_logits'].clone()
+            head.use_one_kernel = False
+            head({'spatial_features': sf})
+            two = head.forward_ret_dict['hm_logits'].clone()
+            head.use_one_kernel = True
+    finally:
+        l.pdm_tune_rows_chain_dw_wg_per_cu(oldcap)
+    assert tuple(one.shape) == (B, 3, H, W) and torch.isfinite(one).all()
+    assert torch.equal(one, two)
+
+
+@pytest.mark.gpu
 def test_heatmap_head_fused_inference_equals_torch_layers(dev):
     """pdm_bev_depthwise3x3 + the per-cell MFMA row kernels against the torch convolutions of the same module, on a
     channels-last grid like the neck's (with empty cells and a border)."""
