@@ -926,6 +926,8 @@ def main():
             sys.exit(f"[bench] --global-batch {args.global_batch} does not divide over {world} ranks (whole clouds per rank)")
         B, scaling = args.global_batch // world, "strong"
     model = build_detector(device)
+    if os.environ.get("PDM_HM_FUSED_LOSS"):      # A/B knob: 0 = the heat-map head's targets and loss as torch kernels
+        model.dense_head.use_fused_loss = os.environ["PDM_HM_FUSED_LOSS"] != "0"
     if os.environ.get("PDM_FP_HEAD_FUSION"):     # A/B knob: 0 = the last FP module and the point head as separate launches
         model.point_head.use_fp_fusion = os.environ["PDM_FP_HEAD_FUSION"] != "0"
     if args.train:

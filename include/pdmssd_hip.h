@@ -260,6 +260,21 @@ int pdm_point_head_loss(void *stream, long long n_total, int n_per_sample, int b
                         size_t workspace_bytes);
 size_t pdm_point_head_loss_workspace_bytes(long long n_total);
 
+/* Heat-map head in training (the dense half of the hybrid head; /root/reference/pcdet/models/dense_heads/center_head.py:100-160
+ * targets, :232 clamped sigmoid, /root/reference/pcdet/utils/loss_utils.py:266-304 penalty-reduced focal loss).
+ * pdm_heatmap_targets: heatmap (B, C, H, W) fp32, zeroed here, then per gt box (B, M, 8) [x y z dx dy dz heading class >= 1] a
+ *   gaussian of radius max(int(gaussian_radius(dx, dy in cells, min_overlap)), min_radius), window clipped at max_radius,
+ *   max-merged (/root/reference/pcdet/models/model_utils/centernet_utils.py:9-70).  cell = (x - x0) / vx / stride.
+ * pdm_heatmap_focal_loss: logits (B, C, H, W) fp32 / bf16 with element strides; out[0] = - weight * S / max(peaks, 1),
+ *   out[1] = - weight / max(peaks, 1), out[2] = peaks; dlogits (B, C, H, W) contiguous fp32 = d S / d logit (multiply by
+ *   out[1] and the incoming gradient).  Partial sums folded in double in a fixed order: bit-reproducible. */
+int pdm_heatmap_targets(void *stream, int B, int M, int C, int H, int W, const float *gt_boxes, float x0, float y0, float vx,
+                        float vy, float stride, double min_overlap, int min_radius, int max_radius, float *heatmap);
+size_t pdm_heatmap_focal_loss_workspace_bytes(long long n);
+int pdm_heatmap_focal_loss(void *stream, int B, int C, int H, int W, const void *logits, int logits_bf16, long long sb, long long sc,
+                           long long sh, long long sw, const float *heatmap, float weight, float *dlogits, float *out,
+                           void *workspace, size_t workspace_bytes);
+
 /* OPT-IN: the same three-layer per-row MLP with fp32 EMULATED on the bf16 matrix pipe — every fp32 operand split into three
  * bf16 pieces (8 + 8 + 8 significand bits), a product formed from the six leading partial products on
  * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (3/8 of the fp32-MFMA pipe time; dropped terms <= 2^-24 |a b|).

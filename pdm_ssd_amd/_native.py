@@ -88,6 +88,9 @@ _SIGNATURES = {
     "pdm_rows_mlp_fused": [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_point_head_loss": [ctypes.c_longlong, _i, _i, _i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong,
                             _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t],
+    "pdm_heatmap_targets": [_i, _i, _i, _i, _i, _vp, _f, _f, _f, _f, _f, ctypes.c_double, _i, _i, _vp],
+    "pdm_heatmap_focal_loss": [_i, _i, _i, _i, _vp, _i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _vp, _f, _vp, _vp,
+                               _vp, ctypes.c_size_t],
     "pdm_rows_mlp_x3": [_i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp, _i, _vp, _i, _i],
     "pdm_rows_mlp_fused_pair": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i],
     "pdm_fp_head_fused": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
@@ -151,7 +154,7 @@ EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_b
            "pdm_three_nn_grid_workspace_bytes", "pdm_furthest_point_sampling_ws_bytes",
            "pdm_fps_max_coresident_workgroups",
            "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
-           "pdm_sa_pack_rows", "pdm_rows_mlp_x3_stream_bytes", "pdm_point_head_loss_workspace_bytes", "pdm_three_interpolate_grad_ws_bytes",
+           "pdm_sa_pack_rows", "pdm_rows_mlp_x3_stream_bytes", "pdm_point_head_loss_workspace_bytes", "pdm_heatmap_focal_loss_workspace_bytes", "pdm_three_interpolate_grad_ws_bytes",
            "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes", "pdm_bn_parts", "pdm_bn_pool_parts",
            "pdm_tg_stats_parts", "pdm_tg_wgrad_ws_bytes", "pdm_tg_colsum_ws_floats"] + list(_SIGNATURES)
 
@@ -193,6 +196,8 @@ def lib():
         l.pdm_three_interpolate_grad_ws_bytes.argtypes = [_i, _i, _i]
         l.pdm_point_head_loss_workspace_bytes.restype = ctypes.c_size_t
         l.pdm_point_head_loss_workspace_bytes.argtypes = [ctypes.c_longlong]
+        l.pdm_heatmap_focal_loss_workspace_bytes.restype = ctypes.c_size_t
+        l.pdm_heatmap_focal_loss_workspace_bytes.argtypes = [ctypes.c_longlong]
         l.pdm_rows_mlp_x3_stream_bytes.restype = ctypes.c_size_t
         l.pdm_rows_mlp_x3_stream_bytes.argtypes = [_i, _vp]
         l.pdm_sa_pack_rows.restype = ctypes.c_size_t

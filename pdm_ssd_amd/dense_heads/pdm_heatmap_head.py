@@ -119,6 +119,11 @@ class PDMHeatmapHead(nn.Module):
         B, M, _ = gt_boxes.shape
         vx, vy = float(self.voxel_size[0]), float(self.voxel_size[1])
         s = self.feature_map_stride
+        if gt_boxes.is_cuda and gt_boxes.dtype == torch.float32 and getattr(self, 'use_fused_loss', True) and _get(cfg, 'MAX_RADIUS', 8) <= 64:
+            # one launch (pdm_heatmap_targets): the same arithmetic in the same order, gaussians max-merged by atomics
+            from .. import heatmap_loss
+            return heatmap_loss.heatmap_targets(gt_boxes, self.num_class, H, W, float(self.point_cloud_range[0]), float(self.point_cloud_range[1]),
+                                                vx, vy, s, _get(cfg, 'GAUSSIAN_OVERLAP', 0.1), _get(cfg, 'MIN_RADIUS', 2), _get(cfg, 'MAX_RADIUS', 8))
         cx = torch.clamp((gt_boxes[..., 0] - self.point_cloud_range[0]) / vx / s, min=0, max=W - 0.5)
         cy = torch.clamp((gt_boxes[..., 1] - self.point_cloud_range[1]) / vy / s, min=0, max=H - 0.5)
         centers_int = torch.stack((cx, cy), dim=-1).int().long()
@@ -135,9 +140,16 @@ class PDMHeatmapHead(nn.Module):
 
     def get_loss(self, tb_dict=None):
         tb_dict = {} if tb_dict is None else tb_dict
-        pred = self.sigmoid(self.forward_ret_dict['hm_logits'].float())
-        hm_loss = self.hm_loss_func(pred, self.forward_ret_dict['heatmap'])
-        hm_loss = hm_loss * _get(_get(_get(self.model_cfg, 'LOSS_CONFIG'), 'LOSS_WEIGHTS'), 'cls_weight', 1.0)
+        logits, target = self.forward_ret_dict['hm_logits'], self.forward_ret_dict['heatmap']
+        w = _get(_get(_get(self.model_cfg, 'LOSS_CONFIG'), 'LOSS_WEIGHTS'), 'cls_weight', 1.0)
+        if (logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and target.dtype == torch.float32 and target.is_contiguous()
+                and getattr(self, 'use_fused_loss', True) and type(self.hm_loss_func) is loss_utils.FocalLossCenterNet):
+            # clamped sigmoid + penalty-reduced focal loss + its gradient: pdm_heatmap_focal_loss (two launches, bit-reproducible)
+            from .. import heatmap_loss
+            hm_loss = heatmap_loss.heatmap_focal_loss(logits, target, w)
+        else:
+            pred = self.sigmoid(logits.float())
+            hm_loss = self.hm_loss_func(pred, target) * w
         tb_dict['hm_loss'] = hm_loss.detach()
         return hm_loss, tb_dict
 

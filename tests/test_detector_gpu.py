@@ -338,6 +338,70 @@ def test_heatmap_head_one_kernel_equals_two_kernels_on_odd_maps(dev, B, H, W, ca
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,M,seed", [(4, 12, 0), (2, 40, 1), (1, 1, 2), (2, 0, 3)])
+def test_heatmap_targets_kernel_equals_torch_formulation(dev, B, M, seed):
+    """pdm_heatmap_targets against assign_targets' torch formulation (gaussian_radius + one batched scatter-max): the same
+    map bit for bit, with padding rows, boxes on the map's border, coinciding centres, tiny boxes (MIN_RADIUS) and large ones
+    (window clipped at MAX_RADIUS)."""
+    head = build_pdm_ssd().dense_head.to(dev).train()
+    rng = np.random.default_rng(seed)
+    gt = scene_boxes(B, max(M, 1), seed)[:, :M].copy() if M else np.zeros((B, 0, 8), np.float32)
+    if M >= 6:
+        gt[:, 1] = 0.0                                              # a padding row in the middle
+        gt[:, 2, :2] = [0.05, -39.9]                                # on the map's corner
+        gt[:, 3, :3] = gt[:, 4, :3]; gt[:, 3, 7] = gt[:, 4, 7]      # two boxes of one class on one cell
+        gt[:, 5, 3:5] = [0.3, 0.2]                                  # smaller than a cell: MIN_RADIUS
+        gt[0, 0, 3:5] = [30.0, 12.0]                                # a radius beyond MAX_RADIUS
+    g = torch.from_numpy(gt.astype(np.float32)).to(dev)
+    H, W = 188, 188
+    a = head.assign_targets(g, (H, W))
+    head.use_fused_loss = False
+    b = head.assign_targets(g, (H, W))
+    head.use_fused_loss = True
+    assert a.shape == b.shape == (B, 3, H, W) and a.dtype == torch.float32
+    assert torch.equal(a, b)
+    if M >= 6:
+        assert int((a == 1).sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bf16,layout", [(False, "nchw"), (False, "nhwc"), (True, "nhwc")])
+def test_heatmap_focal_loss_kernel_equals_torch_formulation(dev, bf16, layout):
+    """pdm_heatmap_focal_loss (clamped sigmoid + penalty-reduced focal loss + gradient) against the torch formulation under
+    autograd: loss 1e-5, gradient 1e-5 of its scale (fp32) / one bf16 rounding (bf16 logits); saturated logits (the clamp's
+    zero-gradient zone), a map without peaks, strided logits."""
+    from pdm_ssd_amd import heatmap_loss
+    from pdm_ssd_amd.utils import loss_utils
+    torch.manual_seed(7)
+    B, C, H, W = 3, 3, 61, 47
+    head = build_pdm_ssd().dense_head
+    gt = torch.from_numpy(scene_boxes(B, 9, 5)).to(dev)
+    hm = heatmap_loss.heatmap_targets(gt, C, H, W, 0.0, -40.0, 0.4, 0.4, 1, 0.1, 2, 8)
+    for case in ("peaks", "no peaks"):
+        if case == "no peaks":
+            hm = torch.where(hm == 1, torch.full_like(hm, 0.5), hm)
+        x = torch.randn(B, C, H, W, device=dev) * 4
+        x[0, 0, :4, :4] = 30.0; x[0, 1, :4, :4] = -30.0            # clamp(sigmoid) saturates: no gradient there
+        if layout == "nhwc":
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        if bf16:
+            x = x.bfloat16()
+        x1 = x.clone().requires_grad_(True)
+        x2 = x.clone().requires_grad_(True)
+        la = heatmap_loss.heatmap_focal_loss(x1, hm, 1.5)
+        lb = loss_utils.neg_loss_cornernet(head.sigmoid(x2.float()), hm) * 1.5
+        (la * 2.0).backward(); (lb * 2.0).backward()
+        assert la.dtype == torch.float32 and la.dim() == 0
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb))), (case, float(la), float(lb))
+        ga, gb = x1.grad.float(), x2.grad.float()
+        assert x1.grad.dtype == x.dtype and x1.grad.shape == x.shape
+        scale = float(gb.abs().max())
+        tol = (1.0 / 128 if bf16 else 1e-5) * scale
+        assert float((ga - gb).abs().max()) <= tol, (case, float((ga - gb).abs().max()), scale)
+        assert float(ga[0, 0, :4, :4].abs().max()) == 0.0 and float(ga[0, 1, :4, :4].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_heatmap_head_fused_inference_equals_torch_layers(dev):
     """pdm_bev_depthwise3x3 + the per-cell MFMA row kernels against the torch convolutions of the same module, on a
     channels-last grid like the neck's (with empty cells and a border)."""
