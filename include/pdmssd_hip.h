@@ -447,6 +447,9 @@ int pdm_bn_relu_backward_stats(void *stream, int dtype, int layout, long long n,
                                const float *coef, float *grads, float *partial, int relu);
 int pdm_bn_relu_backward_apply(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x, const void *dy,
                                void *dx, const float *coef, float *grads, int relu);
+/* finalize only: grads (4, C) from [parts][C][2] sums (sum g, sum g xhat) a producer of dy has already taken in its epilogue
+ * (pdm_tg_gemm_nt_bs / pdm_tg_gemm_nt_dy_bs): pdm_bn_relu_backward_stats without its pass over dy and x */
+int pdm_bn_finalize_bwd_stats(void *stream, long long n, int C, const float *coef, float *grads, const float *partial, int parts);
 
 /* The tail of an SA scale in training — BatchNorm + ReLU + max over the ns neighbours of each group
  * (pointnet2_modules.py:46-52: the last (BatchNorm2d, ReLU) of the shared MLP, then F.max_pool2d over nsample) — as ONE
@@ -550,6 +553,18 @@ int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long 
 int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
                       const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
                       const float *grads);
+/* The two products above when their result IS the gradient of relu(bn(Bx)) — the data gradient of the layer that follows a
+ * BatchNorm + ReLU in a stack (pointnet2_modules.py:91-97, point_head_template.py:35-48): the epilogue also leaves the statistics
+ * that BatchNorm's backward needs, per slot and column the sums of g = y [bn(Bx) > 0] and of g (Bx - mean) invstd over the ROUNDED
+ * outputs, in bstats (parts, N, 2) fp32 with parts = pdm_tg_stats_parts(R, N) / pdm_tg_dy_stats_parts(R, N) — the reduce pass of
+ * pdm_bn_relu_backward_stats (a second read of Y and Bx) disappears; pdm_bn_finalize_bwd_stats folds the parts.
+ * Bx (R, N) bf16 = that BatchNorm's input, bcoef (4, N) = its coefficients from pdm_bn_finalize_stats. */
+int pdm_tg_gemm_nt_bs(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                      void *Y, long long ldy, const void *Bx, long long ldbx, const float *bcoef, float *bstats);
+int pdm_tg_dy_stats_parts(long long rows, int N);
+int pdm_tg_gemm_nt_dy_bs(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
+                         const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
+                         const float *grads, const void *Bx, long long ldbx, const float *bcoef, float *bstats);
 size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N);
 /* dW (N, K) fp32 (+)= dY (R, N)^T . X (R, K): row slabs summed in a fixed order (bit-reproducible) */
 int pdm_tg_wgrad(void *stream, long long R, int K, int N, const void *dY, long long ldy, const void *X, long long ldx, float *dW,
@@ -561,6 +576,10 @@ int pdm_tg_colsum(void *stream, long long R, int N, const void *Y, long long ld,
 int pdm_tg_pack_weight(void *stream, int N, int K, const float *W, void *Wb, int ldb, void *Wt, int ldt);
 /* the pair a layer needs, every element written: Wb (rows_to, cols_to) = W zero padded, Wt (cols_to, rows_to) = its transpose */
 int pdm_tg_pack_weight_pair(void *stream, int N, int K, const float *W, void *Wb, void *Wt, int rows_to, int cols_to);
+/* the same for many layers in one launch.  jobs: njobs records of 48 bytes in DEVICE memory,
+ * { const float *W; void *Wb; void *Wt; int N, K, rows_to, cols_to; long long first_block; } with first_block[0] = 0,
+ * first_block[j + 1] = first_block[j] + ceil(rows_to[j] * cols_to[j] / 256); total_blocks = their sum */
+int pdm_tg_pack_weight_many(void *stream, int njobs, const void *jobs, long long total_blocks);
 
 
 /* ---- diagnostics (process-global tuning switches used by tools/diag/ A/B measurements; every setting gives

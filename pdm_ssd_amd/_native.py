@@ -107,11 +107,17 @@ _SIGNATURES = {
     "pdm_tg_gemm_nt": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "pdm_tg_gemm_nt_dy": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong,
                           _vp, ctypes.c_longlong, _vp, _vp],
+    "pdm_tg_gemm_nt_bs": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp,
+                          ctypes.c_longlong, _vp, _vp],
+    "pdm_tg_gemm_nt_dy_bs": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp,
+                             ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp],
+    "pdm_bn_finalize_bwd_stats": [ctypes.c_longlong, _i, _vp, _vp, _vp, _i],
     "pdm_tg_wgrad": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _i, _vp, ctypes.c_size_t, _vp],
     "pdm_bn_finalize_stats": [ctypes.c_longlong, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_tg_colsum": [ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "pdm_tg_pack_weight": [_i, _i, _vp, _vp, _i, _vp, _i],
     "pdm_tg_pack_weight_pair": [_i, _i, _vp, _vp, _vp, _i, _i],
+    "pdm_tg_pack_weight_many": [_i, _vp, ctypes.c_longlong],
     "pdm_tune_fps_variant": None,
     "pdm_tune_fused_waves": None,
     "pdm_tune_fused_tiles": None,
@@ -156,7 +162,7 @@ EXPORTS = ["pdm_abi_version", "pdm_last_error", "pdm_ball_query_grid_workspace_b
            "pdm_gather_bev_workspace_bytes", "pdm_nms_workspace_bytes", "pdm_sa_pack_workspace_bytes",
            "pdm_sa_pack_rows", "pdm_rows_mlp_x3_stream_bytes", "pdm_point_head_loss_workspace_bytes", "pdm_heatmap_focal_loss_workspace_bytes", "pdm_three_interpolate_grad_ws_bytes",
            "pdm_group_points_grad_ws_bytes", "pdm_group_concat_cl_grad_ws_bytes", "pdm_bn_parts", "pdm_bn_pool_parts",
-           "pdm_tg_stats_parts", "pdm_tg_wgrad_ws_bytes", "pdm_tg_colsum_ws_floats"] + list(_SIGNATURES)
+           "pdm_tg_stats_parts", "pdm_tg_dy_stats_parts", "pdm_tg_wgrad_ws_bytes", "pdm_tg_colsum_ws_floats"] + list(_SIGNATURES)
 
 
 class NativeLibraryError(RuntimeError):
@@ -209,6 +215,8 @@ def lib():
         l.pdm_tg_colsum_ws_floats.argtypes = [ctypes.c_longlong, _i]
         l.pdm_tg_stats_parts.restype = _i
         l.pdm_tg_stats_parts.argtypes = [ctypes.c_longlong, _i]
+        l.pdm_tg_dy_stats_parts.restype = _i
+        l.pdm_tg_dy_stats_parts.argtypes = [ctypes.c_longlong, _i]
         l.pdm_tg_wgrad_ws_bytes.restype = ctypes.c_size_t
         l.pdm_tg_wgrad_ws_bytes.argtypes = [ctypes.c_longlong, _i, _i]
         l.pdm_bn_parts.restype = _i

@@ -434,17 +434,20 @@ __global__ __launch_bounds__(256) void bn_pool_dx_kernel(const T *__restrict__ x
 }
 
 // ---- per-channel finalize: one wave per channel folds the parts in double -------------------------------------------
+// (four 8-byte loads in flight per lane, a butterfly of wave shuffles instead of six barriers over LDS: every lane ends with the
+// sums, added in a fixed order)
 __device__ __forceinline__ void bn_fold(const float *__restrict__ partial, int parts, int C, int c, double &s, double &q) {
-    __shared__ double sh_s[64], sh_q[64];
+    const float2 *__restrict__ src = reinterpret_cast<const float2 *>(partial) + c;
     double ls = 0.0, lq = 0.0;
-    for (int p = threadIdx.x; p < parts; p += 64) { ls += partial[((size_t)p * C + c) * 2]; lq += partial[((size_t)p * C + c) * 2 + 1]; }
-    sh_s[threadIdx.x] = ls; sh_q[threadIdx.x] = lq;
-    __syncthreads();
-    for (int half = 32; half >= 1; half >>= 1) {
-        if ((int)threadIdx.x < half) { sh_s[threadIdx.x] += sh_s[threadIdx.x + half]; sh_q[threadIdx.x] += sh_q[threadIdx.x + half]; }
-        __syncthreads();
+    int p = threadIdx.x;
+    for (; p + 192 < parts; p += 256) {
+        const float2 v0 = src[(size_t)p * C], v1 = src[(size_t)(p + 64) * C], v2 = src[(size_t)(p + 128) * C], v3 = src[(size_t)(p + 192) * C];
+        ls += v0.x; lq += v0.y; ls += v1.x; lq += v1.y; ls += v2.x; lq += v2.y; ls += v3.x; lq += v3.y;
     }
-    s = sh_s[0]; q = sh_q[0];
+    for (; p < parts; p += 64) { const float2 v = src[(size_t)p * C]; ls += v.x; lq += v.y; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { ls += __shfl_xor(ls, off, 64); lq += __shfl_xor(lq, off, 64); }
+    s = ls; q = lq;
 }
 // forward: mean, biased variance -> invstd, scale, shift; running statistics updated as torch.nn.BatchNorm does
 // (momentum, unbiased variance).  coef layout: [mean | invstd | gamma invstd | beta] (4, C); on entry row 3 holds the pivots.
@@ -634,6 +637,15 @@ extern "C" int pdm_bn_relu_backward_stats(void *stream, int dtype, int layout, l
 extern "C" int pdm_bn_relu_backward_apply(void *stream, int dtype, int layout, long long n, int C, long long L, const void *x,
                                           const void *dy, void *dx, const float *coef, float *grads, int relu) {
     return bn_relu_backward_phases("bn_relu_backward_apply", 2, stream, dtype, layout, n, C, L, x, dy, dx, coef, grads, nullptr, relu);
+}
+
+// Only the finalize step of pdm_bn_relu_backward_stats: grads (4, C) = [dgamma | dbeta | p | q] from sums a producer has already taken —
+// pdm_tg_gemm_nt_bs / pdm_tg_gemm_nt_dy_bs leave [parts][C][2] = per slot sum g and sum g xhat of the gradient they produce
+// (train_gemm.hip); folded in double, in slot order.
+extern "C" int pdm_bn_finalize_bwd_stats(void *stream, long long n, int C, const float *coef, float *grads, const float *partial, int parts) {
+    PDM_REQUIRE(n >= 1 && C >= 1 && coef && grads && partial && parts >= 1, PDM_E_BADARG, "bn_finalize_bwd_stats: bad argument");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n, coef, grads);
+    return check_launch("bn_finalize_bwd_stats");
 }
 
 static int bn_pool_check(const char *who, int dtype, long long G, int ns, int C, const void *a, const void *b, const void *c,

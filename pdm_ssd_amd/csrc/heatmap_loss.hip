@@ -135,9 +135,15 @@ __global__ __launch_bounds__(HM_T) void hm_loss_kernel(HmLossArgs a) {
 }
 
 __global__ __launch_bounds__(64) void hm_loss_finalize_kernel(int blocks, const double *__restrict__ partials, float weight, float *__restrict__ out) {
-    if (threadIdx.x != 0) return;
+    // lane l adds partials l, l + 64, ... in order, then a butterfly over the wave: a fixed order (bit-reproducible) without the
+    // 2048-step dependent chain one thread walked (180 us of a training step)
     double s_peak = 0.0, s_else = 0.0, n_peak = 0.0;
-    for (int k = 0; k < blocks; ++k) { s_peak += partials[3 * k]; s_else += partials[3 * k + 1]; n_peak += partials[3 * k + 2]; }
+    for (int k = threadIdx.x; k < blocks; k += 64) { s_peak += partials[3 * k]; s_else += partials[3 * k + 1]; n_peak += partials[3 * k + 2]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s_peak += __shfl_xor(s_peak, off, 64); s_else += __shfl_xor(s_else, off, 64); n_peak += __shfl_xor(n_peak, off, 64);
+    }
+    if (threadIdx.x != 0) return;
     const double den = n_peak > 1.0 ? n_peak : 1.0;
     out[0] = (float)(-(s_peak + s_else) / den * (double)weight);
     out[1] = (float)(-(double)weight / den);

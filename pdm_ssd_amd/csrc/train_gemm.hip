@@ -74,6 +74,12 @@ struct TgNtArgs {
     const unsigned short *Xa; long long ldxa;   // Yp (R, K) bf16: the BatchNorm's input
     unsigned short *Xo; long long ldxo;         // dY (R, K) bf16 out
     const float *gf;                            // (4, K) fp32 [dgamma | dbeta | p | q] of that BatchNorm's backward
+    // BS (the product IS the gradient of relu(bn(Bx)), e.g. the data gradient of the layer behind that BatchNorm): the statistics of
+    // that BatchNorm's backward are taken from the rounded outputs in the epilogue — per slot and column sum g and sum g xhat with
+    // g = y [bn(Bx) > 0], xhat = (Bx - mean) invstd: the two sums bn_cl_reduce_kernel<MODE 1> (bn_relu.hip) forms, element for element
+    const unsigned short *Bx; long long ldbx;   // (R, N) bf16: that BatchNorm's input
+    const float *bcf;                           // (4, N) fp32 [mean | invstd | scale | shift] (pdm_bn_finalize_stats)
+    float *bstats;                              // [slots][N][2]
     long long R;
     int K, N;
 };
@@ -140,6 +146,32 @@ __device__ __forceinline__ uint4 tg_bn_bwd8(uint4 dz, uint4 y, const TgBnBwd &c,
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Epilogue statistics of a BatchNorm + ReLU backward (TgNtArgs::bstats): eight rounded outputs `v` (the gradient of relu(bn(x)))
+// and the eight inputs `xv` of that BatchNorm at the same place.  a += g, b = fma(g, d invstd, b) with d = x - mean,
+// g = y [fma(d, scale, shift) > 0] — bn_cl_reduce_kernel<MODE 1>'s arithmetic.
+struct TgBsCoef { float mu[8], is[8], sc[8], sh[8]; };
+__device__ __forceinline__ void tg_bs_accum(uint4 v, uint4 xv, const TgBsCoef &c, float (&s1)[8], float (&s2)[8]) {
+    const unsigned wy[4] = {v.x, v.y, v.z, v.w}, wx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * e + h;
+            const float yv = h ? __uint_as_float(wy[e] & 0xffff0000u) : __uint_as_float(wy[e] << 16);
+            const float xx = h ? __uint_as_float(wx[e] & 0xffff0000u) : __uint_as_float(wx[e] << 16);
+            const float d = xx - c.mu[i];
+            const float g = fmaf(d, c.sc[i], c.sh[i]) > 0.f ? yv : 0.f;
+            s1[i] += g;
+            s2[i] = fmaf(g, d * c.is[i], s2[i]);
+        }
+    }
+}
+// the coefficients of columns n .. n + 7; a chunk beyond N reads those of columns 0 .. 7 (its outputs and inputs are zeros: g = 0)
+__device__ __forceinline__ void tg_bs_coef8(TgBsCoef &c, const float *__restrict__ coef, int N, int n) {
+    const int k = n < N ? n : 0;
+    tg_ld8(coef + k, c.mu); tg_ld8(coef + N + k, c.is); tg_ld8(coef + 2 * N + k, c.sc); tg_ld8(coef + 3 * N + k, c.sh);
+}
+
 // 16-byte chunk `chunk` (0..7) of row `row` of a [rows][64] bf16 LDS tile: rows 2i, 2i+1 sit in the two 128-byte halves of
 // a 256-byte bank line, the pair index permutes the chunk — 16 distinct rows reading one logical chunk hit 16 different
 // (half, chunk) slots
@@ -155,7 +187,7 @@ __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + (
 // The product is formed TRANSPOSED (D = W_tile . X_tile^T): a lane then owns one output ROW and, per 4 accumulator
 // registers, 4 CONSECUTIVE channels — 8 bytes of bf16, one ds_write_b64 — where the direct form had 16 scattered 2-byte LDS
 // writes per 32 x 32 tile (the epilogue's LDS writes alone were 1.7x the HBM time of a narrow tile).
-template <int WN, int JT, int XF>
+template <int WN, int JT, int XF, bool BS = false>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
     constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
@@ -307,6 +339,12 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
         }
         // ---- epilogue: bf16 (RNE) into an LDS tile [BM][pitch YP]; lane = output row, 4 registers = 4 consecutive channels
         if (nk == 1 && XB + WB <= MAIN && YB <= XB) w_resident = true;      // the epilogue tile does not reach the weight stage
+        TgBsCoef bcf;
+        if constexpr (BS) {   // fetched per tile (L2-hot): held across the k-loop they cost the widest tile 20 spilled registers
+            const float *cp = a.bcf;
+            asm volatile("" : "+s"(cp));
+            tg_bs_coef8(bcf, cp, a.N, col0 + chunk_o * 8);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = wm * 64 + i * 32 + (lane & 31);
@@ -328,6 +366,15 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
                 }
         }
         __syncthreads();
+        uint4 bx[BS ? BM / RPP : 1];
+        if constexpr (BS) {   // the BatchNorm's inputs under this thread's output chunks, all requested at once (the accumulators are dead)
+            const int n = col0 + chunk_o * 8;
+#pragma unroll
+            for (int i = 0; i < BM / RPP; ++i) {
+                const long long r = row0 + t / CH + RPP * i;
+                bx[i] = (r < a.R && n < a.N) ? *reinterpret_cast<const uint4 *>(a.Bx + r * a.ldbx + n) : make_uint4(0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < BM / RPP; ++i) {
             const int row = t / CH + RPP * i;
@@ -335,7 +382,10 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
             const long long r = row0 + row;
             const int n = col0 + chunk_o * 8;
             if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
-            if (XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
+            if constexpr (BS) {   // rows beyond R / columns beyond N hold zeros: g = 0
+                tg_bs_accum(v, bx[i], bcf, s1, s2);
+            }
+            if (!BS && XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -347,7 +397,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
         }
         __syncthreads();
     }
-    if (XF != 2 && a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
+    if (BS || (XF != 2 && a.stats)) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
         float *red = reinterpret_cast<float *>(smem + MAIN);       // [4 waves][BN columns] sums, then the same of squares
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -368,7 +418,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
         if (t < BN && col0 + t < a.N) {
             const float sa = ((red[t] + red[BN + t]) + red[2 * BN + t]) + red[3 * BN + t];
             const float sb = ((red[4 * BN + t] + red[5 * BN + t]) + red[6 * BN + t]) + red[7 * BN + t];
-            float *o = a.stats + ((long long)slot * a.N + col0 + t) * 2;
+            float *o = (BS ? a.bstats : a.stats) + ((long long)slot * a.N + col0 + t) * 2;
             o[0] = sa; o[1] = sb;
         }
     }
@@ -378,7 +428,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
 // tile) with the X rows of two stages ahead in flight (two register sets that swap roles stage by stage): a wide layer has 4-8
 // k-steps per tile, and one 16 KB stage per workgroup in flight left the kernel waiting for memory at 3.1-3.7 TB/s (head layers
 // 172 -> 152 us).  The narrow tiles keep the loop above: this structure runs them 15-20 % slower (measured).
-template <int XF>
+template <int XF, bool BS = false>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slots) {
     constexpr int WN = 2, JT = 2;
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
@@ -552,6 +602,12 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
         if (kt == nk - 1) {
             // ---- epilogue: bf16 (RNE) into an LDS tile [BM][pitch YP]; lane = output row, 4 registers = 4 consecutive channels
             if (nk == 1 && XB + WB <= MAIN && YB <= XB) w_resident = true;      // the epilogue tile does not reach the weight stage
+            TgBsCoef bcf;
+            if constexpr (BS) {
+                const float *cp = a.bcf;
+                asm volatile("" : "+s"(cp));
+                tg_bs_coef8(bcf, cp, a.N, col0 + chunk_o * 8);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + (lane & 31);
@@ -580,7 +636,11 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
                 const long long r = row0 + row;
                 const int n = col0 + chunk_o * 8;
                 if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
-                if (XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
+                if constexpr (BS) {   // rows beyond R / columns beyond N hold zeros: g = 0
+                    const uint4 bx = (r < a.R && n < a.N) ? *reinterpret_cast<const uint4 *>(a.Bx + r * a.ldbx + n) : make_uint4(0, 0, 0, 0);
+                    tg_bs_accum(v, bx, bcf, s1, s2);
+                }
+                if (!BS && XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
                     const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -603,7 +663,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
     } else {
         while (rt < row_tiles) stage(xr, xa);
     }
-    if (XF != 2 && a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
+    if (BS || (XF != 2 && a.stats)) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
         float *red = reinterpret_cast<float *>(smem + MAIN);       // [4 waves][BN columns] sums, then the same of squares
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -624,7 +684,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
         if (t < BN && col0 + t < a.N) {
             const float sa = ((red[t] + red[BN + t]) + red[2 * BN + t]) + red[3 * BN + t];
             const float sb = ((red[4 * BN + t] + red[5 * BN + t]) + red[6 * BN + t]) + red[7 * BN + t];
-            float *o = a.stats + ((long long)slot * a.N + col0 + t) * 2;
+            float *o = (BS ? a.bstats : a.stats) + ((long long)slot * a.N + col0 + t) * 2;
             o[0] = sa; o[1] = sb;
         }
     }
@@ -833,40 +893,47 @@ __global__ __launch_bounds__(TG_T) void tg_tn_narrow_kernel(TgTnArgs a) {
     }
 }
 
-// out[c][e] = sum of in[c * TG_FOLD + k][e], k < TG_FOLD (in order): one level of a fixed-shape summation tree over the leading
-// dimension (slabs of the weight gradient, row tiles of the BatchNorm statistics).  A single thread per element walking
-// thousands of slabs was a 200 us latency chain per layer; a level of this tree is one coalesced pass over its input.
-constexpr int TG_FOLD = 32;
-__global__ __launch_bounds__(256) void tg_fold_kernel(const float *__restrict__ in, int parts, long long elems, float *__restrict__ out,
-                                                      int accumulate) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
-    const int k0 = blockIdx.y * TG_FOLD, k1 = k0 + TG_FOLD < parts ? k0 + TG_FOLD : parts;
+// out[e] (+)= sum over k < parts of in[k][e], in ONE launch and in a fixed order: a workgroup owns 64 consecutive elements (256-byte
+// lines of every part), its QG groups of 64 threads walk the parts q, q + QG, ... (eight loads in flight per thread, added in
+// order), and the QG partial sums are added in group order through LDS.  (History: one thread per element walking thousands of
+// slabs was a 200 us latency chain per layer; a tree of 32-way levels fixed that at two launches per weight gradient — 83 launches
+// and 0.7 ms of a training step; this form is one launch for any number of parts.)
+constexpr int TG_FOLD_QG = 16;
+__global__ __launch_bounds__(64 * TG_FOLD_QG) void tg_fold_kernel(const float *__restrict__ in, int parts, long long elems, float *__restrict__ out,
+                                                                  int accumulate) {
+    __shared__ float red[TG_FOLD_QG][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, qg = blockDim.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int k = k0; k < k1; ++k) s += in[(long long)k * elems + e];
-    float *o = out + (long long)blockIdx.y * elems + e;
-    *o = accumulate ? *o + s : s;
+    if (e < elems) {
+        int k = q;
+        for (; k + 7 * qg < parts; k += 8 * qg) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[(long long)(k + u * qg) * elems + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < parts; k += qg) s += in[(long long)k * elems + e];
+    }
+    red[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && e < elems) {
+        float tot = red[0][lane];
+        for (int g = 1; g < qg; ++g) tot += red[g][lane];
+        out[e] = accumulate ? out[e] + tot : tot;
+    }
 }
 
-// folds in[parts][elems] down to out[elems] (accumulate: out += ...) through scratch (>= ceil(parts / TG_FOLD) * elems floats)
+// folds in[parts][elems] down to out[elems] (accumulate: out += ...); `scratch` is unused (kept for the callers' workspace layout)
 static int tg_fold(hipStream_t stream, const float *in, int parts, long long elems, float *out, int accumulate, float *scratch) {
-    const unsigned gx = (unsigned)((elems + 255) / 256);
-    float *bufs[2] = {scratch, scratch + (long long)((parts + TG_FOLD - 1) / TG_FOLD) * elems};
-    int which = 0;
-    while (parts > TG_FOLD) {
-        const int np = (parts + TG_FOLD - 1) / TG_FOLD;
-        hipLaunchKernelGGL(tg_fold_kernel, dim3(gx, (unsigned)np), dim3(256), 0, stream, in, parts, elems, bufs[which], 0);
-        in = bufs[which];
-        which ^= 1;
-        parts = np;
-    }
-    hipLaunchKernelGGL(tg_fold_kernel, dim3(gx, 1), dim3(256), 0, stream, in, parts, elems, out, accumulate);
+    (void)scratch;
+    int qg = 1;
+    while (qg < TG_FOLD_QG && qg * 16 < parts) qg <<= 1;      // >= 16 parts per group before another group is added
+    hipLaunchKernelGGL(tg_fold_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * qg), 0, stream, in, parts, elems, out, accumulate);
     return check_launch("tg_fold");
 }
-static size_t tg_fold_scratch_floats(long long parts, long long elems) {
-    const long long l1 = (parts + TG_FOLD - 1) / TG_FOLD, l2 = (l1 + TG_FOLD - 1) / TG_FOLD;
-    return (size_t)((l1 + l2) * elems);
-}
+static size_t tg_fold_scratch_floats(long long parts, long long elems) { (void)parts; (void)elems; return 0; }
 
 // W (N, K) fp32 -> Wb (N, ldb) bf16 and / or Wt (K, ldt) bf16 (transposed), zero padded to the strides
 // (rows_b rows of Wb and rows_t rows of Wt are written: rows >= N of Wb / >= K of Wt are zero padding too)
@@ -880,6 +947,28 @@ __global__ __launch_bounds__(256) void tg_pack_weight_kernel(const float *__rest
     if (Wt && e < (long long)rows_t * ldt) {
         const int k = (int)(e / ldt), n = (int)(e % ldt);
         Wt[e] = (k < K && n < N) ? tg_bf16(W[(long long)n * K + k]) : (unsigned short)0;
+    }
+}
+
+// The same for MANY layers in one launch: job j owns blocks first_block[j] .. first_block[j + 1] - 1 of the grid (a binary search
+// over <= a few hundred jobs) and writes its (rows_to, cols_to) pair whole.  Table in device memory (pdm_tg_pack_weight_many).
+struct TgPackJob { const float *W; unsigned short *Wb, *Wt; int N, K, rows_to, cols_to; long long first_block; };
+__global__ __launch_bounds__(256) void tg_pack_weight_many_kernel(const TgPackJob *__restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                    // last job whose first block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TgPackJob j = jobs[lo];
+    const long long e = ((long long)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (e >= (long long)j.rows_to * j.cols_to) return;
+    {
+        const int n = (int)(e / j.cols_to), k = (int)(e % j.cols_to);
+        j.Wb[e] = (n < j.N && k < j.K) ? tg_bf16(j.W[(long long)n * j.K + k]) : (unsigned short)0;
+    }
+    {
+        const int k = (int)(e / j.rows_to), n = (int)(e % j.rows_to);
+        j.Wt[e] = (k < j.K && n < j.N) ? tg_bf16(j.W[(long long)n * j.K + k]) : (unsigned short)0;
     }
 }
 
@@ -942,32 +1031,56 @@ extern "C" int pdm_tg_stats_parts(long long rows, int N) { return rows <= 0 || N
 // x_bn_coef: null, or (4, K) fp32 [mean | invstd | gamma invstd | beta] (pdm_bn_finalize_stats): X holds the PRE-BatchNorm
 // outputs of the layer before and is read through bf16(relu((x - mean) scale + beta)) — that layer's BatchNorm + ReLU without a
 // pass (and a tensor) of its own.
-extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
-                              void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef) {
-    PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_gemm_nt: negative size");
+static int tg_gemm_nt_impl(const char *who, void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                           void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef, const void *Bx, long long ldbx,
+                           const float *bcoef, float *bstats) {
+    PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "%s: negative size", who);
     if (R == 0 || N == 0) return 0;
-    PDM_REQUIRE(X && W && Y, PDM_E_BADARG, "tg_gemm_nt: null pointer");
+    PDM_REQUIRE(X && W && Y, PDM_E_BADARG, "%s: null pointer", who);
     PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldw >= K && ldy >= N,
-                PDM_E_BADARG, "tg_gemm_nt: K=%d N=%d ldx=%lld ldw=%lld ldy=%lld must be multiples of 8 and cover the rows", K, N, ldx, ldw, ldy);
-    PDM_REQUIRE(tg_al16(X) && tg_al16(W) && tg_al16(Y), PDM_E_BADARG, "tg_gemm_nt: operands must be 16-byte aligned");
-    PDM_REQUIRE(!x_bn_coef || K <= TG_XFK, PDM_E_TOOLARGE, "tg_gemm_nt: x_bn_coef with K=%d (<= %d)", K, TG_XFK);
+                PDM_E_BADARG, "%s: K=%d N=%d ldx=%lld ldw=%lld ldy=%lld must be multiples of 8 and cover the rows", who, K, N, ldx, ldw, ldy);
+    PDM_REQUIRE(tg_al16(X) && tg_al16(W) && tg_al16(Y), PDM_E_BADARG, "%s: operands must be 16-byte aligned", who);
+    PDM_REQUIRE(!x_bn_coef || K <= TG_XFK, PDM_E_TOOLARGE, "%s: x_bn_coef with K=%d (<= %d)", who, K, TG_XFK);
+    const bool bs = bstats != nullptr;
+    if (bs) {
+        PDM_REQUIRE(Bx && bcoef && !stats && !x_bn_coef && !bias, PDM_E_BADARG, "%s: the gradient statistics take Bx and bcoef and exclude stats / x_bn_coef / bias", who);
+        PDM_REQUIRE(ldbx % 8 == 0 && ldbx >= N && tg_al16(Bx) && tg_al16(bcoef), PDM_E_BADARG, "%s: ldbx=%lld (a multiple of 8, >= N), 16-byte aligned Bx / bcoef", who, ldbx);
+    }
     const int bn = tg_bn_for(N);
     const int slots = tg_slots(R, N);
     const unsigned wgs = (unsigned)slots * (unsigned)((N + bn - 1) / bn);
     TgNtArgs a{};
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
     a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.xf = x_bn_coef; a.R = R; a.K = K; a.N = N;
+    a.Bx = static_cast<const unsigned short *>(Bx); a.ldbx = ldbx; a.bcf = bcoef; a.bstats = bstats;
 #define TG_NT(WN, JT)                                                                                                        \
     do {                                                                                                                     \
-        if (x_bn_coef) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);  \
+        if (bs) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 0, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);   \
+        else if (x_bn_coef) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);  \
         else hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 0>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);           \
     } while (0)
     if (bn == 32) TG_NT(1, 1);
     else if (bn == 64) TG_NT(1, 2);
+    else if (bs) hipLaunchKernelGGL((tg_nt_kernel<2, 2, 0, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);   // (the two-stages-ahead form has no registers left for the statistics)
     else if (x_bn_coef) hipLaunchKernelGGL((tg_nt_deep_kernel<1>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
     else hipLaunchKernelGGL((tg_nt_deep_kernel<0>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
 #undef TG_NT
-    return check_launch("tg_gemm_nt");
+    return check_launch(who);
+}
+
+extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                              void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef) {
+    return tg_gemm_nt_impl("tg_gemm_nt", stream, R, K, N, X, ldx, W, ldw, Y, ldy, bias, stats, x_bn_coef, nullptr, 0, nullptr, nullptr);
+}
+
+// The same product when Y IS the gradient of relu(bn(Bx)) (the data gradient of the layer behind a BatchNorm + ReLU): the epilogue
+// also leaves, per slot, the column sums of g = y [bn(Bx) > 0] and of g xhat over the ROUNDED outputs in bstats
+// (pdm_tg_stats_parts(R, N), N, 2) — what pdm_bn_relu_backward_stats' reduce pass forms from a second read of Y and Bx
+// (pdm_bn_finalize_bwd_stats folds the parts).  Bx (R, N) bf16 = that BatchNorm's input, bcoef (4, N) from pdm_bn_finalize_stats.
+extern "C" int pdm_tg_gemm_nt_bs(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                                 void *Y, long long ldy, const void *Bx, long long ldbx, const float *bcoef, float *bstats) {
+    PDM_REQUIRE(bstats, PDM_E_BADARG, "tg_gemm_nt_bs: null pointer");
+    return tg_gemm_nt_impl("tg_gemm_nt_bs", stream, R, K, N, X, ldx, W, ldw, Y, ldy, nullptr, nullptr, nullptr, Bx, ldbx, bcoef, bstats);
 }
 
 // Data gradient straight behind a BatchNorm + ReLU backward: dX (R, N) = dY (R, K) . W (N, K)^T where dY is not in memory yet:
@@ -976,36 +1089,70 @@ extern "C" int pdm_tg_gemm_nt(void *stream, long long R, int K, int N, const voi
 // is formed while the operand is staged and written to dYout (R, K) on the way (the weight gradient of the layer reads it from
 // there): the values of pdm_bn_relu_backward's dx bit for bit, without that operator's pass over dZ and Yp and without this
 // contraction's own read of dY.  Everything else as pdm_tg_gemm_nt (no bias, no statistics).
-extern "C" int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
-                                 const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
-                                 const float *grads) {
-    PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "tg_gemm_nt_dy: negative size");
-    if (R == 0 || N == 0 || K == 0) return 0;
-    PDM_REQUIRE(dZ && Yp && W && dX && dYout && coef && grads, PDM_E_BADARG, "tg_gemm_nt_dy: null pointer");
-    PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && lddz % 8 == 0 && ldyp % 8 == 0 && ldw % 8 == 0 && lddx % 8 == 0 && lddy % 8 == 0 &&
-                lddz >= K && ldyp >= K && ldw >= K && lddx >= N && lddy >= K, PDM_E_BADARG,
-                "tg_gemm_nt_dy: K=%d N=%d and the strides must be multiples of 8 and cover the rows", K, N);
-    PDM_REQUIRE(tg_al16(dZ) && tg_al16(Yp) && tg_al16(W) && tg_al16(dX) && tg_al16(dYout) && tg_al16(coef) && tg_al16(grads), PDM_E_BADARG,
-                "tg_gemm_nt_dy: operands must be 16-byte aligned");
-    PDM_REQUIRE(K <= TG_XFK, PDM_E_TOOLARGE, "tg_gemm_nt_dy: K=%d (<= %d)", K, TG_XFK);
-    // tiles: 128 x 128 as pdm_tg_gemm_nt for wide outputs; 128 x 64 for N <= 64 (the 256-row tiles of the plain kernel would
-    // hold 64 more registers of staged operands than a wave has left: two tensors travel per row here)
+static int tg_dy_slots(long long R, int N) {
     const int bn = N <= 64 ? 64 : 128, bm = 128;
     const long long row_tiles = (R + bm - 1) / bm;
     const int ncol = (N + bn - 1) / bn;
     long long sl = 1024 / ncol;
     if (sl < 64) sl = 64;
     if (sl > row_tiles) sl = row_tiles;
-    const int slots = (int)sl;
+    return (int)sl;
+}
+// parts of pdm_tg_gemm_nt_dy_bs' statistics: (parts, N, 2) fp32
+extern "C" int pdm_tg_dy_stats_parts(long long rows, int N) { return rows <= 0 || N <= 0 ? 0 : tg_dy_slots(rows, N); }
+
+static int tg_gemm_nt_dy_impl(const char *who, void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
+                              const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
+                              const float *grads, const void *Bx, long long ldbx, const float *bcoef, float *bstats) {
+    PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "%s: negative size", who);
+    if (R == 0 || N == 0 || K == 0) return 0;
+    PDM_REQUIRE(dZ && Yp && W && dX && dYout && coef && grads, PDM_E_BADARG, "%s: null pointer", who);
+    PDM_REQUIRE(K % 8 == 0 && N % 8 == 0 && lddz % 8 == 0 && ldyp % 8 == 0 && ldw % 8 == 0 && lddx % 8 == 0 && lddy % 8 == 0 &&
+                lddz >= K && ldyp >= K && ldw >= K && lddx >= N && lddy >= K, PDM_E_BADARG,
+                "%s: K=%d N=%d and the strides must be multiples of 8 and cover the rows", who, K, N);
+    PDM_REQUIRE(tg_al16(dZ) && tg_al16(Yp) && tg_al16(W) && tg_al16(dX) && tg_al16(dYout) && tg_al16(coef) && tg_al16(grads), PDM_E_BADARG,
+                "%s: operands must be 16-byte aligned", who);
+    PDM_REQUIRE(K <= TG_XFK, PDM_E_TOOLARGE, "%s: K=%d (<= %d)", who, K, TG_XFK);
+    const bool bs = bstats != nullptr;
+    if (bs) PDM_REQUIRE(Bx && bcoef && ldbx % 8 == 0 && ldbx >= N && tg_al16(Bx) && tg_al16(bcoef), PDM_E_BADARG,
+                        "%s: Bx / bcoef missing or misaligned (ldbx=%lld)", who, ldbx);
+    // tiles: 128 x 128 as pdm_tg_gemm_nt for wide outputs; 128 x 64 for N <= 64 (the 256-row tiles of the plain kernel would
+    // hold 64 more registers of staged operands than a wave has left: two tensors travel per row here)
+    const int bn = N <= 64 ? 64 : 128;
+    const int ncol = (N + bn - 1) / bn;
+    const int slots = tg_dy_slots(R, N);
     const unsigned wgs = (unsigned)slots * (unsigned)ncol;
     TgNtArgs a{};
     a.X = static_cast<const unsigned short *>(dZ); a.ldx = lddz; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
     a.Y = static_cast<unsigned short *>(dX); a.ldy = lddx; a.xf = coef; a.gf = grads;
     a.Xa = static_cast<const unsigned short *>(Yp); a.ldxa = ldyp; a.Xo = static_cast<unsigned short *>(dYout); a.ldxo = lddy;
+    a.Bx = static_cast<const unsigned short *>(Bx); a.ldbx = ldbx; a.bcf = bcoef; a.bstats = bstats;
     a.R = R; a.K = K; a.N = N;
-    if (bn == 64) hipLaunchKernelGGL((tg_nt_kernel<2, 1, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
-    else hipLaunchKernelGGL((tg_nt_kernel<2, 2, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
-    return check_launch("tg_gemm_nt_dy");
+    if (bn == 64) {
+        if (bs) hipLaunchKernelGGL((tg_nt_kernel<2, 1, 2, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+        else hipLaunchKernelGGL((tg_nt_kernel<2, 1, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    } else {
+        if (bs) hipLaunchKernelGGL((tg_nt_kernel<2, 2, 2, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+        else hipLaunchKernelGGL((tg_nt_kernel<2, 2, 2>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+    }
+    return check_launch(who);
+}
+
+extern "C" int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
+                                 const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
+                                 const float *grads) {
+    return tg_gemm_nt_dy_impl("tg_gemm_nt_dy", stream, R, K, N, dZ, lddz, Yp, ldyp, W, ldw, dX, lddx, dYout, lddy, coef, grads, nullptr, 0,
+                              nullptr, nullptr);
+}
+
+// pdm_tg_gemm_nt_dy whose product dX is itself the gradient of relu(bn(Bx)) (an inner layer of a stack): the gradient statistics
+// of THAT BatchNorm leave through the epilogue as in pdm_tg_gemm_nt_bs; bstats (pdm_tg_dy_stats_parts(R, N), N, 2).
+extern "C" int pdm_tg_gemm_nt_dy_bs(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
+                                    const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,
+                                    const float *grads, const void *Bx, long long ldbx, const float *bcoef, float *bstats) {
+    PDM_REQUIRE(bstats, PDM_E_BADARG, "tg_gemm_nt_dy_bs: null pointer");
+    return tg_gemm_nt_dy_impl("tg_gemm_nt_dy_bs", stream, R, K, N, dZ, lddz, Yp, ldyp, W, ldw, dX, lddx, dYout, lddy, coef, grads, Bx, ldbx,
+                              bcoef, bstats);
 }
 
 static long long tg_wgrad_slabs(long long R, int K, int N) {
@@ -1120,4 +1267,18 @@ extern "C" int pdm_tg_pack_weight_pair(void *stream, int N, int K, const float *
     hipLaunchKernelGGL(tg_pack_weight_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, as_stream(stream), W, N, K,
                        static_cast<unsigned short *>(Wb), cols_to, static_cast<unsigned short *>(Wt), rows_to, rows_to, cols_to);
     return check_launch("tg_pack_weight_pair");
+}
+
+// pdm_tg_pack_weight_pair for every layer of a model in ONE launch (a training step repacks ~40 parameters after each optimizer
+// step: 40 launches of ~4.5 us).  jobs: `njobs` records in DEVICE memory, 48 bytes each, in this order:
+//   { const float *W; void *Wb; void *Wt; int N, K, rows_to, cols_to; long long first_block; }
+// first_block[0] = 0, first_block[j + 1] = first_block[j] + ceil(rows_to[j] cols_to[j] / 256); total_blocks = the sum.
+extern "C" int pdm_tg_pack_weight_many(void *stream, int njobs, const void *jobs, long long total_blocks) {
+    static_assert(sizeof(TgPackJob) == 48, "TgPackJob is part of the C ABI");
+    PDM_REQUIRE(njobs >= 0 && total_blocks >= 0 && total_blocks <= 0x7fffffffll, PDM_E_BADARG, "tg_pack_weight_many: bad size");
+    if (njobs == 0 || total_blocks == 0) return 0;
+    PDM_REQUIRE(jobs, PDM_E_BADARG, "tg_pack_weight_many: null pointer");
+    hipLaunchKernelGGL(tg_pack_weight_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                       static_cast<const TgPackJob *>(jobs), njobs);
+    return check_launch("tg_pack_weight_many");
 }

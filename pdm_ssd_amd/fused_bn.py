@@ -215,14 +215,22 @@ def _round8(v):
 LAZY_BN_BACKWARD = os.environ.get("PDM_LAZY_BN_BACKWARD", "1") == "1"
 
 
-def _take_lazy_bn_backward(link, dyr, wt, want_dx):
+# 1 (default): the statistics of a BatchNorm + ReLU backward between two contractions of a stack (sum g, sum g xhat over the gradient
+# the next layer's data gradient produces) are taken in THAT contraction's epilogue (pdm_tg_gemm_nt_bs / pdm_tg_gemm_nt_dy_bs): the
+# reduce pass over (gradient, x) — a second read of both — disappears; only the finalize launch is left.
+BWD_STATS_IN_GEMM = os.environ.get("PDM_BWD_STATS_IN_GEMM", "1") == "1"
+
+
+def _take_lazy_bn_backward(link, dyr, wt, want_dx, bs=None):
     """The gradient rows `dyr` of a contraction's output may be UNFORMED: when the BatchNorm + ReLU behind it belongs to a
     _BnReluRowsGemm, that node hands back the gradient of relu(bn(y)) as it is and leaves (y, coef, grads) in the link it shares
     with the producer of y — this node.  Returns (dy rows formed, dx rows or None): with want_dx the data gradient forms dy on
-    the way (pdm_tg_gemm_nt_dy), otherwise the BatchNorm operator's apply half does."""
+    the way (pdm_tg_gemm_nt_dy), otherwise the BatchNorm operator's apply half does.
+    bs = (x rows, coef) of the BatchNorm + ReLU in FRONT of this layer (its output gradient is this node's dx): when the data
+    gradient is formed here, its epilogue takes that BatchNorm's gradient statistics; returned as a third value (or None)."""
     lazy = link.pop('lazy', None) if link is not None else None
     if lazy is None:
-        return dyr, None
+        return dyr, None, None
     from . import train_gemm as tg
     y_rows, coef, grads, ptr = lazy
     if dyr.data_ptr() != ptr or dyr.shape != y_rows.shape or dyr.dtype != torch.bfloat16:
@@ -233,12 +241,15 @@ def _take_lazy_bn_backward(link, dyr, wt, want_dx):
     # (N <= 256) and rows of >= 64 bytes; 16-channel rows (0.69x) and three or more column tiles (every tile re-reads and
     # re-forms the operand: 0.72-0.81x) take the apply half of the operator and the plain contraction
     if want_dx and 32 <= K <= 512 and wt.shape[0] <= 256:
+        if bs is not None:
+            dxr, dy_formed, partial = tg.gemm_nt_dy(dyr, y_rows, coef, grads, wt, bs=bs)
+            return dy_formed, dxr, partial
         dxr, dy_formed = tg.gemm_nt_dy(dyr, y_rows, coef, grads, wt)
-        return dy_formed, dxr
+        return dy_formed, dxr, None
     dy_formed = torch.empty_like(y_rows)
     _native.call("pdm_bn_relu_backward_apply", torch.cuda.current_stream(dyr.device).cuda_stream, 1, 0, R, K, 1, y_rows.data_ptr(),
                  dyr.data_ptr(), dy_formed.data_ptr(), coef.data_ptr(), grads.data_ptr(), 1)
-    return dy_formed, None
+    return dy_formed, None, None
 
 
 class _RowsGemm(Function):
@@ -296,7 +307,7 @@ class _RowsGemm(Function):
             dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
             dyr[:, :nc].copy_(src)
         dx = None
-        dyr, dxr = _take_lazy_bn_backward(ctx.link, dyr, wt, ctx.needs_input_grad[0])
+        dyr, dxr, _ = _take_lazy_bn_backward(ctx.link, dyr, wt, ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0]:
             if dxr is None:
                 dxr = tg.gemm_nt(dyr, wt)                    # (R, K) bf16: the pad channels come out zero
@@ -365,29 +376,34 @@ class _BnReluRowsGemm(Function):
             src = dy.movedim(1, -1).reshape(R, nc) if xdim > 2 else dy
             dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
             dyr[:, :nc].copy_(src)
-        dyr, da = _take_lazy_bn_backward(ctx.link, dyr, wt, True)   # this layer's own output gradient may arrive unformed (see there)
-        if da is None:
-            da = tg.gemm_nt(dyr, wt)                         # gradient of relu(bn(x)), (R, K) bf16
+        # the gradient statistics of the BatchNorm in front (over da and x) come out of the contraction that forms da
+        bs = (xr, coef) if BWD_STATS_IN_GEMM and xr.stride(0) % 8 == 0 else None
+        dyr, da, partial = _take_lazy_bn_backward(ctx.link, dyr, wt, True, bs)   # this layer's own output gradient may arrive unformed (see there)
+        if da is None:                                       # gradient of relu(bn(x)), (R, K) bf16
+            da, partial = tg.gemm_nt_bs(dyr, wt, xr, coef) if bs is not None else (tg.gemm_nt(dyr, wt), None)
         dw = tg.wgrad(dyr, xr, x_bn_coef=coef)[:N, :Kw].reshape(weight.shape)   # the layer's input recomputed while it is read
         db = None
         if has_bias:
             db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
-        grads = torch.empty((4, K), dtype=torch.float32, device=dy.device)
-        parts = _native.lib().pdm_bn_parts(0, R, K, 1)
-        partial = torch.empty((parts, K, 2), dtype=torch.float32, device=dy.device)
         stream = torch.cuda.current_stream(dy.device).cuda_stream
+        if partial is not None:
+            grads = tg.bn_bwd_finalize(R, coef, partial)
+        else:
+            grads = torch.empty((4, K), dtype=torch.float32, device=dy.device)
+            parts = _native.lib().pdm_bn_parts(0, R, K, 1)
+            scratch = torch.empty((parts, K, 2), dtype=torch.float32, device=dy.device)
+            _native.call("pdm_bn_relu_backward_stats", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(), coef.data_ptr(),
+                         grads.data_ptr(), scratch.data_ptr(), 1)
         if LAZY_BN_BACKWARD and ctx.in_link is not None:
             # The BatchNorm + ReLU backward's elementwise half is left to the producer of x: its data gradient forms
             # dx = scale (da [bn(x) > 0] - p - (x - mean) q) while it reads da and x (pdm_tg_gemm_nt_dy) and writes it out for its
             # weight gradient.  What travels back through autograd is `da` itself; the link says how to read it.
-            _native.call("pdm_bn_relu_backward_stats", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(), coef.data_ptr(),
-                         grads.data_ptr(), partial.data_ptr(), 1)
             ctx.in_link['lazy'] = (xr, coef, grads, da.data_ptr())
             dx = da
         else:
             dx = torch.empty_like(xr)
-            _native.call("pdm_bn_relu_backward", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(),
-                         dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), 1)
+            _native.call("pdm_bn_relu_backward_apply", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(), dx.data_ptr(), coef.data_ptr(),
+                         grads.data_ptr(), 1)
         return (_rows_to_layout(dx, None, K, xshape, xdim), None, grads[0], grads[1], None, None, None, None, dw, db, None, None,
                 None, None)
 

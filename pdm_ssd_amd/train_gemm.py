@@ -2,6 +2,8 @@
 
 Rows layout throughout: a channels-last activation tensor IS a (rows, channels) matrix.  No fallback: the calls raise
 when the HIP library is missing or an argument does not fit (callers test `usable()` first and otherwise keep torch)."""
+import os
+
 import torch
 
 from . import _native
@@ -56,16 +58,106 @@ def pack_weight_into(w, out, transposed=False):
     return out
 
 
-def pack_weight_pair(w, rows_to, cols_to):
-    """fp32 (N, K) parameter -> (wb (rows_to, cols_to), wt (cols_to, rows_to)) bf16: the weight for the forward product and
-    its transpose for the data gradient, zero padded (rows_to >= N, cols_to >= K, both multiples of 8), in ONE launch."""
-    assert w.dim() == 2 and w.is_cuda and w.dtype == torch.float32
-    w = w.detach().contiguous()
+def _pack_weight_pair_now(w, rows_to, cols_to, buf=None):
     N, K = w.shape
-    buf = torch.empty((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)     # the kernel writes the padding too
+    if buf is None:
+        buf = torch.empty((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)     # the kernel writes the padding too
     wb, wt = buf[0].view(rows_to, cols_to), buf[1].view(cols_to, rows_to)
     _native.call("pdm_tg_pack_weight_pair", _stream(w), N, K, w.data_ptr(), wb.data_ptr(), wt.data_ptr(), rows_to, cols_to)
     return wb, wt
+
+
+# The packed pairs of a model's parameters are kept between calls and refreshed TOGETHER: a parameter changes once per optimizer
+# step, and a training step of the detector packed ~40 of them in 40 launches.  An entry remembers the parameter (weakly), its
+# storage address and its version counter (torch bumps it on every in-place update: optimizer steps, load_state_dict, copy_);
+# the first request that finds a stale entry repacks EVERY live entry in one launch (pdm_tg_pack_weight_many over a job table in
+# device memory, rebuilt only when the set of entries changes).  The buffers are persistent: a pair handed out (and saved for a
+# backward) is overwritten by the next refresh, i.e. after the parameter itself has been overwritten.  PDM_PACK_CACHE=0: one launch
+# per request, fresh buffers.  Not used while a stream is being captured into a graph.
+PACK_CACHE = os.environ.get("PDM_PACK_CACHE", "1") == "1"
+_packs = {}                       # (device index, address, N, K, rows_to, cols_to) -> [weakref(parameter), buffer (2, rows_to * cols_to), version]
+_pack_tables = {}                 # device index -> (job table tensor, njobs, total blocks, tuple of keys)
+
+
+def _refresh_packs(dev_index, device):
+    import weakref  # noqa: F401
+    import numpy as np
+    live = []
+    for key in [k for k in _packs if k[0] == dev_index]:
+        ref, buf, _ = _packs[key]
+        base = ref()
+        if base is None or base.data_ptr() != key[1]:
+            del _packs[key]                           # the parameter is gone (or moved): its pair with it
+        else:
+            live.append((key, base, buf))
+    keys = tuple((k, buf.data_ptr()) for k, _, buf in live)       # the table holds addresses: parameters AND buffers
+    table = _pack_tables.get(dev_index)
+    if table is None or table[3] != keys:
+        rec = np.zeros(len(live), dtype=np.dtype([('W', '<u8'), ('Wb', '<u8'), ('Wt', '<u8'), ('N', '<i4'), ('K', '<i4'), ('rows_to', '<i4'),
+                                                   ('cols_to', '<i4'), ('first_block', '<i8')]))
+        first = 0
+        for j, (key, base, buf) in enumerate(live):
+            _, ptr, N, K, rows_to, cols_to = key
+            rec[j] = (ptr, buf[0].data_ptr(), buf[1].data_ptr(), N, K, rows_to, cols_to, first)
+            first += (rows_to * cols_to + 255) // 256
+        host = torch.from_numpy(rec.view(np.uint8).copy())
+        table = (host.to(device), len(live), first, keys)
+        _pack_tables[dev_index] = table
+    if table[1]:
+        _native.call("pdm_tg_pack_weight_many", torch.cuda.current_stream(device).cuda_stream, table[1], table[0].data_ptr(), table[2])
+    for key, base, _ in live:
+        _packs[key][2] = base._version
+
+
+def pack_weight_pair(w, rows_to, cols_to):
+    """fp32 (N, K) parameter -> (wb (rows_to, cols_to), wt (cols_to, rows_to)) bf16: the weight for the forward product and
+    its transpose for the data gradient, zero padded (rows_to >= N, cols_to >= K, both multiples of 8), in ONE launch — and, for
+    a parameter seen before, no launch at all until the parameter changes (see PACK_CACHE above)."""
+    assert w.dim() == 2 and w.is_cuda and w.dtype == torch.float32
+    base = w._base if w._base is not None else w
+    if not (PACK_CACHE and w.is_contiguous() and base.data_ptr() == w.data_ptr() and not torch.cuda.is_current_stream_capturing()):
+        return _pack_weight_pair_now(w.detach().contiguous(), rows_to, cols_to)
+    import weakref
+    N, K = w.shape
+    key = (w.device.index, w.data_ptr(), N, K, rows_to, cols_to)
+    ent = _packs.get(key)
+    if ent is not None and ent[0]() is base:
+        if ent[2] != base._version:
+            _refresh_packs(w.device.index, w.device)
+        buf = ent[1]
+        return buf[0].view(rows_to, cols_to), buf[1].view(cols_to, rows_to)
+    if len(_packs) > 4096:                             # models come and go (tests): drop the pairs of dead parameters
+        for k in [k for k, e in _packs.items() if e[0]() is None]:
+            del _packs[k]
+    buf = torch.empty((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)
+    _packs[key] = [weakref.ref(base), buf, base._version]
+    return _pack_weight_pair_now(w.detach(), rows_to, cols_to, buf)
+
+
+def gemm_nt_bs(x, w, bx, bcoef):
+    """gemm_nt whose product y (R, N) IS the gradient of relu(bn(bx)) (the data gradient of the layer behind that BatchNorm + ReLU):
+    also returns the per-slot sums (parts, N, 2) of g = y [bn(bx) > 0] and g xhat taken in the epilogue — what
+    pdm_bn_relu_backward_stats' reduce pass would read y and bx again for (finalize: bn_bwd_finalize).  bx (R, N) bf16 rows, bcoef
+    (4, N) fp32 from pdm_bn_finalize_stats."""
+    R, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and bx.dtype == torch.bfloat16 and x.stride(1) == 1 and w.stride(1) == 1
+    assert bx.shape == (R, N) and bx.stride(1) == 1 and bcoef.shape == (4, N) and bcoef.dtype == torch.float32 and bcoef.is_contiguous()
+    y = torch.empty((R, N), dtype=torch.bfloat16, device=x.device)
+    st = torch.empty((_native.lib().pdm_tg_stats_parts(R, N), N, 2), dtype=torch.float32, device=x.device)
+    _native.call("pdm_tg_gemm_nt_bs", _stream(x), R, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
+                 bx.data_ptr(), bx.stride(0), bcoef.data_ptr(), st.data_ptr())
+    return y, st
+
+
+def bn_bwd_finalize(rows, coef, partial):
+    """grads (4, C) fp32 = [dgamma | dbeta | p | q] of a BatchNorm + ReLU backward from the (parts, C, 2) sums a producing
+    contraction took (gemm_nt_bs / gemm_nt_dy(..., bs=...))."""
+    C = coef.shape[1]
+    assert partial.shape[1:] == (C, 2) and partial.dtype == torch.float32 and partial.is_contiguous()
+    grads = torch.empty((4, C), dtype=torch.float32, device=coef.device)
+    _native.call("pdm_bn_finalize_bwd_stats", _stream(coef), rows, C, coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), partial.shape[0])
+    return grads
 
 
 def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None):
@@ -86,7 +178,7 @@ def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None):
     return (y, st) if stats else y
 
 
-def gemm_nt_dy(dz, yp, coef, grads, w):
+def gemm_nt_dy(dz, yp, coef, grads, w, bs=None):
     """Data gradient straight behind a BatchNorm + ReLU backward: dz (R, K) bf16 = the gradient of relu(bn(yp)), yp (R, K) bf16 the
     BatchNorm's input, coef / grads (4, K) fp32 from pdm_bn_finalize_stats / pdm_bn_relu_backward_stats, w (N, K) bf16 ->
     (dx (R, N) bf16 = dy . w^T, dy (R, K) bf16) with dy = the BatchNorm + ReLU backward of dz, formed while dz and yp are read
@@ -97,6 +189,16 @@ def gemm_nt_dy(dz, yp, coef, grads, w):
     assert dz.stride(1) == 1 and yp.stride(1) == 1 and w.stride(1) == 1 and coef.shape == (4, K) and grads.shape == (4, K)
     dx = torch.empty((R, N), dtype=torch.bfloat16, device=dz.device)
     dy = torch.empty((R, K), dtype=torch.bfloat16, device=dz.device)
+    if bs is not None:
+        # bs = (bx (R, N) bf16, bcoef (4, N)): dx is itself the gradient of relu(bn(bx)); its statistics leave through the epilogue
+        # (see gemm_nt_bs); returns (dx, dy, partial (parts, N, 2))
+        bx, bcoef = bs
+        assert bx.shape == (R, N) and bx.dtype == torch.bfloat16 and bx.stride(1) == 1 and bcoef.shape == (4, N) and bcoef.is_contiguous()
+        st = torch.empty((_native.lib().pdm_tg_dy_stats_parts(R, N), N, 2), dtype=torch.float32, device=dz.device)
+        _native.call("pdm_tg_gemm_nt_dy_bs", _stream(dz), R, K, N, dz.data_ptr(), dz.stride(0), yp.data_ptr(), yp.stride(0), w.data_ptr(),
+                     w.stride(0), dx.data_ptr(), dx.stride(0), dy.data_ptr(), dy.stride(0), coef.data_ptr(), grads.data_ptr(),
+                     bx.data_ptr(), bx.stride(0), bcoef.data_ptr(), st.data_ptr())
+        return dx, dy, st
     _native.call("pdm_tg_gemm_nt_dy", _stream(dz), R, K, N, dz.data_ptr(), dz.stride(0), yp.data_ptr(), yp.stride(0), w.data_ptr(),
                  w.stride(0), dx.data_ptr(), dx.stride(0), dy.data_ptr(), dy.stride(0), coef.data_ptr(), grads.data_ptr())
     return dx, dy

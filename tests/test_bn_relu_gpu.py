@@ -199,9 +199,11 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
             m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
     x0 = torch.randn(3, 16, 40, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
     res = []
-    default = fused_bn.BN_IN_GEMM
-    for flag in (True, False):
-        fused_bn.BN_IN_GEMM = flag
+    default, default_bs = fused_bn.BN_IN_GEMM, fused_bn.BWD_STATS_IN_GEMM
+    # (in-GEMM BatchNorm, gradient statistics in the data gradient's epilogue): the bit-identity is stated with the statistics
+    # taken by the reduce operator on both sides; the epilogue form sums the same terms in another order (third run)
+    for flag, bs in ((True, False), (False, False), (True, True)):
+        fused_bn.BN_IN_GEMM, fused_bn.BWD_STATS_IN_GEMM = flag, bs
         try:
             m = copy.deepcopy(net)
             x = x0.clone().requires_grad_(True)
@@ -212,13 +214,21 @@ def test_bn_relu_inside_the_next_contraction_is_bit_identical(dev):
             res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
                         {k: b.clone() for k, b in m.named_buffers()}))
         finally:
-            fused_bn.BN_IN_GEMM = default
-    (ya, ga, pa, ba), (yb, gb, pb, bb) = res
+            fused_bn.BN_IN_GEMM, fused_bn.BWD_STATS_IN_GEMM = default, default_bs
+    (ya, ga, pa, ba), (yb, gb, pb, bb), (yc, gc, pc, bc) = res
     assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb) and torch.equal(ga, gb)
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
     for k in ba:
         assert torch.equal(ba[k], bb[k]), k
+    # statistics from the epilogue: the forward is untouched; gradients agree to the order of the fp32 partial sums (a changed last
+    # bit of p / q may move a bf16 rounding of the input gradient)
+    assert default_bs and torch.equal(ya, yc)
+    for k in ba:
+        assert torch.equal(ba[k], bc[k]), k
+    assert float((ga.float() - gc.float()).abs().max()) <= 2.0 ** -7 * float(ga.float().abs().max())
+    for k in pa:
+        assert float((pa[k] - pc[k]).abs().max()) <= 1e-3 * float(pa[k].abs().max()) + 1e-6, k
 
 
 @pytest.mark.parametrize("widths,x_grad,end_bn", [((16, 32, 20, 8), True, False), ((16, 32, 20, 8), False, False),
@@ -247,10 +257,13 @@ def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths,
             m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
     x0 = torch.randn(3, c0, 50, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
     res = []
-    default = fused_bn.LAZY_BN_BACKWARD
-    assert default and fused_bn.BN_IN_GEMM, "the fused forms are the default path"
-    for flag in (True, False):
-        fused_bn.LAZY_BN_BACKWARD = flag
+    default, default_bs = fused_bn.LAZY_BN_BACKWARD, fused_bn.BWD_STATS_IN_GEMM
+    assert default and default_bs and fused_bn.BN_IN_GEMM, "the fused forms are the default path"
+    # the bit-identity is stated with the gradient statistics taken by the reduce operator on both sides; with the statistics
+    # taken in the data gradients' epilogues (the default, third run) the two forms tile their products differently and sum the
+    # same terms in another order
+    for flag, bs in ((True, False), (False, False), (True, True)):
+        fused_bn.LAZY_BN_BACKWARD, fused_bn.BWD_STATS_IN_GEMM = flag, bs
         try:
             m = copy.deepcopy(net)
             x = x0.clone().requires_grad_(x_grad)
@@ -260,11 +273,16 @@ def test_bn_relu_backward_inside_the_data_gradient_is_bit_identical(dev, widths,
             loss.backward()
             res.append((y.detach().clone(), x.grad.clone() if x_grad else None, {k: p.grad.clone() for k, p in m.named_parameters()}))
         finally:
-            fused_bn.LAZY_BN_BACKWARD = default
-    (ya, ga, pa), (yb, gb, pb) = res
+            fused_bn.LAZY_BN_BACKWARD, fused_bn.BWD_STATS_IN_GEMM = default, default_bs
+    (ya, ga, pa), (yb, gb, pb), (yc, gc, pc) = res
     assert torch.equal(ya, yb) and (not x_grad or torch.equal(ga, gb))
     for k in pa:
         assert torch.isfinite(pa[k]).all() and torch.equal(pa[k], pb[k]), k
+    assert torch.equal(ya, yc)
+    if x_grad:
+        assert float((ga.float() - gc.float()).abs().max()) <= 2.0 ** -6 * float(ga.float().abs().max())
+    for k in pa:
+        assert torch.isfinite(pc[k]).all() and float((pa[k] - pc[k]).abs().max()) <= 2e-3 * float(pa[k].abs().max()) + 1e-6, k
 
 
 @pytest.mark.gpu

@@ -102,3 +102,114 @@ def test_colsum_exact_on_integer_data(dev, R, N, ld):
     ys[:, N:] = 5.0
     got = tg.colsum(ys[:, :N])
     assert torch.equal(got, ys[:, :N].double().sum(0).float())      # |sums| < 2^24: exact in fp32
+
+
+def _bn_coef(N, dev, seed):
+    """(4, N) [mean | invstd | scale | shift] with integer means and power-of-two invstd (g xhat sums then stay exact on integer data)"""
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.randint(-2, 3, (N,), generator=g).float()
+    invstd = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (N,), generator=g)]
+    gamma = torch.randint(-2, 3, (N,), generator=g).float()          # zero and negative gammas: the mask follows scale's sign
+    shift = torch.randint(-3, 4, (N,), generator=g).float() * 0.5
+    return torch.stack([mean, invstd, gamma * invstd, shift]).contiguous().to(dev)
+
+
+def _bwd_stats_reference(bx, y, coef):
+    """the operator these epilogues replace: pdm_bn_relu_backward_stats over (x, dy)"""
+    from pdm_ssd_amd import _native
+    R, N = y.shape
+    grads = torch.empty((4, N), dtype=torch.float32, device=y.device)
+    part = torch.empty((_native.lib().pdm_bn_parts(0, R, N, 1), N, 2), dtype=torch.float32, device=y.device)
+    _native.call("pdm_bn_relu_backward_stats", torch.cuda.current_stream().cuda_stream, 1, 0, R, N, 1, bx.data_ptr(), y.data_ptr(),
+                 coef.data_ptr(), grads.data_ptr(), part.data_ptr(), 1)
+    return grads
+
+
+@pytest.mark.parametrize("R,K,N", [(1000, 64, 32), (129, 8, 8), (300, 72, 200), (20000, 128, 128), (9000, 104, 64), (513, 32, 48),
+                                   (70000, 16, 24), (4096, 512, 264), (77, 200, 136)])   # all three tile shapes, ragged edges
+def test_gemm_nt_with_bn_backward_statistics_in_the_epilogue(dev, R, K, N):
+    """pdm_tg_gemm_nt_bs: the product is unchanged and the sums its epilogue leaves (sum g, sum g xhat with g = y [bn(bx) > 0])
+    give the grads (dgamma, dbeta, p, q) of pdm_bn_relu_backward_stats over the same tensors — BIT for bit on integer data (every
+    fp32 sum exact), to summation order on random data."""
+    x = ints((R, K), -3, 3, 21, dev).bfloat16()
+    w32 = ints((N, K), -2, 2, 22, dev)
+    w = tg.pack_weight(w32)
+    bx = ints((R, N), -4, 4, 23, dev).bfloat16()
+    coef = _bn_coef(N, dev, 24)
+    y, part = tg.gemm_nt_bs(x, w, bx, coef)
+    assert torch.equal(y, tg.gemm_nt(x, w)) and part.shape == (part.shape[0], N, 2)
+    got, want = tg.bn_bwd_finalize(R, coef, part), _bwd_stats_reference(bx, y, coef)
+    assert torch.equal(got, want)
+    # random data: same values up to the order of the fp32 partial sums
+    x = torch.randn(R, K, device=dev).bfloat16()
+    w = tg.pack_weight(torch.randn(N, K, device=dev) * 0.2)
+    bx = (torch.randn(R, N, device=dev) * 1.5 + 0.3).bfloat16()
+    coef = torch.stack([torch.randn(N) * 0.3, torch.rand(N) + 0.5, torch.randn(N), torch.randn(N) * 0.3]).contiguous().to(dev)
+    y, part = tg.gemm_nt_bs(x, w, bx, coef)
+    got, want = tg.bn_bwd_finalize(R, coef, part), _bwd_stats_reference(bx, y, coef)
+    scale = want.abs().amax(1, keepdim=True).clamp_min(1e-6)
+    assert float(((got - want).abs() / scale).max()) < 2e-5
+
+
+@pytest.mark.parametrize("R,K,N", [(1000, 64, 32), (5000, 128, 64), (300, 72, 200), (20000, 256, 128), (513, 32, 48), (4097, 40, 256)])
+def test_gemm_nt_dy_with_bn_backward_statistics_in_the_epilogue(dev, R, K, N):
+    """pdm_tg_gemm_nt_dy_bs (the data gradient that forms its operand from an unformed BatchNorm gradient AND whose product is the
+    next BatchNorm's gradient): dX and dYout bit-equal to pdm_tg_gemm_nt_dy, grads equal to the reduce operator's as above."""
+    dz = ints((R, K), -3, 3, 31, dev).bfloat16()
+    yp = ints((R, K), -4, 4, 32, dev).bfloat16()
+    icoef = _bn_coef(K, dev, 33)
+    igrads = torch.zeros((4, K), device=dev)
+    igrads[2] = ints((K,), -1, 1, 34, dev) * 0.5; igrads[3] = ints((K,), -1, 1, 35, dev) * 0.25
+    w = tg.pack_weight(ints((N, K), -2, 2, 36, dev))
+    bx = ints((R, N), -4, 4, 37, dev).bfloat16()
+    coef = _bn_coef(N, dev, 38)
+    dx0, dy0 = tg.gemm_nt_dy(dz, yp, icoef, igrads, w)
+    dx, dy, part = tg.gemm_nt_dy(dz, yp, icoef, igrads, w, bs=(bx, coef))
+    assert torch.equal(dx, dx0) and torch.equal(dy, dy0)
+    got, want = tg.bn_bwd_finalize(R, coef, part), _bwd_stats_reference(bx, dx, coef)
+    scale = want.abs().amax(1, keepdim=True).clamp_min(1e-6)
+    assert float(((got - want).abs() / scale).max()) < 2e-5
+
+
+def test_packed_weight_pairs_are_cached_and_refreshed_together(dev):
+    """tg.pack_weight_pair keeps the bf16 pair of a parameter until the parameter changes (version counter) and then repacks every
+    cached pair in ONE launch (pdm_tg_pack_weight_many): the pairs always equal a fresh pack of the current values; views of a
+    parameter (reshape) share its entry; a dead parameter's entry is dropped and its address can be reused."""
+    torch.manual_seed(3)
+    shapes = [(32, 16), (20, 24), (200, 136), (8, 8), (512, 1536)]
+    params = [torch.nn.Parameter(torch.randn(n, k, device=dev)) for n, k in shapes]
+    conv = torch.nn.Parameter(torch.randn(64, 40, 1, 1, device=dev))
+
+    def pairs():
+        out = [tg.pack_weight_pair(p, (p.shape[0] + 7) // 8 * 8, (p.shape[1] + 7) // 8 * 8) for p in params]
+        out.append(tg.pack_weight_pair(conv.reshape(64, -1), 64, 40))
+        return out
+
+    def fresh():
+        out = [tg._pack_weight_pair_now(p.detach(), (p.shape[0] + 7) // 8 * 8, (p.shape[1] + 7) // 8 * 8) for p in params]
+        out.append(tg._pack_weight_pair_now(conv.detach().reshape(64, -1), 64, 40))
+        return out
+
+    assert tg.PACK_CACHE
+    first = pairs()
+    for (a, b), (c, d) in zip(first, fresh()):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    again = pairs()
+    assert all(a.data_ptr() == c.data_ptr() for (a, _), (c, _) in zip(first, again))      # no new buffers, no launches
+    with torch.no_grad():
+        for p in params:
+            p.mul_(1.5).add_(0.25)                     # an optimizer step: every version counter moves
+        conv.add_(1.0)
+    for (a, b), (c, d) in zip(pairs(), fresh()):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    # one parameter changes alone; then one dies and another is born (possibly at its address)
+    with torch.no_grad():
+        params[2].zero_()
+    for (a, b), (c, d) in zip(pairs(), fresh()):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    del first, again
+    params[0] = torch.nn.Parameter(torch.randn(32, 16, device=dev))
+    with torch.no_grad():
+        params[1].neg_()
+    for (a, b), (c, d) in zip(pairs(), fresh()):
+        assert torch.equal(a, c) and torch.equal(b, d)
