@@ -489,14 +489,53 @@ def train_bench(args, model, points, B, N, rank, world, local_rank, device, step
     if args.train_profile:
         from torch.profiler import ProfilerActivity, profile
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        if os.environ.get("PDM_TRAIN_PROFILE_OPS") == "2":
+            # every aten operator of ONE step (forward and backward on this thread) with the repo line that issued it:
+            # which torch kernels are left in the step, and where they come from
+            import collections, traceback
+            from torch.utils._python_dispatch import TorchDispatchMode
+            seen = collections.Counter()
+
+            class Log(TorchDispatchMode):
+                def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                    out = func(*args, **(kwargs or {}))
+                    name = func.__name__ if hasattr(func, "__name__") else str(func)
+                    t = next((a for a in args if isinstance(a, torch.Tensor)), None)
+                    if t is not None and not t.is_cuda:
+                        return out
+                    frames = [fr for fr in traceback.extract_stack() if "/pdm_ssd_amd/" in fr.filename or fr.filename.endswith("bench.py")]
+                    site = " <- ".join(f"{os.path.basename(fr.filename)}:{fr.lineno}" for fr in frames[::-1][:2]) if frames else "(autograd)"
+                    shape = tuple(t.shape) if t is not None else ()
+                    seen[(str(func), shape, str(t.dtype) if t is not None else "", site)] += 1
+                    return out
+
+            torch.autograd.set_multithreading_enabled(False)
+            with Log():
+                step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                with open(args.train_profile, "w") as f:
+                    skip = ("aten.view", "aten.detach", "aten.as_strided", "aten.t.", "aten.transpose", "aten.permute", "aten.reshape", "aten._unsafe_view",
+                            "aten.expand", "aten.slice.", "aten.select.", "aten.unsqueeze", "aten.squeeze", "aten.alias", "aten.empty", "aten.movedim",
+                            "aten.unbind", "aten.split", "aten.narrow", "aten.is_", "aten.sym_", "aten.stride", "aten.size", "aten.numel", "aten.dim")
+                    for (name, shape, dt, site), cnt in sorted(seen.items(), key=lambda kv: (-int(torch.Size(kv[0][1]).numel()), kv[0][0])):
+                        if not any(name.startswith(p_) for p_ in skip):
+                            f.write(f"{cnt:3d} x {name:42s} {str(shape):28s} {dt:16s} {site}\n")
+            return
+        by_op = os.environ.get("PDM_TRAIN_PROFILE_OPS") == "1"     # torch operators with their call sites instead of kernels
+        acts = [ProfilerActivity.CPU, ProfilerActivity.CUDA] if by_op else [ProfilerActivity.CUDA]
+        with profile(activities=acts, with_stack=by_op, record_shapes=by_op) as prof:
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
         if rank == 0:
             with open(args.train_profile, "w") as f:
                 f.write("# 3 steady-state train steps (divide totals by 3 for one step)\n")
-                f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=110))
+                if by_op:
+                    f.write(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=60,
+                                                                        max_src_column_width=110))
+                else:
+                    f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=110))
         return
     if args.train_host_profile:     # where the HOST spends a step (the step is within ~1 ms of host-issue-bound)
         import cProfile, pstats

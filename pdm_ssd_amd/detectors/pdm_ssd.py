@@ -18,8 +18,10 @@ class PDMSSD(Detector3DTemplate):
         head = getattr(self, 'point_head', None)
         if head is not None and hasattr(head, 'wants_deferred_fp') and head.wants_deferred_fp():
             batch_dict['defer_last_fp'] = True
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
+        from .. import fused_bn
+        with fused_bn.counter_scope():      # the BatchNorm step counters of every stack: one multi-tensor add
+            for cur_module in self.module_list:
+                batch_dict = cur_module(batch_dict)
         owed = batch_dict.pop('point_features_deferred', None)
         if owed is not None:            # (no module took it)
             owed.materialize()

@@ -182,6 +182,22 @@ def _bump(bn):
         bn.num_batches_tracked += 1
 
 
+class counter_scope:
+    """`with fused_bn.counter_scope():` around a model's forward: every BatchNorm counter inside (all stacks, the pooled operators)
+    is bumped by ONE multi-tensor add when the scope closes instead of one per stack (the detector: 24 launches -> 1)."""
+
+    def __enter__(self):
+        _bump_later.append([])
+        return self
+
+    def __exit__(self, *exc):
+        counters = _bump_later.pop()
+        if counters:
+            with torch.no_grad():
+                torch._foreach_add_(counters, 1)
+        return False
+
+
 def batch_norm_relu(x, bn, relu=True, stats=None, out_bf16=False, link=None):
     """bn(x) followed by ReLU (relu=True), through the fused kernels when `applies`, else through torch.
     stats: the column sums the producing GEMM took of x ([tiles][C][2], rows_linear(..., want_stats=True)) or None."""
@@ -406,6 +422,107 @@ class _BnReluRowsGemm(Function):
                          grads.data_ptr(), 1)
         return (_rows_to_layout(dx, None, K, xshape, xdim), None, grads[0], grads[1], None, None, None, None, dw, db, None, None,
                 None, None)
+
+
+_identity_coef = {}
+
+
+def _relu_coef(K, device):
+    """(coef, grads) that make the BatchNorm + ReLU forms of the contractions a plain ReLU: mean 0, invstd 1, scale 1, shift 0 and
+    p = q = 0 — relu((x - 0) 1 + 0) = relu(x) and 1 (g [x > 0] - 0 - x 0) = g [x > 0], exactly."""
+    key = (K, device)
+    if key not in _identity_coef:
+        coef = torch.zeros((4, K), dtype=torch.float32, device=device)
+        coef[1].fill_(1.0); coef[2].fill_(1.0)
+        _identity_coef[key] = (coef, torch.zeros((4, K), dtype=torch.float32, device=device))
+    return _identity_coef[key]
+
+
+class _ReluRowsGemm(Function):
+    """layer(relu(x)) for x = the raw bf16 rows a _RowsGemm just produced (Conv -> ReLU -> Conv without a BatchNorm: the heat-map
+    head's output stack): the ReLU rides in the second contraction's load path and its backward in the first one's data gradient,
+    through the BatchNorm + ReLU forms of the kernels with identity coefficients (_relu_coef) — relu(x) is never written, its
+    gradient mask never applied in a pass of its own (72 M elements at bs = 32: ~0.13 ms of a step as torch kernels)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, want_stats, keep_pad, in_link=None, out_link=None):
+        from . import train_gemm as tg
+        ctx.in_link, ctx.link = in_link, out_link
+        ctx.set_materialize_grads(False)
+        xr = tg.row_view(x)
+        R, K = xr.shape
+        N = weight.shape[0]
+        w2 = weight.reshape(N, -1)
+        Kw, Np = w2.shape[1], _round8(N)
+        assert xr.dtype == torch.bfloat16 and Kw <= K < Kw + 8 and K % 8 == 0
+        coef, _ = _relu_coef(K, x.device)
+        wb, wt = tg.pack_weight_pair(w2, Np, K)
+        if bias is not None and Np != N:
+            bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
+        if want_stats:
+            y, st = tg.gemm_nt(xr, wb, bias=bias, stats=True, x_bn_coef=coef)
+        else:
+            y, st = tg.gemm_nt(xr, wb, bias=bias, x_bn_coef=coef), None
+        ctx.save_for_backward(xr, weight, wt)
+        ctx.geom = (tuple(x.shape), x.dim(), N, Np, K, Kw, bias is not None)
+        out = _rows_to_layout(y, x, Np if keep_pad else N)
+        if st is not None:
+            ctx.mark_non_differentiable(st)
+        return out, st
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy, _dstats=None):
+        from . import train_gemm as tg
+        if dy is None:
+            return (None,) * 7
+        xr, weight, wt = ctx.saved_tensors
+        xshape, xdim, N, Np, K, Kw, has_bias = ctx.geom
+        R = xr.shape[0]
+        coef, grads = _relu_coef(K, xr.device)
+        dyr = tg.row_view(dy)
+        if dyr is None or dyr.dtype != torch.bfloat16 or dyr.shape[1] != Np or dyr.stride(0) % 8:
+            nc = dy.shape[1]
+            src = dy.movedim(1, -1).reshape(R, nc) if xdim > 2 else dy
+            dyr = torch.zeros((R, Np), dtype=torch.bfloat16, device=dy.device) if Np != nc else torch.empty((R, Np), dtype=torch.bfloat16, device=dy.device)
+            dyr[:, :nc].copy_(src)
+        dyr, da, _ = _take_lazy_bn_backward(ctx.link, dyr, wt, True)
+        if da is None:
+            da = tg.gemm_nt(dyr, wt)                         # gradient of relu(x), (R, K) bf16
+        dw = tg.wgrad(dyr, xr, x_bn_coef=coef)[:N, :Kw].reshape(weight.shape)
+        db = None
+        if has_bias:
+            db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
+        if LAZY_BN_BACKWARD and ctx.in_link is not None:
+            ctx.in_link['lazy'] = (xr, coef, grads, da.data_ptr())     # the producer's data gradient applies the mask while it reads da and x
+            dx = da
+        else:
+            dx = torch.empty_like(xr)
+            _native.call("pdm_bn_relu_backward_apply", torch.cuda.current_stream(dy.device).cuda_stream, 1, 0, R, K, 1, xr.data_ptr(),
+                         da.data_ptr(), dx.data_ptr(), coef.data_ptr(), grads.data_ptr(), 1)
+        return _rows_to_layout(dx, None, K, xshape, xdim), dw, db, None, None, None, None
+
+
+def relu_rows_linear(x, layer, want_stats=False, keep_pad=False, in_link=None, out_link=None):
+    """layer(relu(x)) through _ReluRowsGemm for x fresh out of a rows contraction, or (None, None) when the form does not apply."""
+    from . import train_gemm as tg
+    if not (ENABLED and ROWS_GEMM and BN_IN_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] <= 512 and _bf16_autocast()
+            and layer.weight.dtype == torch.float32 and x.dim() in (2, 3, 4) and in_link is not None):
+        return None, None
+    if isinstance(layer, nn.Linear):
+        kin = layer.in_features
+    else:
+        if not (all(k == 1 for k in layer.kernel_size) and all(v == 1 for v in layer.stride) and all(v == 0 for v in layer.padding)
+                and all(v == 1 for v in layer.dilation) and layer.groups == 1 and isinstance(layer.padding, tuple)
+                and x.dim() == layer.weight.dim()):
+            return None, None
+        kin = layer.in_channels
+    K = x.shape[1]
+    xr = tg.row_view(x)
+    if K != _round8(kin) or K % 8 or xr is None or xr.stride(0) != K:
+        return None, None
+    return _ReluRowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad), in_link, out_link)
 
 
 def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_link=None, out_link=None):
@@ -651,6 +768,8 @@ class TrainSequential(nn.Sequential):
 
     @staticmethod
     def _run(x, mods):
+        if _bump_later and _bump_later[-1] is not None:      # inside a counter_scope (or an outer stack): that one collects
+            return TrainSequential._run_stack(x, mods)
         _bump_later.append([])
         try:
             return TrainSequential._run_stack(x, mods)
@@ -688,6 +807,16 @@ class TrainSequential(nn.Sequential):
                 stats = link = None
                 i += 2 if relu else 1
                 continue
+            if isinstance(m, nn.ReLU) and link is not None and i + 1 < len(mods) and \
+                    (isinstance(mods[i + 1], nn.Linear) or type(mods[i + 1]) in (nn.Conv1d, nn.Conv2d)):
+                # Conv -> ReLU -> Conv: the ReLU rides in the second contraction's load path (and its backward in the first's data gradient)
+                want, pad = _stats_wanted(mods, i + 1)
+                out_link = {}
+                y, st = relu_rows_linear(x, mods[i + 1], want, pad, link, out_link)
+                if y is not None:
+                    x, stats, link = y, st, out_link
+                    i += 2
+                    continue
             stats = link = None
             if isinstance(m, nn.Linear) or type(m) in (nn.Conv1d, nn.Conv2d):
                 want, pad = _stats_wanted(mods, i)

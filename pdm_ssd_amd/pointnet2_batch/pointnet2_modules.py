@@ -246,8 +246,10 @@ class PointnetFPModule(nn.Module):
                 and known_feats.is_cuda and known_feats.dtype == torch.float32
             if fused_ok and interp is not None:
                 idx, weight = interp
-            elif fused_ok:
-                idx, weight = pointnet2_utils.three_nn_weights(unknown, known)   # ref :153-156 in two launches
+            elif fused_ok or (unknown.is_cuda and not (unknown.requires_grad or known.requires_grad)):
+                # ref :153-156 in two launches (coordinates carry no gradient in this pipeline: in training too, instead of
+                # sqrt / add / reciprocal / sum / div as five torch kernels per module)
+                idx, weight = pointnet2_utils.three_nn_weights(unknown, known)
             else:
                 dist, idx = pointnet2_utils.three_nn(unknown.contiguous(), known.contiguous())
                 dist_recip = 1.0 / (dist + 1e-8)  # ref :154

@@ -312,3 +312,36 @@ def test_bn_relu_fp32_in_bf16_out_equals_the_fp32_operator_with_casts(dev):
                     bn.running_var.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("widths,x_grad", [((64, 64, 3), True), ((64, 64, 3), False), ((24, 136, 40), True), ((16, 32, 8), True)])
+@pytest.mark.gpu
+def test_relu_between_two_contractions_rides_in_the_kernels(dev, widths, x_grad):
+    """Conv(bias) -> ReLU -> Conv(bias) under bf16 autocast (the heat-map head's output stack): with the ReLU applied in the second
+    contraction's load path and its backward formed in the first one's data gradient (fused_bn._ReluRowsGemm: the BatchNorm + ReLU
+    forms of the kernels with identity coefficients) outputs, input gradient and parameter gradients are BIT-identical to the path
+    that runs torch's ReLU between the two contractions."""
+    import copy
+    from pdm_ssd_amd import fused_bn
+    torch.manual_seed(21)
+    c0, c1, c2 = widths
+    net = fused_bn.TrainSequential(torch.nn.Conv2d(c0, c1, 1, bias=True), torch.nn.ReLU(), torch.nn.Conv2d(c1, c2, 1, bias=True)).to(dev).train()
+    x0 = torch.randn(3, c0, 50, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    default = fused_bn.BN_IN_GEMM
+    for flag in (True, False):
+        fused_bn.BN_IN_GEMM = flag
+        try:
+            m = copy.deepcopy(net)
+            x = x0.clone().requires_grad_(x_grad)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+                loss = (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum()
+            loss.backward()
+            res.append((y.detach().clone(), x.grad.clone() if x_grad else None, {k: p.grad.clone() for k, p in m.named_parameters()}))
+        finally:
+            fused_bn.BN_IN_GEMM = default
+    (ya, ga, pa), (yb, gb, pb) = res
+    assert torch.equal(ya, yb) and (not x_grad or torch.equal(ga, gb))
+    for k in pa:
+        assert torch.isfinite(pa[k]).all() and torch.equal(pa[k], pb[k]), k
