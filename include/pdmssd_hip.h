@@ -488,6 +488,11 @@ int pdm_point_head_decode(void *stream, long long n, int num_class, const float 
 /* Weight gradient of that convolution (training): gw (9, C), zeroed by the caller, += sum over cells of gout * in[tap].
  * The data gradient is pdm_bev_depthwise3x3 on gout with the nine taps mirrored. */
 int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw);
+/* the pair above with ONE side of the map held in bf16 (training under bf16 autocast; fp32 arithmetic, one rounding to nearest
+ * even): forward fp32 -> bf16 (out_bf16), data gradient bf16 -> fp32 (in_bf16), weight gradient with a bf16 output gradient */
+int pdm_bev_depthwise3x3_t(void *stream, int B, int H, int W, int C, const void *in, int in_bf16, const float *w, const float *shift,
+                           void *out, int out_bf16, int relu);
+int pdm_bev_depthwise3x3_wgrad_t(void *stream, int B, int H, int W, int C, const float *in, const void *gout, int gout_bf16, float *gw);
 
 /* ---- rotated-box IoU / NMS ---------------------------------------------
  * One entry per function of the reference's iou3d_nms_cuda extension (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp):

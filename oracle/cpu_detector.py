@@ -22,8 +22,9 @@ Two modes:
       is > 0, dgamma / dbeta fp32 (the arithmetic of csrc/bn_relu.hip); on an fp32 input nothing is rounded;
     - the SA scales' last BatchNorm + ReLU + max over nsample: the pooled element is the FIRST neighbour attaining the
       max of the layer input x (min where gamma < 0) — pdm_bn_relu_pool_forward's rule;
-    - QueryAndGroup output rounded to bf16 (pdm_group_concat_cl), three_interpolate / PDM scatter / depthwise 3x3 /
-      losses in fp32 (their autograd Functions cast to fp32).
+    - QueryAndGroup output rounded to bf16 (pdm_group_concat_cl), three_interpolate / PDM scatter / losses in fp32 (their
+      autograd Functions cast to fp32); the heat-map head's depthwise 3x3 computes in fp32 on the fp32 map and hands on a
+      bf16 output (its gradient arrives in bf16).
   The comparison is then between two bf16 computations that differ only in fp32 summation order (and the bf16 roundings
   that a last-bit difference flips), instead of a bf16 result against an fp32 one.
 """
@@ -191,9 +192,10 @@ def emu_stack(mods, x, is_bf16, pooled=False):
                 x = _unrows(_MatmulBf16.apply(x2, w, m.bias), shp)
             is_bf16 = True
             i += 1
-        elif isinstance(m, nn.Conv2d):                            # the heat-map head's depthwise 3x3: an fp32 operator
-            x = F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
-            is_bf16 = False
+        elif isinstance(m, nn.Conv2d):                            # the heat-map head's depthwise 3x3: fp32 arithmetic on an fp32 map,
+            # the OUTPUT (and the gradient that comes back for it) held in bf16 (pdm_bev_depthwise3x3_t)
+            x = _AsBf16.apply(F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups))
+            is_bf16 = True
             i += 1
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "pdm_points_in_boxes": [_i, _i, _i, _vp, _vp, _vp],
     "pdm_bev_depthwise3x3": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i],
     "pdm_bev_depthwise3x3_wgrad": [_i, _i, _i, _i, _vp, _vp, _vp],
+    "pdm_bev_depthwise3x3_t": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i],
+    "pdm_bev_depthwise3x3_wgrad_t": [_i, _i, _i, _i, _vp, _vp, _i, _vp],
     "pdm_point_head_decode": [ctypes.c_longlong, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "pdm_bev_head_fused": [_i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i],
     "pdm_sample_points": [_i, _i, ctypes.c_uint, _i, _vp, _vp, _vp, _vp],

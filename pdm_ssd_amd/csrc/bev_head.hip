@@ -9,16 +9,44 @@
 
 namespace pdm {
 
-__global__ __launch_bounds__(256) void depthwise3x3_cl_kernel(int H, int W, int C4, const float4 *__restrict__ in,
+// A map may be held in bf16 (training under bf16 autocast: the convolution's OUTPUT and the gradient that comes back for it; the
+// arithmetic stays fp32, one rounding to nearest even on the way out): four channels = one 8-byte load / store.
+typedef __bf16 dw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+template <bool BF>
+__device__ __forceinline__ float4 dw_ld(const void *__restrict__ base, size_t q) {
+    if constexpr (BF) {
+        const uint2 v = reinterpret_cast<const uint2 *>(base)[q];
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+    } else {
+        return reinterpret_cast<const float4 *>(base)[q];
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void dw_st(void *__restrict__ base, size_t q, const float4 &a) {
+    if constexpr (BF) {
+        const dw_f32x2 lo = {a.x, a.y}, hi = {a.z, a.w};
+        uint2 v;
+        v.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, dw_bf16x2));
+        v.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, dw_bf16x2));
+        reinterpret_cast<uint2 *>(base)[q] = v;
+    } else {
+        reinterpret_cast<float4 *>(base)[q] = a;
+    }
+}
+
+template <bool IB, bool OB>
+__global__ __launch_bounds__(256) void depthwise3x3_cl_kernel(int H, int W, int C4, const void *__restrict__ in,
                                                              const float4 *__restrict__ w, const float4 *__restrict__ shift,
-                                                             float4 *__restrict__ out, int relu) {
+                                                             void *__restrict__ out, int relu) {
     const int b = blockIdx.y;
     const long long cell0 = (long long)blockIdx.x * (256 / C4);
     const int cq = threadIdx.x % C4, lc = threadIdx.x / C4;
     const long long cell = cell0 + lc;
     if (cell >= (long long)H * W || lc >= 256 / C4) return;
     const int y = (int)(cell / W), x = (int)(cell - (long long)y * W);
-    const float4 *__restrict__ img = in + (size_t)b * H * W * C4;
+    const size_t img0 = (size_t)b * H * W * C4;
     float4 acc = shift[cq];
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
@@ -28,22 +56,23 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_kernel(int H, int W, int 
         for (int dx = -1; dx <= 1; ++dx) {
             const int xx = x + dx;
             if (xx < 0 || xx >= W) continue;
-            const float4 v = img[((size_t)yy * W + xx) * C4 + cq];
+            const float4 v = dw_ld<IB>(in, img0 + ((size_t)yy * W + xx) * C4 + cq);
             const float4 k = w[((dy + 1) * 3 + dx + 1) * C4 + cq];
             acc.x = fmaf(k.x, v.x, acc.x); acc.y = fmaf(k.y, v.y, acc.y);
             acc.z = fmaf(k.z, v.z, acc.z); acc.w = fmaf(k.w, v.w, acc.w);
         }
     }
     if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    out[((size_t)b * H * W + cell) * C4 + cq] = acc;
+    dw_st<OB>(out, ((size_t)b * H * W + cell) * C4 + cq, acc);
 }
 
 // The same, a thread owning a STRIP of four consecutive cells of a map row (same channel quad): the 3 x 6 input cells it needs
 // are loaded once (18 loads for 4 outputs instead of 36; the one-cell form ran at 2.5 TB/s of map traffic, bound by the vector
 // L1's request rate).  Same fma order per output as the one-cell kernel (taps row by row, left to right): identical results.
-__global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W, int C4, const float4 *__restrict__ in,
+template <bool IB, bool OB>
+__global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W, int C4, const void *__restrict__ in,
                                                                    const float4 *__restrict__ w, const float4 *__restrict__ shift,
-                                                                   float4 *__restrict__ out, int relu, unsigned wg_per_img) {
+                                                                   void *__restrict__ out, int relu, unsigned wg_per_img) {
     // one-dimensional grid of (image, group of strips).  Launch ids go round-robin over the 8 XCDs; XCD x takes a CONTIGUOUS
     // range of work ids, i.e. bands of map rows: the rows above and below a strip then sit in the same L2 (in launch order the
     // three readers of a map row were on three XCDs, and the map crossed the fabric ~3 times: 3.7 TB/s of map traffic).
@@ -56,7 +85,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W
     const long long strip = (long long)sx * (256 / C4) + ls;
     if (strip >= (long long)H * spr || ls >= 256 / C4) return;
     const int y = (int)(strip / spr), x0 = (int)(strip - (long long)y * spr) * 4;
-    const float4 *__restrict__ img = in + (size_t)b * H * W * C4;
+    const size_t img0 = (size_t)b * H * W * C4;
     float4 k[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) k[t] = w[t * C4 + cq];
@@ -70,7 +99,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int xx = x0 - 1 + j;
-            v[j] = (xx >= 0 && xx < W) ? img[((size_t)yy * W + xx) * C4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[j] = (xx >= 0 && xx < W) ? dw_ld<IB>(in, img0 + ((size_t)yy * W + xx) * C4 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -87,7 +116,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W
         if (x0 + i >= W) break;
         float4 a = acc[i];
         if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-        out[((size_t)b * H * W + (size_t)y * W + x0 + i) * C4 + cq] = a;
+        dw_st<OB>(out, ((size_t)b * H * W + (size_t)y * W + x0 + i) * C4 + cq, a);
     }
 }
 
@@ -95,30 +124,46 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_strip_kernel(int H, int W
 
 // in / out (B, H, W, C) fp32 channels-last (distinct buffers), w (9, C) tap-major with the BatchNorm scale folded in,
 // shift (C).  C a multiple of 4, C <= 1024; all pointers 16-byte aligned.
-extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, const float *in, const float *w,
-                                    const float *shift, float *out, int relu) {
+static int bev_depthwise3x3_impl(const char *who, void *stream, int B, int H, int W, int C, const void *in, int in_bf16, const float *w,
+                                 const float *shift, void *out, int out_bf16, int relu) {
     using namespace pdm;
-    PDM_REQUIRE(B >= 0 && H >= 0 && W >= 0 && C >= 0, PDM_E_BADARG, "bev_depthwise3x3: negative size");
+    PDM_REQUIRE(B >= 0 && H >= 0 && W >= 0 && C >= 0, PDM_E_BADARG, "%s: negative size", who);
     if (B == 0 || H == 0 || W == 0 || C == 0) return 0;
-    PDM_REQUIRE(C % 4 == 0 && C <= 1024 && B <= 65535, PDM_E_BADARG, "bev_depthwise3x3: C=%d (multiple of 4, <= 1024), B=%d", C, B);
-    PDM_REQUIRE(in && w && shift && out && in != out, PDM_E_BADARG, "bev_depthwise3x3: null or aliased pointer");
+    PDM_REQUIRE(C % 4 == 0 && C <= 1024 && B <= 65535, PDM_E_BADARG, "%s: C=%d (multiple of 4, <= 1024), B=%d", who, C, B);
+    PDM_REQUIRE(in && w && shift && out && in != out, PDM_E_BADARG, "%s: null or aliased pointer", who);
     PDM_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(shift) |
-                  reinterpret_cast<uintptr_t>(out)) & 15) == 0, PDM_E_BADARG, "bev_depthwise3x3: buffers must be 16-byte aligned");
+                  reinterpret_cast<uintptr_t>(out)) & 15) == 0, PDM_E_BADARG, "%s: buffers must be 16-byte aligned", who);
+    PDM_REQUIRE(!(in_bf16 && out_bf16), PDM_E_BADARG, "%s: bf16 on one side only (forward: fp32 -> bf16, data gradient: bf16 -> fp32)", who);
     const int C4 = C / 4, cells_per_wg = 256 / C4 > 0 ? 256 / C4 : 1;
-    PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "bev_depthwise3x3: C=%d", C);
+    PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "%s: C=%d", who, C);
     const long long cells = (long long)H * W;
+    const float4 *w4 = reinterpret_cast<const float4 *>(w), *s4 = reinterpret_cast<const float4 *>(shift);
     if (W >= 8) {   // strips of four cells along x
         const long long strips = (long long)H * ((W + 3) / 4);
         const unsigned wpi = (unsigned)((strips + cells_per_wg - 1) / cells_per_wg);
-        hipLaunchKernelGGL(depthwise3x3_cl_strip_kernel, dim3(wpi * (unsigned)B), dim3(256), 0,
-                           as_stream(stream), H, W, C4, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(w),
-                           reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu, wpi);
-        return check_launch("bev_depthwise3x3");
+        const dim3 g(wpi * (unsigned)B), t(256);
+        if (in_bf16) hipLaunchKernelGGL((depthwise3x3_cl_strip_kernel<true, false>), g, t, 0, as_stream(stream), H, W, C4, in, w4, s4, out, relu, wpi);
+        else if (out_bf16) hipLaunchKernelGGL((depthwise3x3_cl_strip_kernel<false, true>), g, t, 0, as_stream(stream), H, W, C4, in, w4, s4, out, relu, wpi);
+        else hipLaunchKernelGGL((depthwise3x3_cl_strip_kernel<false, false>), g, t, 0, as_stream(stream), H, W, C4, in, w4, s4, out, relu, wpi);
+        return check_launch(who);
     }
-    hipLaunchKernelGGL(depthwise3x3_cl_kernel, dim3((unsigned)((cells + cells_per_wg - 1) / cells_per_wg), B), dim3(256), 0,
-                       as_stream(stream), H, W, C4, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(w),
-                       reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out), relu);
-    return check_launch("bev_depthwise3x3");
+    const dim3 g((unsigned)((cells + cells_per_wg - 1) / cells_per_wg), B), t(256);
+    if (in_bf16) hipLaunchKernelGGL((depthwise3x3_cl_kernel<true, false>), g, t, 0, as_stream(stream), H, W, C4, in, w4, s4, out, relu);
+    else if (out_bf16) hipLaunchKernelGGL((depthwise3x3_cl_kernel<false, true>), g, t, 0, as_stream(stream), H, W, C4, in, w4, s4, out, relu);
+    else hipLaunchKernelGGL((depthwise3x3_cl_kernel<false, false>), g, t, 0, as_stream(stream), H, W, C4, in, w4, s4, out, relu);
+    return check_launch(who);
+}
+
+extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, const float *in, const float *w,
+                                    const float *shift, float *out, int relu) {
+    return bev_depthwise3x3_impl("bev_depthwise3x3", stream, B, H, W, C, in, 0, w, shift, out, 0, relu);
+}
+
+// The same with ONE side of the map in bf16 (training under bf16 autocast): in_bf16 = the input is bf16 (the data gradient, fed the
+// bf16 gradient of the output), out_bf16 = the output is rounded to bf16 (the forward).  fp32 arithmetic either way.
+extern "C" int pdm_bev_depthwise3x3_t(void *stream, int B, int H, int W, int C, const void *in, int in_bf16, const float *w,
+                                      const float *shift, void *out, int out_bf16, int relu) {
+    return bev_depthwise3x3_impl("bev_depthwise3x3_t", stream, B, H, W, C, in, in_bf16, w, shift, out, out_bf16, relu);
 }
 
 // Weight gradient of the depthwise 3x3 convolution above:
@@ -128,8 +173,9 @@ extern "C" int pdm_bev_depthwise3x3(void *stream, int B, int H, int W, int C, co
 // (The data gradient is the same convolution with the taps mirrored: pdm_bev_depthwise3x3 on gout.)
 namespace pdm {
 
+template <bool GB>
 __global__ __launch_bounds__(256) void depthwise3x3_cl_wgrad_kernel(int H, int W, int C4, long long cells_total, int cells_per_wg,
-                                                                   const float4 *__restrict__ in, const float4 *__restrict__ gout,
+                                                                   const float4 *__restrict__ in, const void *__restrict__ gout,
                                                                    float *__restrict__ gw) {
     extern __shared__ float red[];   // (256 / C4) rows x 36 x C4 x 4 floats -> reduced over rows
     const int cq = threadIdx.x % C4, lc = threadIdx.x / C4, rows = 256 / C4;
@@ -152,7 +198,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_wgrad_kernel(int H, int W
             float4 g[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                g[i] = x0 + i < W ? gout[(by * W + x0 + i) * C4 + cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+                g[i] = x0 + i < W ? dw_ld<GB>(gout, (size_t)((by * W + x0 + i) * C4 + cq)) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy) {
                 const int yy = y + dy;
@@ -194,26 +240,40 @@ __global__ __launch_bounds__(256) void depthwise3x3_cl_wgrad_kernel(int H, int W
 
 // in, gout (B, H, W, C) fp32 channels-last; gw (9, C) fp32, ZEROED by the caller, receives the sums (float atomics
 // between workgroups: the order of the last additions is free, compare with a tolerance).
-extern "C" int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw) {
+static int bev_depthwise3x3_wgrad_impl(const char *who, void *stream, int B, int H, int W, int C, const float *in, const void *gout,
+                                       int gout_bf16, float *gw) {
     using namespace pdm;
-    PDM_REQUIRE(B >= 0 && H >= 0 && W >= 0 && C >= 0, PDM_E_BADARG, "bev_depthwise3x3_wgrad: negative size");
+    PDM_REQUIRE(B >= 0 && H >= 0 && W >= 0 && C >= 0, PDM_E_BADARG, "%s: negative size", who);
     if (B == 0 || H == 0 || W == 0 || C == 0) return 0;
-    PDM_REQUIRE(C % 4 == 0 && C <= 1024, PDM_E_BADARG, "bev_depthwise3x3_wgrad: C=%d (multiple of 4, <= 1024)", C);
-    PDM_REQUIRE(in && gout && gw, PDM_E_BADARG, "bev_depthwise3x3_wgrad: null pointer");
+    PDM_REQUIRE(C % 4 == 0 && C <= 1024, PDM_E_BADARG, "%s: C=%d (multiple of 4, <= 1024)", who, C);
+    PDM_REQUIRE(in && gout && gw, PDM_E_BADARG, "%s: null pointer", who);
     PDM_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(gw)) & 15) == 0,
-                PDM_E_BADARG, "bev_depthwise3x3_wgrad: buffers must be 16-byte aligned");
+                PDM_E_BADARG, "%s: buffers must be 16-byte aligned", who);
     const int C4 = C / 4;
     const long long cells = (long long)B * H * ((W + 3) / 4);   // work units: strips of four cells along x
     const int rows = 256 / C4 > 0 ? 256 / C4 : 1;
-    PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "bev_depthwise3x3_wgrad: C=%d", C);
+    PDM_REQUIRE(C4 <= 256, PDM_E_BADARG, "%s: C=%d", who, C);
     int wgs = 2048;
     if (cells < wgs * (long long)rows) wgs = (int)((cells + rows - 1) / rows);
     const int per = (int)((cells + wgs - 1) / wgs);
     const size_t lds = (size_t)rows * 9 * C4 * 4 * sizeof(float);
-    PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "bev_depthwise3x3_wgrad: %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(depthwise3x3_cl_wgrad_kernel, dim3((unsigned)((cells + per - 1) / per)), dim3(256), lds, as_stream(stream), H, W,
-                       C4, cells, per, reinterpret_cast<const float4 *>(in), reinterpret_cast<const float4 *>(gout), gw);
-    return check_launch("bev_depthwise3x3_wgrad");
+    PDM_REQUIRE(lds <= 64 * 1024, PDM_E_TOOLARGE, "%s: %zu bytes of LDS", who, lds);
+    const dim3 g((unsigned)((cells + per - 1) / per)), t(256);
+    if (gout_bf16) hipLaunchKernelGGL((depthwise3x3_cl_wgrad_kernel<true>), g, t, lds, as_stream(stream), H, W, C4, cells, per,
+                                      reinterpret_cast<const float4 *>(in), gout, gw);
+    else hipLaunchKernelGGL((depthwise3x3_cl_wgrad_kernel<false>), g, t, lds, as_stream(stream), H, W, C4, cells, per,
+                            reinterpret_cast<const float4 *>(in), gout, gw);
+    return check_launch(who);
+}
+
+extern "C" int pdm_bev_depthwise3x3_wgrad(void *stream, int B, int H, int W, int C, const float *in, const float *gout, float *gw) {
+    return bev_depthwise3x3_wgrad_impl("bev_depthwise3x3_wgrad", stream, B, H, W, C, in, gout, 0, gw);
+}
+
+// the same with the output gradient held in bf16 (gout_bf16 = 1): see pdm_bev_depthwise3x3_t
+extern "C" int pdm_bev_depthwise3x3_wgrad_t(void *stream, int B, int H, int W, int C, const float *in, const void *gout, int gout_bf16,
+                                            float *gw) {
+    return bev_depthwise3x3_wgrad_impl("bev_depthwise3x3_wgrad_t", stream, B, H, W, C, in, gout, gout_bf16, gw);
 }
 
 // Point head epilogue in one pass: class scores and decoded boxes of every point.

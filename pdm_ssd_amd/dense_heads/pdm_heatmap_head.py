@@ -14,6 +14,8 @@ is 128 x 200 x 176 — a dense 2-D problem MIOpen handles; nothing on it is a ho
   more FLOPs than the whole point backbone; 'full' = 3x3 conv + BN + ReLU as CenterPoint's shared_conv.
   batch_dict['bev_heatmap'] = sigmoid(logits)  (B, num_class, H, W)
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -26,22 +28,26 @@ from ..fused_bn import TrainSequential
 class _Depthwise3x3CL(torch.autograd.Function):
     """Depthwise 3x3 convolution (padding 1, no bias) on a channels-last fp32 map, forward and backward on the HIP
     kernels of csrc/bev_head.hip.  MIOpen's depthwise path for this shape (128 channels x 200 x 176 x 32) costs ~170 ms
-    per training step in its weight-gradient kernel alone; these are three memory-bound passes over the map."""
+    per training step in its weight-gradient kernel alone; these are three memory-bound passes over the map.
+    out_bf16 (training under bf16 autocast): fp32 arithmetic on the fp32 map, the OUTPUT rounded once to bf16 — what autocast
+    gives a convolution's output, without its rounding of the inputs — and the gradient taken in bf16: the BatchNorm behind it
+    and the two gradient kernels then move half the bytes (576 -> 288 MB per pass at bs = 32)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, out_bf16=False):
         from .. import _native
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
             rows = rows.contiguous()
         B, H, W, C = rows.shape
         w9 = weight.reshape(C, 9).t().contiguous()                 # (9, C) tap-major
-        out = torch.empty_like(rows)
+        out = torch.empty_like(rows, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(rows)
         zero = torch.zeros(C, dtype=torch.float32, device=x.device)
-        _native.call("pdm_bev_depthwise3x3", torch.cuda.current_stream(x.device).cuda_stream, B, H, W, C, rows.data_ptr(),
-                     w9.data_ptr(), zero.data_ptr(), out.data_ptr(), 0)
+        _native.call("pdm_bev_depthwise3x3_t", torch.cuda.current_stream(x.device).cuda_stream, B, H, W, C, rows.data_ptr(), 0,
+                     w9.data_ptr(), zero.data_ptr(), out.data_ptr(), 1 if out_bf16 else 0, 0)
         ctx.save_for_backward(rows, w9)
+        ctx.out_bf16 = bool(out_bf16)
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -50,7 +56,8 @@ class _Depthwise3x3CL(torch.autograd.Function):
         from .. import _native
         rows, w9 = ctx.saved_tensors
         B, H, W, C = rows.shape
-        gr = g.float().permute(0, 2, 3, 1)
+        gb = 1 if ctx.out_bf16 else 0
+        gr = (g.to(torch.bfloat16) if gb else g.float()).permute(0, 2, 3, 1)
         if not gr.is_contiguous():
             gr = gr.contiguous()
         stream = torch.cuda.current_stream(rows.device).cuda_stream
@@ -58,14 +65,14 @@ class _Depthwise3x3CL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx_rows = torch.empty_like(rows)
             zero = torch.zeros(C, dtype=torch.float32, device=rows.device)
-            _native.call("pdm_bev_depthwise3x3", stream, B, H, W, C, gr.data_ptr(), w9.flip(0).contiguous().data_ptr(),
-                         zero.data_ptr(), gx_rows.data_ptr(), 0)
+            _native.call("pdm_bev_depthwise3x3_t", stream, B, H, W, C, gr.data_ptr(), gb, w9.flip(0).contiguous().data_ptr(),
+                         zero.data_ptr(), gx_rows.data_ptr(), 0, 0)
             gx = gx_rows.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw9 = torch.zeros((9, C), dtype=torch.float32, device=rows.device)
-            _native.call("pdm_bev_depthwise3x3_wgrad", stream, B, H, W, C, rows.data_ptr(), gr.data_ptr(), gw9.data_ptr())
+            _native.call("pdm_bev_depthwise3x3_wgrad_t", stream, B, H, W, C, rows.data_ptr(), gr.data_ptr(), gb, gw9.data_ptr())
             gw = gw9.t().reshape(C, 1, 3, 3)
-        return gx, gw
+        return gx, gw, None
 
 
 class _DepthwiseConv3x3(nn.Conv2d):
@@ -74,8 +81,14 @@ class _DepthwiseConv3x3(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and x.shape[1] % 4 == 0:
-            return _Depthwise3x3CL.apply(x, self.weight)
+            from .. import fused_bn
+            bf = self.training and fused_bn.ENABLED and fused_bn._bf16_autocast() and x.shape[1] % 8 == 0 and DEPTHWISE_BF16_OUT
+            return _Depthwise3x3CL.apply(x, self.weight, bool(bf))
         return super().forward(x)
+
+
+# 1 (default): under bf16 autocast in training the depthwise convolution hands on a bf16 map (see _Depthwise3x3CL)
+DEPTHWISE_BF16_OUT = os.environ.get("PDM_DEPTHWISE_BF16_OUT", "1") == "1"
 
 
 class PDMHeatmapHead(nn.Module):

@@ -447,3 +447,26 @@ def test_depthwise3x3_hip_forward_backward_match_torch_conv(dev):
         got.backward(go)
         torch.testing.assert_close(x2.grad, x1.grad, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(w2.grad, w1.grad, rtol=1e-4, atol=1e-4 * float(w1.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_depthwise3x3_with_a_bf16_output_is_the_fp32_operator_rounded_once(dev):
+    """_Depthwise3x3CL(out_bf16=True) (pdm_bev_depthwise3x3_t / _wgrad_t: the training form under bf16 autocast): the output is
+    the fp32 operator's output rounded to bf16, BIT for bit; fed a bf16 gradient, the input gradient equals the fp32 operator's
+    on that gradient bit for bit (same kernel arithmetic, bf16 values are exact in fp32) and the weight gradient agrees to the
+    order of the float atomics.  Odd sizes (one-cell kernel) included."""
+    from pdm_ssd_amd.dense_heads.pdm_heatmap_head import _Depthwise3x3CL
+    torch.manual_seed(6)
+    for (B, C, H, W) in ((2, 128, 50, 44), (1, 8, 5, 3), (3, 64, 17, 200)):
+        x = (torch.randn(B, H, W, C, device=dev) * (torch.rand(B, H, W, 1, device=dev) < 0.5)).permute(0, 3, 1, 2)
+        w = torch.randn(C, 1, 3, 3, device=dev)
+        x1, w1 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        want = _Depthwise3x3CL.apply(x1, w1)
+        got = _Depthwise3x3CL.apply(x2, w2, True)
+        assert got.dtype == torch.bfloat16 and torch.equal(got, want.to(torch.bfloat16))
+        go = torch.randn_like(want).to(torch.bfloat16)
+        want.backward(go.float())
+        got.backward(go)
+        assert torch.equal(x2.grad, x1.grad)
+        torch.testing.assert_close(w2.grad, w1.grad, rtol=1e-4, atol=1e-4 * float(w1.grad.abs().max()))
