@@ -428,7 +428,9 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
 // tile) with the X rows of two stages ahead in flight (two register sets that swap roles stage by stage): a wide layer has 4-8
 // k-steps per tile, and one 16 KB stage per workgroup in flight left the kernel waiting for memory at 3.1-3.7 TB/s (head layers
 // 172 -> 152 us).  The narrow tiles keep the loop above: this structure runs them 15-20 % slower (measured).
-template <int XF, bool BS = false>
+// (no BS form: with the gradient statistics' sixteen sums this structure spills ~100 registers; wide products with statistics
+// take tg_nt_kernel<2, 2, 0, true>)
+template <int XF>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slots) {
     constexpr int WN = 2, JT = 2;
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
@@ -602,12 +604,6 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
         if (kt == nk - 1) {
             // ---- epilogue: bf16 (RNE) into an LDS tile [BM][pitch YP]; lane = output row, 4 registers = 4 consecutive channels
             if (nk == 1 && XB + WB <= MAIN && YB <= XB) w_resident = true;      // the epilogue tile does not reach the weight stage
-            TgBsCoef bcf;
-            if constexpr (BS) {
-                const float *cp = a.bcf;
-                asm volatile("" : "+s"(cp));
-                tg_bs_coef8(bcf, cp, a.N, col0 + chunk_o * 8);
-            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + (lane & 31);
@@ -636,11 +632,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
                 const long long r = row0 + row;
                 const int n = col0 + chunk_o * 8;
                 if (r < a.R && n < a.N) *reinterpret_cast<uint4 *>(a.Y + r * a.ldy + n) = v;
-                if constexpr (BS) {   // rows beyond R / columns beyond N hold zeros: g = 0
-                    const uint4 bx = (r < a.R && n < a.N) ? *reinterpret_cast<const uint4 *>(a.Bx + r * a.ldbx + n) : make_uint4(0, 0, 0, 0);
-                    tg_bs_accum(v, bx, bcf, s1, s2);
-                }
-                if (!BS && XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
+                if (XF != 2 && a.stats) {   // rows beyond R were staged as zeros: they add nothing
                     const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -663,7 +655,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
     } else {
         while (rt < row_tiles) stage(xr, xa);
     }
-    if (BS || (XF != 2 && a.stats)) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
+    if (XF != 2 && a.stats) {   // one partial per slot.  Lanes with equal t % CH hold the same columns.
         float *red = reinterpret_cast<float *>(smem + MAIN);       // [4 waves][BN columns] sums, then the same of squares
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -684,7 +676,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
         if (t < BN && col0 + t < a.N) {
             const float sa = ((red[t] + red[BN + t]) + red[2 * BN + t]) + red[3 * BN + t];
             const float sb = ((red[4 * BN + t] + red[5 * BN + t]) + red[6 * BN + t]) + red[7 * BN + t];
-            float *o = (BS ? a.bstats : a.stats) + ((long long)slot * a.N + col0 + t) * 2;
+            float *o = a.stats + ((long long)slot * a.N + col0 + t) * 2;
             o[0] = sa; o[1] = sb;
         }
     }
@@ -1159,7 +1151,7 @@ static long long tg_wgrad_slabs(long long R, int K, int N) {
     long long slabs = (R + 1023) / 1024;
     const long long cap = (24ll << 20) / ((long long)N * K * 4);
     if (slabs > cap) slabs = cap < 1 ? 1 : cap;
-    if (slabs > 1024) slabs = 1024;                  // two levels of the fold tree at most
+    if (slabs > 1024) slabs = 1024;                  // (what one fold launch sums per element: 16 groups x 64 parts)
     return slabs < 1 ? 1 : slabs;
 }
 extern "C" size_t pdm_tg_wgrad_ws_bytes(long long R, int K, int N) {

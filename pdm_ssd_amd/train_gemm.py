@@ -69,14 +69,33 @@ def _pack_weight_pair_now(w, rows_to, cols_to, buf=None):
 
 # The packed pairs of a model's parameters are kept between calls and refreshed TOGETHER: a parameter changes once per optimizer
 # step, and a training step of the detector packed ~40 of them in 40 launches.  An entry remembers the parameter (weakly), its
-# storage address and its version counter (torch bumps it on every in-place update: optimizer steps, load_state_dict, copy_);
-# the first request that finds a stale entry repacks EVERY live entry in one launch (pdm_tg_pack_weight_many over a job table in
-# device memory, rebuilt only when the set of entries changes).  The buffers are persistent: a pair handed out (and saved for a
+# storage address, its version counter (torch bumps it on in-place updates: load_state_dict, copy_, the foreach optimizers) and the
+# count of optimizer steps seen so far (the FUSED optimizers move no version counter: _watch_optimizers);
+# the first request that finds a stale entry — or that asks for a pair a second time since the last refresh, i.e. at the start of
+# every new pass over a model — repacks EVERY live entry in one launch (pdm_tg_pack_weight_many over a job table in device memory,
+# rebuilt only when the set of entries changes).  The buffers are persistent: a pair handed out (and saved for a
 # backward) is overwritten by the next refresh, i.e. after the parameter itself has been overwritten.  PDM_PACK_CACHE=0: one launch
-# per request, fresh buffers.  Not used while a stream is being captured into a graph.
+# per request, fresh buffers.  Not used while a stream is being captured into a graph.  What the cache cannot see — a write through
+# `.data` or a raw pointer that is not followed by a new pass over the same layers — needs invalidate_packs().
 PACK_CACHE = os.environ.get("PDM_PACK_CACHE", "1") == "1"
-_packs = {}                       # (device index, address, N, K, rows_to, cols_to) -> [weakref(parameter), buffer (2, rows_to * cols_to), version]
+_packs = {}                       # (device index, address, N, K, rows_to, cols_to) -> [weakref(parameter), buffer (2, rows_to * cols_to), version, epoch]
 _pack_tables = {}                 # device index -> (job table tensor, njobs, total blocks, tuple of keys)
+_served = {}                      # device index -> keys handed out since the last refresh
+_opt_epoch = [0, False]           # [optimizer steps seen (a global post-step hook), hook registered]
+
+
+def _note_optimizer_step(*_args, **_kwargs):
+    _opt_epoch[0] += 1
+
+
+def _watch_optimizers():
+    """torch's FUSED multi-tensor optimizers (AdamW(fused=True): bench.py's default) update parameters without moving their version
+    counters — a cache keyed on the counter alone served the initial weights for a whole run (final loss 250 instead of 25 after 14
+    steps).  Every optimizer step therefore also advances an epoch (a global post-step hook) that the entries remember."""
+    if not _opt_epoch[1]:
+        _opt_epoch[1] = True
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(_note_optimizer_step)
 
 
 def _refresh_packs(dev_index, device):
@@ -84,7 +103,7 @@ def _refresh_packs(dev_index, device):
     import numpy as np
     live = []
     for key in [k for k in _packs if k[0] == dev_index]:
-        ref, buf, _ = _packs[key]
+        ref, buf = _packs[key][0], _packs[key][1]
         base = ref()
         if base is None or base.data_ptr() != key[1]:
             del _packs[key]                           # the parameter is gone (or moved): its pair with it
@@ -107,6 +126,15 @@ def _refresh_packs(dev_index, device):
         _native.call("pdm_tg_pack_weight_many", torch.cuda.current_stream(device).cuda_stream, table[1], table[0].data_ptr(), table[2])
     for key, base, _ in live:
         _packs[key][2] = base._version
+        _packs[key][3] = _opt_epoch[0]
+
+
+def invalidate_packs():
+    """Forget every cached pair (the next requests pack afresh).  For edits the cache cannot see: a write through `.data` or a raw
+    pointer between two requests that are not a pass apart."""
+    _packs.clear()
+    _pack_tables.clear()
+    _served.clear()
 
 
 def pack_weight_pair(w, rows_to, cols_to):
@@ -118,19 +146,26 @@ def pack_weight_pair(w, rows_to, cols_to):
     if not (PACK_CACHE and w.is_contiguous() and base.data_ptr() == w.data_ptr() and not torch.cuda.is_current_stream_capturing()):
         return _pack_weight_pair_now(w.detach().contiguous(), rows_to, cols_to)
     import weakref
+    _watch_optimizers()
     N, K = w.shape
     key = (w.device.index, w.data_ptr(), N, K, rows_to, cols_to)
     ent = _packs.get(key)
+    served = _served.setdefault(w.device.index, set())
     if ent is not None and ent[0]() is base:
-        if ent[2] != base._version:
+        # stale by the version counter, OR asked for a second time since the last refresh: a new pass over the model has begun, and
+        # an edit through `.data` (which moves no version counter) may lie in between — one refresh launch per pass either way
+        if ent[2] != base._version or ent[3] != _opt_epoch[0] or key in served:
             _refresh_packs(w.device.index, w.device)
+            served.clear()
+        served.add(key)
         buf = ent[1]
         return buf[0].view(rows_to, cols_to), buf[1].view(cols_to, rows_to)
+    served.add(key)
     if len(_packs) > 4096:                             # models come and go (tests): drop the pairs of dead parameters
         for k in [k for k, e in _packs.items() if e[0]() is None]:
             del _packs[k]
     buf = torch.empty((2, rows_to * cols_to), dtype=torch.bfloat16, device=w.device)
-    _packs[key] = [weakref.ref(base), buf, base._version]
+    _packs[key] = [weakref.ref(base), buf, base._version, _opt_epoch[0]]
     return _pack_weight_pair_now(w.detach(), rows_to, cols_to, buf)
 
 

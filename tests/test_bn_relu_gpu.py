@@ -345,3 +345,40 @@ def test_relu_between_two_contractions_rides_in_the_kernels(dev, widths, x_grad)
     assert torch.equal(ya, yb) and (not x_grad or torch.equal(ga, gb))
     for k in pa:
         assert torch.isfinite(pa[k]).all() and torch.equal(pa[k], pb[k]), k
+
+
+@pytest.mark.parametrize("fused_opt", [True, False])
+@pytest.mark.gpu
+def test_training_over_several_optimizer_steps_is_the_same_with_and_without_the_weight_cache(dev, fused_opt):
+    """Six AdamW steps of a Conv -> BN -> ReLU -> Conv -> BN -> ReLU -> Conv stack under bf16 autocast: with the packed bf16 weight
+    pairs cached between steps (train_gemm.PACK_CACHE) every loss equals, BIT for bit, the run that repacks on every request.
+    (torch's FUSED optimizers update parameters without moving their version counters: a cache that trusted the counter alone
+    trained on the initial weights — losses then stop falling; this is the regression test of that.)"""
+    import copy
+    from pdm_ssd_amd import fused_bn, train_gemm as tg
+    torch.manual_seed(31)
+    net = fused_bn.TrainSequential(torch.nn.Conv2d(16, 32, 1, bias=False), torch.nn.BatchNorm2d(32), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(32, 64, 1, bias=False), torch.nn.BatchNorm2d(64), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(64, 8, 1, bias=True)).to(dev).train()
+    x = torch.randn(4, 16, 40, 16, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    want = torch.randn(4, 8, 40, 16, device=dev)
+    runs = []
+    default = tg.PACK_CACHE
+    for cache in (True, False):
+        tg.PACK_CACHE = cache
+        try:
+            m = copy.deepcopy(net)
+            opt = torch.optim.AdamW(m.parameters(), lr=3e-2, fused=fused_opt)
+            losses = []
+            for _ in range(6):
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = ((m(x).float() - want) ** 2).mean()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            runs.append(losses)
+        finally:
+            tg.PACK_CACHE = default
+    assert default and runs[0] == runs[1], runs
+    assert runs[0][-1] < runs[0][0] and len(set(runs[0])) == 6, runs[0]     # and it does train (every step sees new weights)

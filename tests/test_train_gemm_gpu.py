@@ -202,6 +202,31 @@ def test_packed_weight_pairs_are_cached_and_refreshed_together(dev):
         conv.add_(1.0)
     for (a, b), (c, d) in zip(pairs(), fresh()):
         assert torch.equal(a, c) and torch.equal(b, d)
+    # torch's fused multi-tensor optimizer moves no version counter either: a pair asked for the FIRST time since the last refresh, after
+    # an optimizer step, must still be current (two models taking turns: the generator / discriminator pattern)
+    other = torch.nn.Parameter(torch.randn(40, 24, device=dev))
+    pair_other = lambda: tg.pack_weight_pair(other, 40, 24)
+    pair_other()
+    for p in params + [other]:
+        p.grad = torch.randn_like(p)
+    opt_a, opt_b = torch.optim.AdamW(params, lr=0.1, fused=True), torch.optim.AdamW([other], lr=0.1, fused=True)
+    opt_a.step()
+    for (a, b), (c, d) in zip(pairs()[:-1], fresh()[:-1]):      # refresh (clears what was handed out)
+        assert torch.equal(a, c) and torch.equal(b, d)
+    opt_b.step()                                               # `other` changes; it has not been asked for since the refresh
+    a, b = pair_other()
+    c, d = tg._pack_weight_pair_now(other.detach(), 40, 24)
+    assert torch.equal(a, c) and torch.equal(b, d)
+    # an edit through .data moves no version counter and no optimizer hook: the next pass over the same parameters (a pair asked for
+    # AGAIN since the last refresh) refreshes anyway; tg.invalidate_packs() is the explicit form
+    pairs()
+    params[3].data.mul_(-2.0)
+    for (a, b), (c, d) in zip(pairs(), fresh()):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    params[4].data.add_(1.0)
+    tg.invalidate_packs()
+    for (a, b), (c, d) in zip(pairs(), fresh()):
+        assert torch.equal(a, c) and torch.equal(b, d)
     # one parameter changes alone; then one dies and another is born (possibly at its address)
     with torch.no_grad():
         params[2].zero_()
