@@ -962,6 +962,9 @@ def main():
     if os.environ.get("PDM_DW_WG_PER_CU"):       # A/B knob: grid cap of the heat-map head's one-kernel form
         _native.lib().pdm_tune_rows_chain_dw_wg_per_cu(int(os.environ["PDM_DW_WG_PER_CU"]))
 
+    if os.environ.get("PDM_RC_WG_PER_CU"):       # A/B knob: grid cap of the point head's chain kernels (workgroups per CU over the launch)
+        _native.lib().pdm_tune_rows_chain_wg_per_cu(int(os.environ["PDM_RC_WG_PER_CU"]))
+
     B, N = args.batch, args.points
     scaling = "weak"
     if args.global_batch:
