@@ -462,6 +462,11 @@ int pdm_bn_pool_parts(int dtype, long long G, int C);
 int pdm_bn_relu_pool_forward(void *stream, int dtype, long long G, int ns, int C, const void *x, void *y, void *xmax, void *xmin,
                              unsigned char *imax, unsigned char *imin, const float *gamma, const float *beta, float eps,
                              float momentum, float *running_mean, float *running_var, float *coef, float *partial, int relu);
+/* the forward when the producer of x (pdm_tg_gemm_nt_pool) has already left the column sums ([parts][C][2]) and every group's
+ * max / min: finalize + pooled output only; bf16 (dtype 1) */
+int pdm_bn_relu_pool_forward_kept(void *stream, int dtype, long long G, int ns, int C, void *y, const void *xmax, const void *xmin,
+                                  const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                  float *running_var, float *coef, const float *partial, int parts, int relu);
 int pdm_bn_relu_pool_backward(void *stream, int dtype, long long G, int ns, int C, const void *x, const void *dy, void *dx,
                               const void *xmax, const void *xmin, const unsigned char *imax, const unsigned char *imin,
                               const float *coef, float *grads, float *partial, int relu);
@@ -566,6 +571,13 @@ int pdm_tg_gemm_nt_dy(void *stream, long long R, int K, int N, const void *dZ, l
  * Bx (R, N) bf16 = that BatchNorm's input, bcoef (4, N) = its coefficients from pdm_bn_finalize_stats. */
 int pdm_tg_gemm_nt_bs(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
                       void *Y, long long ldy, const void *Bx, long long ldbx, const float *bcoef, float *bstats);
+/* pdm_tg_gemm_nt for the last layer of an SA scale (pointnet2_modules.py:46-52: ... -> BatchNorm -> ReLU -> max over nsample): rows
+ * g ns .. g ns + ns - 1 are group g; the epilogue also leaves every group's per-channel max / min of the rounded outputs and the first
+ * index attaining them (xmax, xmin (R / ns, N) bf16; imax, imin (R / ns, N) bytes) — pdm_bn_relu_pool_forward's statistics pass
+ * without its read of Y; pdm_bn_relu_pool_forward_kept finishes the operator.  ns a power of two, 4 .. 128, dividing R. */
+int pdm_tg_gemm_nt_pool(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                        void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef, int ns, void *xmax,
+                        void *xmin, unsigned char *imax, unsigned char *imin);
 int pdm_tg_dy_stats_parts(long long rows, int N);
 int pdm_tg_gemm_nt_dy_bs(void *stream, long long R, int K, int N, const void *dZ, long long lddz, const void *Yp, long long ldyp,
                          const void *W, long long ldw, void *dX, long long lddx, void *dYout, long long lddy, const float *coef,

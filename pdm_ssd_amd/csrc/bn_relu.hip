@@ -694,6 +694,29 @@ extern "C" int pdm_bn_relu_pool_forward(void *stream, int dtype, long long G, in
     return check_launch("bn_relu_pool_forward");
 }
 
+// The same forward when the producer of x has already taken everything the statistics pass computes: pdm_tg_gemm_nt_pool
+// (train_gemm.hip) leaves the column sums of x and x^2 per slot (`partial` = [parts][C][2], plain sums) and every group's max / min
+// with their first indices.  What is left: the finalize (coef, running statistics) and the pooled output.  bf16 only (dtype 1).
+extern "C" int pdm_bn_relu_pool_forward_kept(void *stream, int dtype, long long G, int ns, int C, void *y, const void *xmax, const void *xmin,
+                                             const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                             float *running_var, float *coef, const float *partial, int parts, int relu) {
+    PDM_REQUIRE(dtype == 1, PDM_E_BADARG, "bn_relu_pool_forward_kept: dtype %d (1 = bf16)", dtype);
+    PDM_REQUIRE(G >= 0 && ns >= 1 && ns <= 255 && C >= 8 && C % 8 == 0 && C / 8 <= 256, PDM_E_BADARG,
+                "bn_relu_pool_forward_kept: G=%lld ns=%d C=%d", G, ns, C);
+    if (G == 0) return 0;
+    PDM_REQUIRE(y && xmax && xmin && coef && partial && parts >= 1, PDM_E_BADARG, "bn_relu_pool_forward_kept: null pointer");
+    PDM_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(xmax) | reinterpret_cast<uintptr_t>(xmin)) & 15) == 0, PDM_E_BADARG,
+                "bn_relu_pool_forward_kept: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)G * (double)ns, gamma, beta,
+                       eps, momentum, running_mean, running_var, coef, 1);
+    const int per = 256 / (C / 8);
+    const unsigned grid = bn_pool_grid(G, per);
+    const BnCoef k = coef_of(coef, nullptr, C);
+    hipLaunchKernelGGL((bn_pool_small_kernel<bf16_t, 0>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)xmax, (const bf16_t *)xmin,
+                       (const bf16_t *)nullptr, (bf16_t *)y, G, C, k, relu, (float *)nullptr);
+    return check_launch("bn_relu_pool_forward_kept");
+}
+
 // Backward of the above: dx (G, ns, C) from dy (G, C); grads (4, C) = [dgamma | dbeta | p | q].
 extern "C" int pdm_bn_relu_pool_backward(void *stream, int dtype, long long G, int ns, int C, const void *x, const void *dy, void *dx,
                                          const void *xmax, const void *xmin, const unsigned char *imax, const unsigned char *imin,

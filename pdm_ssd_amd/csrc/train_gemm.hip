@@ -80,6 +80,12 @@ struct TgNtArgs {
     const unsigned short *Bx; long long ldbx;   // (R, N) bf16: that BatchNorm's input
     const float *bcf;                           // (4, N) fp32 [mean | invstd | scale | shift] (pdm_bn_finalize_stats)
     float *bstats;                              // [slots][N][2]
+    // PL (the product is the input of BatchNorm + ReLU + max over the ns neighbours of a group — the tail of an SA scale, rows g ns ..
+    // g ns + ns - 1 = group g): the epilogue also leaves every group's max / min of the ROUNDED outputs per channel with the first
+    // index attaining them, (R / ns, N) each — what bn_pool_stats_kernel (bn_relu.hip) reads the whole tensor again for
+    int pl_ns;
+    unsigned short *pl_max, *pl_min;            // (R / ns, N) bf16
+    unsigned char *pl_imax, *pl_imin;           // (R / ns, N)
     long long R;
     int K, N;
 };
@@ -177,6 +183,64 @@ __device__ __forceinline__ void tg_bs_coef8(TgBsCoef &c, const float *__restrict
 // (half, chunk) slots
 __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// Pooled-operator epilogue (TgNtArgs::pl_*): the groups of a row tile that sits in LDS as [BM][pitch] bf16.  Work item = (group of the
+// tile, 16-byte chunk of 8 channels, QUARTER of the group's ns rows): four neighbouring lanes share a (group, chunk) and are folded with
+// two shuffles — with one thread per (group, chunk) a quarter of the workgroup walked 16-32 rows each while the rest waited (+30 % on
+// the widest-row contractions).  Strict comparisons keep the FIRST neighbour attaining an extreme (bn_pool_stats_kernel's rule); between
+// quarters a tie goes to the lower quarter.
+template <int BM, int CH, int YP>
+__device__ __forceinline__ void tg_pool_tile(const TgNtArgs &a, const unsigned char *tile, long long row0, int col0, int t) {
+    const int ns = a.pl_ns, gpt = BM / ns, nq = ns >> 2;          // host: ns a power of two, 4 <= ns <= 128
+    for (int item = t; item < gpt * CH * 4; item += TG_T) {       // TG_T and the bound are multiples of 4: a quad stays together
+        const int q = item & 3, gc = item >> 2;
+        const int gi = gc / CH, ch = gc - gi * CH;
+        const long long g = row0 / ns + gi;
+        const int n = col0 + ch * 8;
+        float mx[8], mn[8];
+        unsigned ix[8], in_[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; mn[e] = INFINITY; ix[e] = in_[e] = 0u; }
+        const unsigned char *p = tile + (size_t)(gi * ns + q * nq) * YP + ch * 16;
+        for (int s_ = 0; s_ < nq; ++s_) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + (size_t)s_ * YP);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            const unsigned si = (unsigned)(q * nq + s_);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                if (lo > mx[2 * e]) { mx[2 * e] = lo; ix[2 * e] = si; }
+                if (lo < mn[2 * e]) { mn[2 * e] = lo; in_[2 * e] = si; }
+                if (hi > mx[2 * e + 1]) { mx[2 * e + 1] = hi; ix[2 * e + 1] = si; }
+                if (hi < mn[2 * e + 1]) { mn[2 * e + 1] = hi; in_[2 * e + 1] = si; }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float omx = __shfl_xor(mx[e], off, 64), omn = __shfl_xor(mn[e], off, 64);
+                const unsigned oix = __shfl_xor(ix[e], off, 64), oin = __shfl_xor(in_[e], off, 64);
+                if (omx > mx[e] || (omx == mx[e] && oix < ix[e])) { mx[e] = omx; ix[e] = oix; }
+                if (omn < mn[e] || (omn == mn[e] && oin < in_[e])) { mn[e] = omn; in_[e] = oin; }
+            }
+        }
+        if (q != 0 || g * ns >= a.R || n >= a.N) continue;        // (after the shuffles: every lane of the quad took part)
+        uint4 pm, pn;      // the extremes ARE bf16 values: their upper halves
+        pm.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u); pm.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+        pm.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u); pm.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+        pn.x = (__float_as_uint(mn[0]) >> 16) | (__float_as_uint(mn[1]) & 0xffff0000u); pn.y = (__float_as_uint(mn[2]) >> 16) | (__float_as_uint(mn[3]) & 0xffff0000u);
+        pn.z = (__float_as_uint(mn[4]) >> 16) | (__float_as_uint(mn[5]) & 0xffff0000u); pn.w = (__float_as_uint(mn[6]) >> 16) | (__float_as_uint(mn[7]) & 0xffff0000u);
+        const size_t o = (size_t)g * a.N + n;
+        *reinterpret_cast<uint4 *>(a.pl_max + o) = pm;
+        *reinterpret_cast<uint4 *>(a.pl_min + o) = pn;
+        uint2 bi, bn_;
+        bi.x = ix[0] | (ix[1] << 8) | (ix[2] << 16) | (ix[3] << 24); bi.y = ix[4] | (ix[5] << 8) | (ix[6] << 16) | (ix[7] << 24);
+        bn_.x = in_[0] | (in_[1] << 8) | (in_[2] << 16) | (in_[3] << 24); bn_.y = in_[4] | (in_[5] << 8) | (in_[6] << 16) | (in_[7] << 24);
+        *reinterpret_cast<uint2 *>(a.pl_imax + o) = bi;
+        *reinterpret_cast<uint2 *>(a.pl_imin + o) = bn_;
+    }
+}
+
 // Tile shapes (4 waves, each 64 rows x JT * 32 columns): WN x JT = 2 x 2 -> 128 rows x 128 columns (wide layers),
 // 1 x 2 -> 256 x 64, 1 x 1 -> 256 x 32 (the narrow first SA levels: no MFMA work and no LDS traffic on absent columns,
 // twice the rows per workgroup behind one latency chain).
@@ -187,7 +251,7 @@ __device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + (
 // The product is formed TRANSPOSED (D = W_tile . X_tile^T): a lane then owns one output ROW and, per 4 accumulator
 // registers, 4 CONSECUTIVE channels — 8 bytes of bf16, one ds_write_b64 — where the direct form had 16 scattered 2-byte LDS
 // writes per 32 x 32 tile (the epilogue's LDS writes alone were 1.7x the HBM time of a narrow tile).
-template <int WN, int JT, int XF, bool BS = false>
+template <int WN, int JT, int XF, bool BS = false, bool PL = false>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
     constexpr int XB = BM * 128, WB = BN * 128;                  // bytes of the X / W stage (64 k x 2 B rows)
@@ -366,6 +430,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
                 }
         }
         __syncthreads();
+        if constexpr (PL) tg_pool_tile<BM, CH, YP>(a, smem, row0, col0, t);
         uint4 bx[BS ? BM / RPP : 1];
         if constexpr (BS) {   // the BatchNorm's inputs under this thread's output chunks, all requested at once (the accumulators are dead)
             const int n = col0 + chunk_o * 8;
@@ -430,7 +495,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_kernel(TgNtArgs a, int slots) {
 // 172 -> 152 us).  The narrow tiles keep the loop above: this structure runs them 15-20 % slower (measured).
 // (no BS form: with the gradient statistics' sixteen sums this structure spills ~100 registers; wide products with statistics
 // take tg_nt_kernel<2, 2, 0, true>)
-template <int XF>
+template <int XF, bool PL = false>
 __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slots) {
     constexpr int WN = 2, JT = 2;
     constexpr int BM = (4 / WN) * 64, BN = WN * JT * 32;
@@ -625,6 +690,7 @@ __global__ __launch_bounds__(TG_T, 2) void tg_nt_deep_kernel(TgNtArgs a, int slo
                     }
             }
             __syncthreads();
+            if constexpr (PL) tg_pool_tile<BM, CH, YP>(a, smem, row0, col0, t);
 #pragma unroll
             for (int i = 0; i < BM / RPP; ++i) {
                 const int row = t / CH + RPP * i;
@@ -1023,9 +1089,11 @@ extern "C" int pdm_tg_stats_parts(long long rows, int N) { return rows <= 0 || N
 // x_bn_coef: null, or (4, K) fp32 [mean | invstd | gamma invstd | beta] (pdm_bn_finalize_stats): X holds the PRE-BatchNorm
 // outputs of the layer before and is read through bf16(relu((x - mean) scale + beta)) — that layer's BatchNorm + ReLU without a
 // pass (and a tensor) of its own.
+struct TgPool { int ns; void *xmax, *xmin; unsigned char *imax, *imin; };
+
 static int tg_gemm_nt_impl(const char *who, void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
                            void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef, const void *Bx, long long ldbx,
-                           const float *bcoef, float *bstats) {
+                           const float *bcoef, float *bstats, const TgPool *pool = nullptr) {
     PDM_REQUIRE(R >= 0 && K >= 0 && N >= 0, PDM_E_BADARG, "%s: negative size", who);
     if (R == 0 || N == 0) return 0;
     PDM_REQUIRE(X && W && Y, PDM_E_BADARG, "%s: null pointer", who);
@@ -1045,6 +1113,26 @@ static int tg_gemm_nt_impl(const char *who, void *stream, long long R, int K, in
     a.X = static_cast<const unsigned short *>(X); a.ldx = ldx; a.W = static_cast<const unsigned short *>(W); a.ldw = ldw;
     a.Y = static_cast<unsigned short *>(Y); a.ldy = ldy; a.bias = bias; a.stats = stats; a.xf = x_bn_coef; a.R = R; a.K = K; a.N = N;
     a.Bx = static_cast<const unsigned short *>(Bx); a.ldbx = ldbx; a.bcf = bcoef; a.bstats = bstats;
+    if (pool) {
+        PDM_REQUIRE(!bs && pool->ns >= 4 && pool->ns <= 128 && (pool->ns & (pool->ns - 1)) == 0 && R % pool->ns == 0, PDM_E_BADARG,
+                    "%s: pooled groups of ns=%d rows (a power of two, 4 .. 128, dividing R=%lld)", who, pool->ns, R);
+        PDM_REQUIRE(pool->xmax && pool->xmin && pool->imax && pool->imin && tg_al16(pool->xmax) && tg_al16(pool->xmin) &&
+                    (reinterpret_cast<uintptr_t>(pool->imax) & 7u) == 0 && (reinterpret_cast<uintptr_t>(pool->imin) & 7u) == 0, PDM_E_BADARG,
+                    "%s: null or misaligned pool outputs", who);
+        a.pl_ns = pool->ns; a.pl_max = static_cast<unsigned short *>(pool->xmax); a.pl_min = static_cast<unsigned short *>(pool->xmin);
+        a.pl_imax = pool->imax; a.pl_imin = pool->imin;
+#define TG_NT_PL(WN, JT)                                                                                                              \
+        do {                                                                                                                          \
+            if (x_bn_coef) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 1, false, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);  \
+            else hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 0, false, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);   \
+        } while (0)
+        if (bn == 32) TG_NT_PL(1, 1);
+        else if (bn == 64) TG_NT_PL(1, 2);
+        else if (x_bn_coef) hipLaunchKernelGGL((tg_nt_deep_kernel<1, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+        else hipLaunchKernelGGL((tg_nt_deep_kernel<0, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);
+#undef TG_NT_PL
+        return check_launch(who);
+    }
 #define TG_NT(WN, JT)                                                                                                        \
     do {                                                                                                                     \
         if (bs) hipLaunchKernelGGL((tg_nt_kernel<WN, JT, 0, true>), dim3(wgs), dim3(TG_T), 0, as_stream(stream), a, slots);   \
@@ -1081,6 +1169,18 @@ extern "C" int pdm_tg_gemm_nt_bs(void *stream, long long R, int K, int N, const 
 // is formed while the operand is staged and written to dYout (R, K) on the way (the weight gradient of the layer reads it from
 // there): the values of pdm_bn_relu_backward's dx bit for bit, without that operator's pass over dZ and Yp and without this
 // contraction's own read of dY.  Everything else as pdm_tg_gemm_nt (no bias, no statistics).
+// pdm_tg_gemm_nt whose product is the input of the SA scales' tail, BatchNorm + ReLU + max over the ns neighbours of a group (rows
+// g ns .. g ns + ns - 1 = group g; pointnet2_modules.py:46-52): besides Y and the BatchNorm column sums (`stats`), the epilogue leaves
+// every group's max / min of the rounded outputs per channel and the first index attaining them — xmax, xmin (R / ns, N) bf16,
+// imax, imin (R / ns, N) bytes, exactly what pdm_bn_relu_pool_forward's statistics pass computes from a second read of Y
+// (pdm_bn_relu_pool_forward_kept finishes the operator from them).  ns a power of two, 4 .. 128, dividing R.
+extern "C" int pdm_tg_gemm_nt_pool(void *stream, long long R, int K, int N, const void *X, long long ldx, const void *W, long long ldw,
+                                   void *Y, long long ldy, const float *bias, float *stats, const float *x_bn_coef, int ns, void *xmax,
+                                   void *xmin, unsigned char *imax, unsigned char *imin) {
+    const TgPool pool{ns, xmax, xmin, imax, imin};
+    return tg_gemm_nt_impl("tg_gemm_nt_pool", stream, R, K, N, X, ldx, W, ldw, Y, ldy, bias, stats, x_bn_coef, nullptr, 0, nullptr, nullptr, &pool);
+}
+
 static int tg_dy_slots(long long R, int N) {
     const int bn = N <= 64 ? 64 : 128, bm = 128;
     const long long row_tiles = (R + bm - 1) / bm;

@@ -113,21 +113,29 @@ class _BnReluPool(Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, stats=None, keep=None, idx=None):
         B, C, M, ns = x.shape
         G = B * M
         dtype = 1 if x.dtype == torch.bfloat16 else 0
         dev = x.device
         y = torch.empty((B, M, 1, C), dtype=x.dtype, device=dev)
-        keep = torch.empty((2, G, C), dtype=x.dtype, device=dev)
-        idx = torch.empty((2, G, C), dtype=torch.uint8, device=dev)
         coef = torch.empty((4, C), dtype=torch.float32, device=dev)
         parts = _native.lib().pdm_bn_pool_parts(dtype, G, C)
-        partial = torch.empty((parts, C, 2), dtype=torch.float32, device=dev)
-        _native.call("pdm_bn_relu_pool_forward", torch.cuda.current_stream(dev).cuda_stream, dtype, G, ns, C, x.data_ptr(), y.data_ptr(),
-                     keep[0].data_ptr(), keep[1].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), weight.data_ptr(), bias.data_ptr(),
-                     float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(),
-                     partial.data_ptr(), 1)
+        if stats is not None:
+            # the contraction that produced x left the column sums AND every group's extremes in its epilogue (pdm_tg_gemm_nt_pool):
+            # no statistics pass over x (POOL_IN_GEMM)
+            assert dtype == 1 and keep.shape == (2, G, C) and idx.shape == (2, G, C) and stats.shape[1:] == (C, 2)
+            _native.call("pdm_bn_relu_pool_forward_kept", torch.cuda.current_stream(dev).cuda_stream, 1, G, ns, C, y.data_ptr(), keep[0].data_ptr(),
+                         keep[1].data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), float(momentum), running_mean.data_ptr(),
+                         running_var.data_ptr(), coef.data_ptr(), stats.data_ptr(), stats.shape[0], 1)
+        else:
+            keep = torch.empty((2, G, C), dtype=x.dtype, device=dev)
+            idx = torch.empty((2, G, C), dtype=torch.uint8, device=dev)
+            partial = torch.empty((parts, C, 2), dtype=torch.float32, device=dev)
+            _native.call("pdm_bn_relu_pool_forward", torch.cuda.current_stream(dev).cuda_stream, dtype, G, ns, C, x.data_ptr(), y.data_ptr(),
+                         keep[0].data_ptr(), keep[1].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                         float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(),
+                         partial.data_ptr(), 1)
         ctx.save_for_backward(x, keep, idx, coef)
         ctx.meta = (dtype, G, ns, C, parts)
         return y.permute(0, 3, 1, 2)
@@ -144,7 +152,15 @@ class _BnReluPool(Function):
         _native.call("pdm_bn_relu_pool_backward", torch.cuda.current_stream(x.device).cuda_stream, dtype, G, ns, C, x.data_ptr(),
                      dyp.data_ptr(), dx.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(),
                      coef.data_ptr(), grads.data_ptr(), partial.data_ptr(), 1)
-        return dx, grads[0], grads[1], None, None, None, None
+        return dx, grads[0], grads[1], None, None, None, None, None, None, None
+
+
+# 1: the last contraction of an SA scale leaves the pooled operator's statistics (column sums, group extremes + indices) in its
+# epilogue (pdm_tg_gemm_nt_pool): the operator's own pass over the (B M ns, C) tensor disappears.  Built, exact, measured and NOT
+# faster: 18.77-18.81 ms per step against 18.53-18.62 (A/B twice on one box) — the epilogue's compare / select work per element does
+# not overlap the tile's memory traffic at two workgroups per CU, and costs the eight widest-row contractions more than the 0.4 ms
+# pass it removes (with one thread per (group, chunk) instead of a quad: 18.88).  Off by default.
+POOL_IN_GEMM = os.environ.get("PDM_POOL_IN_GEMM", "0") == "1"
 
 
 def pool_applies(x, bn):
@@ -281,7 +297,7 @@ class _RowsGemm(Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, want_stats, keep_pad=False, link=None):
+    def forward(ctx, x, weight, bias, want_stats, keep_pad=False, link=None, pool_ns=0):
         from . import train_gemm as tg
         ctx.link = link
         ctx.set_materialize_grads(False)     # no zero tensor (a fill launch per node and step) for the statistics output's gradient
@@ -297,7 +313,10 @@ class _RowsGemm(Function):
         wb, wt = tg.pack_weight_pair(w2, Np, K)              # forward weights and their transpose (data gradient): one launch
         if bias is not None and Np != N:
             bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
-        y, stats = tg.gemm_nt(xr, wb, bias=bias, stats=True) if want_stats else (tg.gemm_nt(xr, wb, bias=bias), None)
+        if pool_ns and want_stats and link is not None:
+            y, stats, link['pool'] = tg.gemm_nt(xr, wb, bias=bias, stats=True, pool_ns=pool_ns)     # (keeps travel beside the autograd graph)
+        else:
+            y, stats = tg.gemm_nt(xr, wb, bias=bias, stats=True) if want_stats else (tg.gemm_nt(xr, wb, bias=bias), None)
         ctx.save_for_backward(xr, weight, wt)
         ctx.geom = (tuple(x.shape), x.dim(), N, Np, K, Kw, bias is not None, x.dtype)
         # keep_pad: the caller (a BatchNorm over the padded width follows) takes all round8(N) channels, the extra ones zero
@@ -311,7 +330,7 @@ class _RowsGemm(Function):
     def backward(ctx, dy, _dstats=None):
         from . import train_gemm as tg
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         xr, weight, wt = ctx.saved_tensors
         xshape, xdim, N, Np, K, Kw, has_bias, xdtype = ctx.geom
         R = xr.shape[0]
@@ -335,7 +354,7 @@ class _RowsGemm(Function):
         db = None
         if has_bias:   # column sums of the gradient rows (torch's strided reduction over 8 of them took 0.28 ms at 524288 rows)
             db = tg.colsum(dyr)[:N] if Np <= 512 else dyr[:, :N].sum(0, dtype=torch.float32)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _BnReluRowsGemm(Function):
@@ -349,7 +368,7 @@ class _BnReluRowsGemm(Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, stats, gamma, beta, running_mean, running_var, eps, momentum, weight, bias, want_stats, keep_pad,
-                in_link=None, out_link=None):
+                in_link=None, out_link=None, pool_ns=0):
         from . import train_gemm as tg
         ctx.in_link, ctx.link = in_link, out_link
         ctx.set_materialize_grads(False)
@@ -366,7 +385,9 @@ class _BnReluRowsGemm(Function):
         wb, wt = tg.pack_weight_pair(w2, Np, K)
         if bias is not None and Np != N:
             bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
-        if want_stats:
+        if pool_ns and want_stats and out_link is not None:
+            y, st, out_link['pool'] = tg.gemm_nt(xr, wb, bias=bias, stats=True, x_bn_coef=coef, pool_ns=pool_ns)
+        elif want_stats:
             y, st = tg.gemm_nt(xr, wb, bias=bias, stats=True, x_bn_coef=coef)
         else:
             y, st = tg.gemm_nt(xr, wb, bias=bias, x_bn_coef=coef), None
@@ -382,7 +403,7 @@ class _BnReluRowsGemm(Function):
     def backward(ctx, dy, _dstats=None):
         from . import train_gemm as tg
         if dy is None:
-            return (None,) * 14
+            return (None,) * 15
         xr, coef, weight, wt = ctx.saved_tensors
         xshape, xdim, N, Np, K, Kw, has_bias = ctx.geom
         R = xr.shape[0]
@@ -421,7 +442,7 @@ class _BnReluRowsGemm(Function):
             _native.call("pdm_bn_relu_backward_apply", stream, 1, 0, R, K, 1, xr.data_ptr(), da.data_ptr(), dx.data_ptr(), coef.data_ptr(),
                          grads.data_ptr(), 1)
         return (_rows_to_layout(dx, None, K, xshape, xdim), None, grads[0], grads[1], None, None, None, None, dw, db, None, None,
-                None, None)
+                None, None, None)
 
 
 _identity_coef = {}
@@ -525,7 +546,7 @@ def relu_rows_linear(x, layer, want_stats=False, keep_pad=False, in_link=None, o
     return _ReluRowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad), in_link, out_link)
 
 
-def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_link=None, out_link=None):
+def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_link=None, out_link=None, pool_ns=0):
     """layer(relu(bn(x))) through _BnReluRowsGemm, or (None, None) when the form does not apply (the caller then runs the
     BatchNorm operator and the layer one after the other)."""
     from . import train_gemm as tg
@@ -549,7 +570,7 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_lin
         z = bn.weight.new_zeros(K - C)
         gamma, beta, rm, rv = torch.cat([gamma, z]), torch.cat([beta, z]), torch.cat([rm, z]), torch.cat([rv, z + 1.0])
     out = _BnReluRowsGemm.apply(x, stats, gamma, beta, rm, rv, bn.eps, bn.momentum, layer.weight, layer.bias, bool(want_stats), bool(keep_pad),
-                                in_link, out_link)
+                                in_link, out_link, int(pool_ns))
     with torch.no_grad():
         if K != C:
             bn.running_mean.copy_(rm[:C]); bn.running_var.copy_(rv[:C])
@@ -575,7 +596,7 @@ def _rows_to_layout(rows, like, channels, shape=None, dim=None):
     return rows.view(*lead, rows.shape[1])[..., :channels].movedim(-1, 1)
 
 
-def rows_linear(x, layer, want_stats=False, keep_pad=False, link=None):
+def rows_linear(x, layer, want_stats=False, keep_pad=False, link=None, pool_ns=0):
     """layer(x) for a 1x1 convolution / Linear through _RowsGemm when x is (castable to) bf16 rows on the GPU under bf16
     autocast; returns (y, stats) — stats None when not requested or not taken; (None, None) when the form does not apply.
     keep_pad: y keeps round8(out_channels) channels (the extra ones zero) for a BatchNorm over the padded width."""
@@ -593,7 +614,7 @@ def rows_linear(x, layer, want_stats=False, keep_pad=False, link=None):
     K = x.shape[1]
     if x.dtype not in (torch.bfloat16, torch.float32) or K != _round8(kin) or tg.row_view(x) is None:
         return None, None
-    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad), link)
+    return _RowsGemm.apply(x, layer.weight, layer.bias, bool(want_stats), bool(keep_pad), link, int(pool_ns))
 
 
 ROWS_GEMM = os.environ.get("PDM_ROWS_GEMM", "1") != "0"   # 0: the round-2 path (vendor GEMMs) for A/B measurements
@@ -750,11 +771,18 @@ class TrainSequential(nn.Sequential):
         mods = list(self)
         if (ENABLED and self.training and x.is_cuda and len(mods) >= 3 and isinstance(mods[-1], nn.ReLU)
                 and isinstance(mods[-2], _BN) and mods[-2].weight.dim() == 1):
-            h = self._run(x, mods[:-2])
+            ns = x.shape[3] if x.dim() == 4 else 0
             bn = mods[-2]
+            # the last contraction may leave the pooled operator's statistics in its epilogue: groups of ns consecutive rows
+            tail = {'pool_ns': ns} if (POOL_IN_GEMM and 4 <= ns <= 128 and ns & (ns - 1) == 0 and bn.num_features % 8 == 0) else None
+            h = self._run(x, mods[:-2], tail)
             if pool_applies(h, bn):
                 with torch.no_grad():
                     _bump(bn)
+                keeps = tail['link'].get('pool') if tail is not None and tail.get('link') is not None else None
+                if keeps is not None and tail.get('stats') is not None and h.dtype == torch.bfloat16:
+                    return _BnReluPool.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, tail['stats'],
+                                             keeps[0], keeps[1])
                 return _BnReluPool.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
             h = self._run(h, mods[-2:])
         else:
@@ -767,12 +795,12 @@ class TrainSequential(nn.Sequential):
         return self._run(x, list(self))
 
     @staticmethod
-    def _run(x, mods):
+    def _run(x, mods, tail=None):
         if _bump_later and _bump_later[-1] is not None:      # inside a counter_scope (or an outer stack): that one collects
-            return TrainSequential._run_stack(x, mods)
+            return TrainSequential._run_stack(x, mods, tail)
         _bump_later.append([])
         try:
-            return TrainSequential._run_stack(x, mods)
+            return TrainSequential._run_stack(x, mods, tail)
         finally:
             counters = _bump_later.pop()
             if counters:
@@ -780,7 +808,10 @@ class TrainSequential(nn.Sequential):
                     torch._foreach_add_(counters, 1)
 
     @staticmethod
-    def _run_stack(x, mods):
+    def _run_stack(x, mods, tail=None):
+        """tail: None, or a dict {'pool_ns': ns} of forward_max_pooled — the LAST contraction of `mods` is asked for the pooled operator's
+        statistics (rows_linear / bn_rows_linear with pool_ns), and the stack's final (stats, link) are handed back in it."""
+        pool_ns = tail['pool_ns'] if tail is not None else 0
         i = 0
         stats = None      # column sums of x taken by the GEMM that produced it, for the BatchNorm right behind it
         link = None       # shared with the autograd node that produced x (a rows GEMM): see _take_lazy_bn_backward
@@ -793,7 +824,8 @@ class TrainSequential(nn.Sequential):
                     # Conv -> BN -> ReLU -> Conv: the BatchNorm + ReLU ride in the second contraction's load path
                     want, pad = _stats_wanted(mods, i + 2)
                     out_link = {}
-                    y, st = bn_rows_linear(x, stats, m, nxt, want, pad, link, out_link)
+                    last = i + 3 == len(mods)
+                    y, st = bn_rows_linear(x, stats, m, nxt, want or (last and pool_ns > 0), pad, link, out_link, pool_ns if last else 0)
                     if y is not None:
                         x, stats, link = y, st, out_link
                         i += 3
@@ -821,7 +853,8 @@ class TrainSequential(nn.Sequential):
             if isinstance(m, nn.Linear) or type(m) in (nn.Conv1d, nn.Conv2d):
                 want, pad = _stats_wanted(mods, i)
                 new_link = {}
-                y, st = rows_linear(x, m, want, pad, new_link)
+                last = i + 1 == len(mods)
+                y, st = rows_linear(x, m, want or (last and pool_ns > 0), pad, new_link, pool_ns if last else 0)
                 if y is not None:
                     x, stats, link = y, st, new_link
                 else:
@@ -833,4 +866,6 @@ class TrainSequential(nn.Sequential):
             else:
                 x = m(x)
                 i += 1
+        if tail is not None:
+            tail['stats'], tail['link'] = stats, link
         return x

@@ -195,7 +195,7 @@ def bn_bwd_finalize(rows, coef, partial):
     return grads
 
 
-def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None):
+def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None, pool_ns=0):
     """x (R, K) bf16 rows (row stride a multiple of 8), w (N, K') bf16 with K' >= K zero padded -> y (R, N) bf16 =
     x . w^T [+ bias], fp32 accumulation, one rounding.  stats=True also returns the column sums (parts, N, 2) fp32 (sum y,
     sum y^2 of the rounded y, one part per persistent workgroup slot): what pdm_bn_relu_forward_stats takes.
@@ -207,6 +207,17 @@ def gemm_nt(x, w, bias=None, stats=False, out=None, x_bn_coef=None):
     st = None
     if stats:
         st = torch.empty((_native.lib().pdm_tg_stats_parts(R, N), N, 2), dtype=torch.float32, device=x.device)
+    if pool_ns:
+        # the product feeds BatchNorm + ReLU + max over groups of pool_ns consecutive rows: the epilogue also leaves each group's max / min
+        # per channel and the first index attaining them (pdm_tg_gemm_nt_pool); returns (y, stats, (keep (2, G, N) bf16, idx (2, G, N) uint8))
+        assert stats and R % pool_ns == 0
+        G = R // pool_ns
+        keep = torch.empty((2, G, N), dtype=torch.bfloat16, device=x.device)
+        idx = torch.empty((2, G, N), dtype=torch.uint8, device=x.device)
+        _native.call("pdm_tg_gemm_nt_pool", _stream(x), R, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
+                     0 if bias is None else bias.data_ptr(), st.data_ptr(), 0 if x_bn_coef is None else x_bn_coef.data_ptr(), pool_ns,
+                     keep[0].data_ptr(), keep[1].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr())
+        return y, st, (keep, idx)
     _native.call("pdm_tg_gemm_nt", _stream(x), R, K, N, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0),
                  0 if bias is None else bias.data_ptr(), 0 if st is None else st.data_ptr(),
                  0 if x_bn_coef is None else x_bn_coef.data_ptr())

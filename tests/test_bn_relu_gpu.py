@@ -382,3 +382,45 @@ def test_training_over_several_optimizer_steps_is_the_same_with_and_without_the_
             tg.PACK_CACHE = default
     assert default and runs[0] == runs[1], runs
     assert runs[0][-1] < runs[0][0] and len(set(runs[0])) == 6, runs[0]     # and it does train (every step sees new weights)
+
+
+@pytest.mark.parametrize("widths,ns", [((8, 16, 32), 16), ((16, 32, 64), 32), ((72, 128, 128), 16), ((24, 200, 256), 32)])
+@pytest.mark.gpu
+def test_pooled_tail_with_its_statistics_from_the_last_contraction(dev, widths, ns):
+    """forward_max_pooled of an SA-like stack under bf16 autocast: with the pooled operator's statistics (column sums, group extremes
+    and their indices) taken in the last contraction's epilogue (fused_bn.POOL_IN_GEMM, pdm_tg_gemm_nt_pool) against the operator's own
+    pass over the tensor: the same pooled elements are selected; outputs and gradients agree to the order of the fp32 sums behind
+    mean / variance (plain sums of the epilogue against pivoted sums of the pass: one bf16 rounding of the output)."""
+    import copy
+    from pdm_ssd_amd import fused_bn
+    torch.manual_seed(17)
+    c0, c1, c2 = widths
+    net = fused_bn.TrainSequential(torch.nn.Conv2d(c0, c1, 1, bias=False), torch.nn.BatchNorm2d(c1), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(c1, c2, 1, bias=False), torch.nn.BatchNorm2d(c2), torch.nn.ReLU()).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
+    x0 = torch.randn(3, c0, 40, ns, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    default = fused_bn.POOL_IN_GEMM          # (opt-in: measured no faster, fused_bn.py)
+    for flag in (True, False):
+        fused_bn.POOL_IN_GEMM = flag
+        try:
+            m = copy.deepcopy(net)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m.forward_max_pooled(x)
+                loss = (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum()
+            loss.backward()
+            res.append((y.detach().float().clone(), x.grad.float().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: b.clone() for k, b in m.named_buffers()}))
+        finally:
+            fused_bn.POOL_IN_GEMM = default
+    (ya, ga, pa, ba), (yb, gb, pb, bb) = res
+    assert ya.shape == (3, c2, 40, 1)
+    assert float((ya - yb).abs().max()) <= 2.0 ** -7 * float(yb.abs().max())
+    assert float((ga - gb).abs().max()) <= 2.0 ** -5 * float(gb.abs().max())
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 5e-3 * float(pb[k].abs().max()) + 1e-6, k
+    for k in ba:
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-4, atol=1e-5), k

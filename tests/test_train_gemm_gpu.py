@@ -238,3 +238,23 @@ def test_packed_weight_pairs_are_cached_and_refreshed_together(dev):
         params[1].neg_()
     for (a, b), (c, d) in zip(pairs(), fresh()):
         assert torch.equal(a, c) and torch.equal(b, d)
+
+
+@pytest.mark.parametrize("R,K,N,ns", [(4096, 64, 32, 16), (2048, 32, 64, 32), (4096, 96, 128, 16), (1024, 200, 256, 32), (512, 264, 512, 64),
+                                      (6400, 16, 24, 128), (48, 8, 8, 16)])
+def test_gemm_nt_leaves_the_pooled_operators_group_extremes(dev, R, K, N, ns):
+    """pdm_tg_gemm_nt_pool: the product and its column sums are those of pdm_tg_gemm_nt; per group of ns consecutive rows and channel the
+    epilogue leaves max / min of the rounded outputs and the FIRST index attaining each (ties: small integers make many) — all three
+    tile shapes, a last row tile that is not full."""
+    x = ints((R, K), -2, 2, 41, dev).bfloat16()
+    w = tg.pack_weight(ints((N, K), -1, 1, 42, dev))
+    y0, st0 = tg.gemm_nt(x, w, stats=True)
+    y, st, (keep, idx) = tg.gemm_nt(x, w, stats=True, pool_ns=ns)
+    assert torch.equal(y, y0) and torch.equal(st, st0)
+    g = y.float().view(R // ns, ns, N)
+    mx, imx = g.max(1)
+    mn, imn = g.min(1)
+    assert torch.equal(keep[0].float(), mx) and torch.equal(keep[1].float(), mn)
+    first_max = (g == mx[:, None, :]).float().argmax(1)       # first index attaining the extreme
+    first_min = (g == mn[:, None, :]).float().argmax(1)
+    assert torch.equal(idx[0].long(), first_max) and torch.equal(idx[1].long(), first_min)
