@@ -436,6 +436,10 @@ int pdm_bn_relu_forward(void *stream, int dtype, int layout, long long n, int C,
 int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, int C, const void *x, void *y, const float *gamma,
                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                               float *coef, const float *partial, int parts, int relu);
+/* statistics only (rows x C; dtype 0 / 1): reduce + finalize -> coef (4, C) and the running statistics, no normalised tensor (a
+ * consumer applies BatchNorm + ReLU while it reads x); partial: pdm_bn_parts(0, n, C, 1) * C * 2 floats */
+int pdm_bn_forward_coef(void *stream, int dtype, long long n, int C, const void *x, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, float *coef, float *partial);
 /* finalize only: coef (4, C) from the producer's sums + running statistics (the consumer normalises while it reads x) */
 int pdm_bn_finalize_stats(void *stream, long long n, int C, const float *gamma, const float *beta, float eps, float momentum,
                           float *running_mean, float *running_var, float *coef, const float *partial, int parts);

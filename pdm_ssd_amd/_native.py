@@ -118,6 +118,7 @@ _SIGNATURES = {
                             _i, _vp, _vp, _vp, _vp],
     "pdm_bn_relu_pool_forward_kept": [_i, ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i],
     "pdm_tg_wgrad": [ctypes.c_longlong, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _i, _vp, ctypes.c_size_t, _vp],
+    "pdm_bn_forward_coef": [_i, ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp],
     "pdm_bn_finalize_stats": [ctypes.c_longlong, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i],
     "pdm_tg_colsum": [ctypes.c_longlong, _i, _vp, ctypes.c_longlong, _vp, _vp],
     "pdm_tg_pack_weight": [_i, _i, _vp, _vp, _i, _vp, _i],

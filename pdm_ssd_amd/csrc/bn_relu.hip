@@ -573,6 +573,24 @@ extern "C" int pdm_bn_relu_forward_stats(void *stream, int dtype, long long n, i
     return check_launch("bn_relu_forward_stats");
 }
 
+// The statistics half of pdm_bn_relu_forward on its own (rows x C): reduce + finalize -> coef (4, C), running statistics updated, and NO
+// normalised tensor — for a consumer that applies BatchNorm + ReLU while it reads x (pdm_tg_gemm_nt / pdm_tg_wgrad with x_bn_coef) when
+// x does not come from a contraction that could have taken the sums itself.  partial: pdm_bn_parts(0, n, C, 1) * C * 2 floats.
+extern "C" int pdm_bn_forward_coef(void *stream, int dtype, long long n, int C, const void *x, const float *gamma, const float *beta, float eps,
+                                   float momentum, float *running_mean, float *running_var, float *coef, float *partial) {
+    if (int rc = bn_check("bn_forward_coef", dtype == 2 ? 0 : dtype, 0, n, C, 1, x, x)) return rc;
+    PDM_REQUIRE(dtype == 0 || dtype == 1, PDM_E_BADARG, "bn_forward_coef: dtype %d (0 = fp32, 1 = bf16)", dtype);
+    PDM_REQUIRE(coef && partial && n >= 1, PDM_E_BADARG, "bn_forward_coef: null workspace or no rows");
+    const int parts = pdm_bn_parts(0, n, C, 1);
+    BnCoef none{};
+    none.pivot = coef + 3 * (size_t)C;   // parked in the shift row until the finalize kernel replaces it
+    if (dtype == 1) hipLaunchKernelGGL((bn_cl_reduce_kernel<bf16_t, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const bf16_t *)x, (const bf16_t *)nullptr, n, C, none, 1, partial);
+    else hipLaunchKernelGGL((bn_cl_reduce_kernel<float, 0>), dim3(parts), dim3(256), 0, as_stream(stream), (const float *)x, (const float *)nullptr, n, C, none, 1, partial);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, parts, C, (double)n, gamma, beta, eps, momentum,
+                       running_mean, running_var, coef);
+    return check_launch("bn_forward_coef");
+}
+
 // Only the finalize step of the above: coef (4, C) from the producer's sums, running statistics updated.  For a consumer that
 // applies the normalisation itself while reading x (pdm_tg_gemm_nt / pdm_tg_wgrad with x_bn_coef).
 extern "C" int pdm_bn_finalize_stats(void *stream, long long n, int C, const float *gamma, const float *beta, float eps, float momentum,

@@ -377,11 +377,20 @@ class _BnReluRowsGemm(Function):
         N = weight.shape[0]
         w2 = weight.reshape(N, -1)
         Kw, Np = w2.shape[1], _round8(N)
-        assert xr.dtype == torch.bfloat16 and Kw <= K < Kw + 8 and K % 8 == 0 and stats.shape[1:] == (K, 2)
+        assert xr.dtype == torch.bfloat16 and Kw <= K < Kw + 8 and K % 8 == 0 and (stats is None or stats.shape[1:] == (K, 2))
         coef = torch.empty((4, K), dtype=torch.float32, device=x.device)
-        _native.call("pdm_bn_finalize_stats", torch.cuda.current_stream(x.device).cuda_stream, R, K, gamma.data_ptr(), beta.data_ptr(),
-                     float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(), stats.data_ptr(),
-                     stats.shape[0])
+        if stats is None:
+            # x does not come from a contraction (the heat-map head's depthwise output): the statistics pass of the operator on its own,
+            # then BatchNorm + ReLU ride in this contraction's load path like anywhere else — no normalised tensor
+            assert xr.stride(0) == K
+            scratch = torch.empty((_native.lib().pdm_bn_parts(0, R, K, 1), K, 2), dtype=torch.float32, device=x.device)
+            _native.call("pdm_bn_forward_coef", torch.cuda.current_stream(x.device).cuda_stream, 1, R, K, xr.data_ptr(), gamma.data_ptr(),
+                         beta.data_ptr(), float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(),
+                         scratch.data_ptr())
+        else:
+            _native.call("pdm_bn_finalize_stats", torch.cuda.current_stream(x.device).cuda_stream, R, K, gamma.data_ptr(), beta.data_ptr(),
+                         float(eps), float(momentum), running_mean.data_ptr(), running_var.data_ptr(), coef.data_ptr(), stats.data_ptr(),
+                         stats.shape[0])
         wb, wt = tg.pack_weight_pair(w2, Np, K)
         if bias is not None and Np != N:
             bias = torch.cat([bias.detach().float(), bias.new_zeros(Np - N, dtype=torch.float32)])
@@ -550,8 +559,10 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_lin
     """layer(relu(bn(x))) through _BnReluRowsGemm, or (None, None) when the form does not apply (the caller then runs the
     BatchNorm operator and the layer one after the other)."""
     from . import train_gemm as tg
-    if not (ENABLED and ROWS_GEMM and BN_IN_GEMM and x.is_cuda and x.shape[1] <= 512 and _bf16_autocast() and layer.weight.dtype == torch.float32 and stats is not None
+    if not (ENABLED and ROWS_GEMM and BN_IN_GEMM and x.is_cuda and x.shape[1] <= 512 and _bf16_autocast() and layer.weight.dtype == torch.float32
             and x.dtype == torch.bfloat16 and x.dim() in (2, 3, 4) and (applies(x, bn) or _padded_applies(x, bn))):
+        return None, None
+    if stats is None and (not BN_FROM_X or x.shape[1] != bn.num_features):     # (no statistics from a producer: see BN_FROM_X)
         return None, None
     if isinstance(layer, nn.Linear):
         kin = layer.in_features
@@ -563,7 +574,8 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_lin
         kin = layer.in_channels
     C, K = bn.num_features, x.shape[1]
     xr = tg.row_view(x)
-    if kin != C or K != _round8(C) or xr is None or xr.stride(0) != K or stats.shape[1] != K or _layout(x) is None or _layout(x)[0] != 0:
+    if kin != C or K != _round8(C) or xr is None or xr.stride(0) != K or (stats is not None and stats.shape[1] != K) or _layout(x) is None \
+            or _layout(x)[0] != 0:
         return None, None
     gamma, beta, rm, rv = bn.weight, bn.bias, bn.running_mean, bn.running_var
     if K != C:   # zero-padded width: zero gamma / beta on the padding (it stays zero), temporary running statistics
@@ -577,6 +589,12 @@ def bn_rows_linear(x, stats, bn, layer, want_stats=False, keep_pad=False, in_lin
         _bump(bn)
     return out
 
+
+# 1 (default): a BatchNorm + ReLU whose bf16 input does NOT come from a rows contraction (the heat-map head's first one, behind the
+# depthwise convolution) still rides in the next contraction's load path: its statistics pass runs alone (pdm_bn_forward_coef), the
+# apply pass and the normalised tensor (288 MB at bs = 32) disappear, and its gradient statistics come out of that contraction's data
+# gradient like everywhere else.
+BN_FROM_X = os.environ.get("PDM_BN_FROM_X", "1") == "1"
 
 # 1 (default): BatchNorm + ReLU of an inner layer ride in the next contraction's load path (_BnReluRowsGemm; bit-identical results,
 # the normalised tensor is never stored).  Measured at bs = 32, A/B twice: 26.17 / 26.24 ms per step with, 26.79 / 26.87
@@ -820,7 +838,8 @@ class TrainSequential(nn.Sequential):
             if isinstance(m, _BN) and (applies(x, m) or _padded_applies(x, m)):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 nxt = mods[i + 2] if relu and i + 2 < len(mods) else None
-                if stats is not None and nxt is not None and (isinstance(nxt, nn.Linear) or type(nxt) in (nn.Conv1d, nn.Conv2d)):
+                if (stats is not None or (BN_FROM_X and x.dtype == torch.bfloat16)) and nxt is not None and \
+                        (isinstance(nxt, nn.Linear) or type(nxt) in (nn.Conv1d, nn.Conv2d)):
                     # Conv -> BN -> ReLU -> Conv: the BatchNorm + ReLU ride in the second contraction's load path
                     want, pad = _stats_wanted(mods, i + 2)
                     out_link = {}

@@ -424,3 +424,47 @@ def test_pooled_tail_with_its_statistics_from_the_last_contraction(dev, widths, 
         assert float((pa[k] - pb[k]).abs().max()) <= 5e-3 * float(pb[k].abs().max()) + 1e-6, k
     for k in ba:
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-4, atol=1e-5), k
+
+
+@pytest.mark.parametrize("widths", [(128, 64, 8), (32, 40, 16)])
+@pytest.mark.gpu
+def test_bn_relu_on_a_tensor_that_no_contraction_produced_rides_in_the_next_contraction(dev, widths):
+    """BN -> ReLU -> Conv -> BN -> ReLU -> Conv on a bf16 channels-last tensor handed in from outside (the heat-map head behind its
+    depthwise convolution): with fused_bn.BN_FROM_X the first BatchNorm's statistics pass runs alone (pdm_bn_forward_coef) and its apply
+    half rides in the contraction's load path — outputs, running statistics and (statistics by the reduce operator on both sides) every
+    gradient BIT-identical to the stand-alone operator; with the gradient statistics from the epilogue (the default) equal to summation
+    order."""
+    import copy
+    from pdm_ssd_amd import fused_bn
+    torch.manual_seed(23)
+    c0, c1, c2 = widths
+    net = fused_bn.TrainSequential(torch.nn.BatchNorm2d(c0), torch.nn.ReLU(), torch.nn.Conv2d(c0, c1, 1, bias=False),
+                                   torch.nn.BatchNorm2d(c1), torch.nn.ReLU(), torch.nn.Conv2d(c1, c2, 1, bias=True)).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(-1.0, 1.5); m.bias.data.normal_(0, 0.3)
+    x0 = (torch.randn(3, c0, 40, 16, device=dev) * 1.3 + 0.2).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = []
+    d_x, d_bs = fused_bn.BN_FROM_X, fused_bn.BWD_STATS_IN_GEMM
+    assert d_x and d_bs
+    for from_x, bs in ((True, False), (False, False), (True, True)):
+        fused_bn.BN_FROM_X, fused_bn.BWD_STATS_IN_GEMM = from_x, bs
+        try:
+            m = copy.deepcopy(net)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+                loss = (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum()
+            loss.backward()
+            res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: b.clone() for k, b in m.named_buffers()}))
+        finally:
+            fused_bn.BN_FROM_X, fused_bn.BWD_STATS_IN_GEMM = d_x, d_bs
+    (ya, ga, pa, ba), (yb, gb, pb, bb), (yc, gc, pc, bc) = res
+    assert torch.equal(ya, yb) and torch.equal(ga, gb) and torch.equal(ya, yc)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+        assert float((pa[k] - pc[k]).abs().max()) <= 2e-3 * float(pa[k].abs().max()) + 1e-6, k
+    for k in ba:
+        assert torch.equal(ba[k], bb[k]) and torch.equal(ba[k], bc[k]), k
+    assert float((ga.float() - gc.float()).abs().max()) <= 2.0 ** -6 * float(ga.float().abs().max())
