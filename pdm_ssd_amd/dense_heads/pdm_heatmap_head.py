@@ -25,6 +25,11 @@ from .point_head_template import _get
 from ..fused_bn import TrainSequential
 
 
+def fused_bn_enabled():
+    from .. import fused_bn
+    return fused_bn.ENABLED
+
+
 class _Depthwise3x3CL(torch.autograd.Function):
     """Depthwise 3x3 convolution (padding 1, no bias) on a channels-last fp32 map, forward and backward on the HIP
     kernels of csrc/bev_head.hip.  MIOpen's depthwise path for this shape (128 channels x 200 x 176 x 32) costs ~170 ms
@@ -214,7 +219,12 @@ class PDMHeatmapHead(nn.Module):
             return data_dict
         if x.dim() == 4 and not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous():
             x = x.contiguous(memory_format=torch.channels_last)   # the neck's grid IS channels-last storage: no copy
-        logits = self.hm(self.shared_conv(x))
+        if self.training and x.is_cuda and fused_bn_enabled():
+            # the two stacks as ONE (hm(shared_conv(x)) is a plain chain): the BatchNorm + ReLU that ends shared_conv then rides in
+            # hm's first contraction like an inner layer's, instead of an apply pass over the 72 M-element map and its two backward passes
+            logits = TrainSequential._run(x, list(self.shared_conv) + list(self.hm))
+        else:
+            logits = self.hm(self.shared_conv(x))
         self.forward_ret_dict['hm_logits'] = logits
         if self.training:
             self.forward_ret_dict['heatmap'] = self.assign_targets(data_dict['gt_boxes'], logits.shape[2:])
