@@ -431,7 +431,10 @@ using namespace pdm;
 static int pg_span(int k) { return (k / 2 * 2 + PG_TS - 1) / PG_TS + 1; }  // tiles a dilation block can touch per axis
 
 extern "C" size_t pdm_gather_bev_workspace_bytes(int B, int P, int W, int H, int kx, int ky) {
-    if (B <= 0 || P <= 0 || W <= 0 || H <= 0) return 0;
+    // P = 0 still needs the per-tile list starts (zeroed; the gather kernel reads them to write empty tiles).  (Until round 4 this returned
+    // 0 for P = 0: the caller's 16-byte stand-in was then overrun by B (ntiles + 1) ints — unnoticed inside the allocator's 2 MB segment
+    // until the block happened to be the last of one, where hipMemsetAsync refused the range.)
+    if (B <= 0 || P < 0 || W <= 0 || H <= 0) return 0;
     const long long ntiles = (long long)((W + PG_TS - 1) / PG_TS) * ((H + PG_TS - 1) / PG_TS);
     const long long cap = (long long)P * pg_span(kx) * pg_span(ky);
     return (size_t)B * ((size_t)(ntiles + 1) + 2 * (size_t)cap) * sizeof(int) + 64;
@@ -469,7 +472,11 @@ extern "C" int pdm_gather_bev(void *stream, int B, int P, int C, int degree, con
                            ntiles, (int)cap, xyz, tile_start, tile_pts);
     else {
         hipError_t e = hipMemsetAsync(tile_start, 0, (size_t)B * (ntiles + 1) * sizeof(int), as_stream(stream));
-        if (e != hipSuccess) { set_error("pdm_gather_bev: memset failed"); return (int)e; }
+        if (e != hipSuccess) {
+            set_error("pdm_gather_bev: memset of %zu bytes at %p failed: %s", (size_t)B * (ntiles + 1) * sizeof(int), (void *)tile_start, hipGetErrorString(e));
+            (void)hipGetLastError();      // (not to be reported again by the next entry point's launch check)
+            return (int)e;
+        }
     }
     int rc = check_launch("pdm_gather_bev(bin)");
     if (rc) return rc;
